@@ -1,0 +1,131 @@
+// extern "C" surface of libgill_amd (see include/gill_amd.h): error plumbing and the operator-level
+// entry points.  The three stage engines export their own entry points from opt.hip / mapper.hip /
+// unet.hip.
+#include "../../include/gill_amd.h"
+#include "ops.h"
+#include "engine_util.h"
+#include <vector>
+
+static thread_local std::string g_last_error;
+void gill_set_error(const std::string& msg) { g_last_error = msg; }
+
+extern "C" const char* gill_last_error(void) { return g_last_error.c_str(); }
+extern "C" int gill_version(void) { return 100; }
+
+extern "C" int gill_op_gemm(const void* A, const void* W, const float* bias, const void* resid_bf16, void* C, int M, int N,
+                            int K, float alpha, int act, int out_f32, int splitk, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g;
+  g.M = M; g.N = N; g.K = K; g.K1 = K;
+  g.A = (const bf16_t*)A; g.lda = K;
+  g.W = (const bf16_t*)W;
+  g.alpha = alpha; g.bias = bias;
+  g.resid = resid_bf16; g.ldr = N; g.resid_f32 = 0;
+  g.act = act;
+  g.out_mode = out_f32 ? OUT_F32 : OUT_BF16;
+  g.C = C; g.ldc = N;
+  g.splitk = splitk > 0 ? splitk : gemm_pick_splitk(M, N, K, act);
+  DevBuf ws;
+  if (g.splitk > 1) {
+    GILL_TRY(ws.alloc(sizeof(float) * (size_t)g.splitk * M * N));
+    g.ws = (float*)ws.p;
+  }
+  GILL_TRY(gemm_launch(g, s));
+  if (g.splitk > 1) GILL_CHECK_HIP(hipStreamSynchronize(s));  // ws is freed on return
+  return 0;
+}
+
+extern "C" int gill_op_geglu(const void* A, const void* W, const float* bias, void* C, int M, int inner, int K,
+                             void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GILL_REQUIRE(inner % 64 == 0, "geglu: inner dim must be a multiple of 64");
+  DevBuf wperm, bperm, idx;
+  GILL_TRY(wperm.alloc(sizeof(bf16_t) * (size_t)2 * inner * K));
+  GILL_TRY(bperm.alloc(sizeof(float) * (size_t)2 * inner));
+  std::vector<int32_t> map = geglu_row_permutation(inner);
+  GILL_TRY(idx.alloc(sizeof(int32_t) * map.size()));
+  GILL_CHECK_HIP(hipMemcpyAsync(idx.p, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice, s));
+  GILL_TRY(scatter_rows_bf16_launch((const bf16_t*)W, 2 * inner, K, (const int32_t*)idx.p, (bf16_t*)wperm.p, K, s));
+  if (bias) GILL_TRY(permute_f32_launch(bias, (const int32_t*)idx.p, 2 * inner, (float*)bperm.p, s));
+  GemmArgs g;
+  g.M = M; g.N = 2 * inner; g.K = K; g.K1 = K;
+  g.A = (const bf16_t*)A; g.lda = K;
+  g.W = (const bf16_t*)wperm.p;
+  g.bias = bias ? (const float*)bperm.p : nullptr;
+  g.act = ACT_GEGLU; g.out_mode = OUT_BF16;
+  g.C = C; g.ldc = inner;
+  GILL_TRY(gemm_launch(g, s));
+  GILL_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+extern "C" int gill_op_conv3x3(const void* x1, int C1, const void* x2, int C2, const float* w_oihw, const float* bias,
+                               const float* rowvec, const void* resid, void* y, int B, int IH, int IW, int Cout,
+                               int stride, int ups, int splitk, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int Cin = C1 + C2;
+  DevBuf wr, ws;
+  GILL_TRY(wr.alloc(sizeof(bf16_t) * (size_t)Cout * 9 * Cin));
+  GILL_TRY(conv_weight_relayout_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wr.p, s));
+  GemmArgs g;
+  g.conv = 1;
+  g.IH = IH; g.IW = IW; g.Cin = Cin; g.stride = stride; g.ups = ups;
+  if (ups) { g.OH = 2 * IH; g.OW = 2 * IW; }
+  else { g.OH = (IH + 2 - 3) / stride + 1; g.OW = (IW + 2 - 3) / stride + 1; }
+  g.M = B * g.OH * g.OW; g.N = Cout; g.K = 9 * Cin;
+  g.A = (const bf16_t*)x1; g.A2 = (const bf16_t*)x2; g.K1 = C1;
+  g.W = (const bf16_t*)wr.p;
+  g.bias = bias;
+  g.rowvec = rowvec; g.rows_per_batch = g.OH * g.OW; g.rowvec_bstride = Cout;
+  g.resid = resid; g.ldr = Cout;
+  g.C = y; g.ldc = Cout;
+  g.splitk = splitk > 0 ? splitk : gemm_pick_splitk(g.M, g.N, g.K, 0);
+  if (g.splitk > 1) {
+    GILL_TRY(ws.alloc(sizeof(float) * (size_t)g.splitk * g.M * g.N));
+    g.ws = (float*)ws.p;
+  }
+  GILL_TRY(gemm_launch(g, s));
+  GILL_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+extern "C" int gill_op_attention(const void* q, const void* k, const void* v, void* o, int B, int H, int nq, int nkv, int d,
+                                 float scale, int causal, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int dp = attn_padded_dim(d);
+  GILL_REQUIRE(dp > 0, "attention: head dim > 160 unsupported");
+  const int dpv = round_up(dp, 32);
+  const int nq_pad = round_up(nq, 32), nkv_pad = round_up(nkv, 32);
+  DevBuf Q, K, Vt, O;
+  GILL_TRY(Q.alloc_zero(sizeof(bf16_t) * (size_t)B * H * nq_pad * dp, s));
+  GILL_TRY(K.alloc_zero(sizeof(bf16_t) * (size_t)B * H * nkv_pad * dp, s));
+  GILL_TRY(Vt.alloc_zero(sizeof(bf16_t) * (size_t)B * H * dpv * nkv_pad, s));
+  GILL_TRY(O.alloc_zero(sizeof(bf16_t) * (size_t)B * nq * H * dp, s));
+  GILL_TRY(pack_heads_launch((const bf16_t*)q, B, nq, H, d, nq_pad, dp, dpv, 0, (bf16_t*)Q.p, s));
+  GILL_TRY(pack_heads_launch((const bf16_t*)k, B, nkv, H, d, nkv_pad, dp, dpv, 0, (bf16_t*)K.p, s));
+  GILL_TRY(pack_heads_launch((const bf16_t*)v, B, nkv, H, d, nkv_pad, dp, dpv, 1, (bf16_t*)Vt.p, s));
+  AttnArgs a;
+  a.Q = (const bf16_t*)Q.p; a.K = (const bf16_t*)K.p; a.Vt = (const bf16_t*)Vt.p; a.O = (bf16_t*)O.p;
+  a.B = B; a.H = H; a.nq = nq; a.nkv = nkv; a.nq_pad = nq_pad; a.nkv_pad = nkv_pad; a.dp = dp; a.dpv = dpv;
+  a.ldo = H * dp; a.scale = scale; a.causal = causal;
+  GILL_TRY(attention_launch(a, s));
+  GILL_TRY(unpad_heads_launch((const bf16_t*)O.p, (int64_t)B * nq, H, d, dp, (bf16_t*)o, s));
+  GILL_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+extern "C" int gill_op_layernorm(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, int rows,
+                                 int C, float eps, void* stream) {
+  return layernorm_launch(x, x_f32, gamma, beta, (bf16_t*)y_bf16, rows, C, eps, (hipStream_t)stream);
+}
+
+extern "C" int gill_op_groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups,
+                                 const float* gamma, const float* beta, float eps, int silu, void* y, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DevBuf stats;
+  GILL_TRY(stats.alloc(sizeof(float) * 2 * (size_t)groups * B));
+  GILL_TRY(groupnorm_launch((const bf16_t*)x1, C1, (const bf16_t*)x2, C2, B, HW, groups, gamma, beta, eps, silu,
+                            (bf16_t*)y, (float*)stats.p, s));
+  GILL_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}

@@ -1,0 +1,420 @@
+// bf16 MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (CDNA4).
+//
+//   C[M,N] = epilogue(alpha * A[M,K] . W[N,K]^T)
+//
+// Tile: 128 x BN x 64 per 256-thread workgroup (4 waves as 2x2, each wave 64 x BN/2 via
+// v_mfma_f32_16x16x32_bf16).  Both operands are K-contiguous, so both LDS tiles are
+// [rows][64 bf16] = 128 B rows filled by direct-to-LDS DMA (global_load_lds_dwordx4: one
+// wave instruction = 1 KiB = 8 tile rows).  The DMA destination is lane-linear, so the
+// bank-conflict swizzle (16-B slot ^= row&7) is applied on the per-lane SOURCE address and
+// again on the ds_read_b128 address (conflict-free for the 16-lane read groups).
+// The MFMA is issued "swapped" (W fragment as the A operand) so every lane ends up with 4
+// consecutive N columns of one M row: bias/residual/activation run on float4s and the
+// store is 8 B of bf16 per lane.
+//
+// The conv path computes the im2col row pointers on the fly: NHWC activations make each
+// 64-wide K step a contiguous 128-B run inside one (tap, pixel); padding taps read a zero page.
+#include "ops.h"
+
+#define BM 128
+#define BK 64
+#define GEMM_THREADS 256
+
+__device__ __attribute__((aligned(256))) uint32_t g_zero_page_storage[128];
+
+const bf16_t* gill_zero_page() {
+  static const bf16_t* p = nullptr;
+  if (!p) {
+    void* d = nullptr;
+    if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_zero_page_storage)) == hipSuccess) {
+      (void)hipMemset(d, 0, sizeof(uint32_t) * 128);
+      p = (const bf16_t*)d;
+    }
+  }
+  return p;
+}
+
+struct GemmDev {
+  GemmArgs a;
+  const bf16_t* zero;
+  int ksteps;        // K / 64
+  int ksteps_per_split;
+  int tiles_n;
+};
+
+__device__ __noinline__ float gelu_erf_call(float v) { return gelu_erf(v); }  // keeps erff out of the unrolled epilogue
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  if (act == ACT_SILU) return silu_f(v);
+  if (act == ACT_GELU) return gelu_erf_call(v);
+  return v;
+}
+
+// Final epilogue for 4 consecutive columns n..n+3 of row m (n % 4 == 0, n + 3 < N).
+__device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0, float v1, float v2, float v3) {
+  float v[4] = {v0 * p.alpha, v1 * p.alpha, v2 * p.alpha, v3 * p.alpha};
+  if (p.bias) {
+    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (p.rowvec) {
+    const float4 b = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_bstride + n);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (p.resid) {
+    if (p.resid_f32) {
+      const float4 r = *reinterpret_cast<const float4*>((const float*)p.resid + (size_t)m * p.ldr + n);
+      v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    } else {
+      const uint2 r = *reinterpret_cast<const uint2*>((const bf16_t*)p.resid + (size_t)m * p.ldr + n);
+      v[0] += bf2f((bf16_t)(r.x & 0xffff)); v[1] += bf2f((bf16_t)(r.x >> 16));
+      v[2] += bf2f((bf16_t)(r.y & 0xffff)); v[3] += bf2f((bf16_t)(r.y >> 16));
+    }
+  }
+  if (p.act != ACT_NONE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], p.act);
+  }
+  if (p.out_mode == OUT_BF16) {
+    uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+    *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+  } else if (p.out_mode == OUT_F32) {
+    *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {  // OUT_QKV
+    const int hd = p.heads * p.dp;
+    const int seg = p.seg_base + n / hd;
+    const int within = n % hd;
+    const int h = within / p.dp, dd = within % p.dp;
+    const int b = m / p.ntok, t = m % p.ntok;
+    if (seg == 0) {
+      uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(p.Cq + ((size_t)(b * p.heads + h) * p.ntok_pad_q + t) * p.dp + dd) = o;
+    } else if (seg == 1) {
+      uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(p.Ck + ((size_t)(b * p.heads + h) * p.ntok_pad_kv + t) * p.dp + dd) = o;
+    } else {
+      bf16_t* base = p.Cvt + ((size_t)(b * p.heads + h) * p.dpv + dd) * p.ntok_pad_kv + t;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) base[(size_t)i * p.ntok_pad_kv] = f2bf(v[i]);
+    }
+  }
+}
+
+// EPI: 0 = row-major / QKV epilogue through store4, 1 = GEGLU, 2 = raw fp32 split-K partials
+template <int BN, bool CONV, int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
+  constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  // layout: [buf][A tile 128*64 | B tile BN*64]
+  constexpr int A_ELEMS = BM * BK;
+  constexpr int B_ELEMS = BN * BK;
+  constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
+
+  const GemmArgs& p = d.a;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x;
+  const int tn = tile % d.tiles_n;
+  const int tm = tile / d.tiles_n;
+  const int m0 = tm * BM;
+  const int n0 = tn * BN;
+  const int z = blockIdx.y;
+  const int kt_beg = z * d.ksteps_per_split;
+  int kt_end = kt_beg + d.ksteps_per_split;
+  if (kt_end > d.ksteps) kt_end = d.ksteps;
+  const int nsteps = kt_end - kt_beg;
+
+  // ---- per-lane staging geometry: instruction i of wave w fills tile rows (i*4+w)*8 .. +8
+  const int srow = lane >> 3;                 // row within the 8-row group == (tile row & 7)
+  const int schunk = (lane & 7) ^ srow;       // logical 16-B chunk this lane fetches (source-side swizzle)
+
+  // A rows (4 per lane).  plain: element offsets of the row start in each source.
+  // conv: centre input pixel index + flag bits {1: dy=-1 in range, 2: dy=+1, 4: dx=-1, 8: dx=+1,
+  // 16: oy odd, 32: ox odd} (the parity bits drive the fused nearest-2x upsample).
+  int a_off1[4], a_off2[4];
+  int a_pc[4], a_fl[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = (i * 4 + w) * 8 + srow;
+    int m = m0 + row;
+    if (m > p.M - 1) m = p.M - 1;
+    a_off1[i] = a_off2[i] = a_pc[i] = a_fl[i] = 0;
+    if constexpr (!CONV) {
+      a_off1[i] = m * p.lda + schunk * 8;
+      a_off2[i] = m * p.lda2 + schunk * 8;
+    } else {
+      const int ohw = p.OH * p.OW;
+      const int b = m / ohw;
+      const int r = m - b * ohw;
+      const int oy = r / p.OW;
+      const int ox = r - oy * p.OW;
+      int fl = 0;
+      if (p.ups) {
+        a_pc[i] = (b * p.IH + (oy >> 1)) * p.IW + (ox >> 1);
+        fl |= (oy - 1 >= 0) ? 1 : 0; fl |= (oy + 1 < p.OH) ? 2 : 0;
+        fl |= (ox - 1 >= 0) ? 4 : 0; fl |= (ox + 1 < p.OW) ? 8 : 0;
+        fl |= (oy & 1) << 4; fl |= (ox & 1) << 5;
+      } else {
+        const int cy = oy * p.stride, cx = ox * p.stride;
+        a_pc[i] = (b * p.IH + cy) * p.IW + cx;
+        fl |= (cy - 1 >= 0) ? 1 : 0; fl |= (cy + 1 < p.IH) ? 2 : 0;
+        fl |= (cx - 1 >= 0) ? 4 : 0; fl |= (cx + 1 < p.IW) ? 8 : 0;
+      }
+      a_fl[i] = fl;
+    }
+  }
+  // W rows: BN/32 instructions per wave (BN rows / 8 rows per instr / 4 waves)
+  constexpr int WI = BN / 32;
+  const bf16_t* w_ptr[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    int row = (i * 4 + w) * 8 + srow;
+    int n = n0 + row;
+    if (n > p.N - 1) n = p.N - 1;
+    w_ptr[i] = p.W + (size_t)n * p.K + schunk * 8;
+  }
+  const bf16_t* zero_lane = d.zero + schunk * 8;
+
+  auto issue = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+    bf16_t* As = smem + buf * BUF_ELEMS;
+    bf16_t* Bs = As + A_ELEMS;
+    if constexpr (!CONV) {
+      const bool first = (k0 < p.K1);
+      const bf16_t* src = first ? p.A : p.A2;
+      const int kk = first ? k0 : k0 - p.K1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16_t* g = src + (first ? a_off1[i] : a_off2[i]) + kk;
+        bf16_t* l = As + (i * 4 + w) * 8 * BK;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+      }
+    } else {
+      const int tap = k0 / p.Cin;
+      const int c0 = k0 - tap * p.Cin;
+      const int ty = tap / 3;
+      const int dy = ty - 1, dx = tap - ty * 3 - 1;
+      const int need = (dy < 0 ? 1 : (dy > 0 ? 2 : 0)) | (dx < 0 ? 4 : (dx > 0 ? 8 : 0));
+      const bool first = (c0 < p.K1);
+      const bf16_t* src = first ? p.A : p.A2;
+      const int cs = first ? p.K1 : (p.Cin - p.K1);
+      const int cc = (first ? c0 : c0 - p.K1) + schunk * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int ddy = dy, ddx = dx;
+        if (p.ups) { ddy = (dy + ((a_fl[i] >> 4) & 1)) >> 1; ddx = (dx + ((a_fl[i] >> 5) & 1)) >> 1; }
+        const bool ok = (a_fl[i] & need) == need;
+        const int pix = a_pc[i] + ddy * p.IW + ddx;
+        const bf16_t* g = src + (size_t)(ok ? pix : 0) * cs + cc;
+        g = ok ? g : zero_lane;
+        bf16_t* l = As + (i * 4 + w) * 8 * BK;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const bf16_t* g = w_ptr[i] + k0;
+      bf16_t* l = Bs + (i * 4 + w) * 8 * BK;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int wm = w >> 1, wn = w & 1;
+  const int frow = lane & 15;       // fragment row within a 16-row sub-tile
+  const int fkc = lane >> 4;        // 16-B k chunk within the 32-wide MFMA k step
+
+  if (nsteps > 0) issue(kt_beg, 0);
+  for (int it = 0; it < nsteps; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 1 < nsteps) issue(kt_beg + it + 1, (it + 1) & 1);
+    const bf16_t* As = smem + (it & 1) * BUF_ELEMS;
+    const bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[4];
+      bf16x8 bfr[NT];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + frow;
+        const int slot = (kk * 4 + fkc) ^ (row & 7);
+        af[i] = *reinterpret_cast<const bf16x8*>(As + row * BK + slot * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int row = wn * (BN / 2) + j * 16 + frow;
+        const int slot = (kk * 4 + fkc) ^ (row & 7);
+        bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * BK + slot * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue.  acc[i][j][r]: m = m0 + wm*64 + i*16 + (lane&15), n = n0 + wn*BN/2 + j*16 + (lane>>4)*4 + r
+  const int mrow = m0 + wm * 64 + frow;
+  const int ncol = n0 + wn * (BN / 2) + fkc * 4;
+  if constexpr (EPI == 2) {
+    float* ws = p.ws + (size_t)z * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mrow + i * 16;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = ncol + j * 16;
+        if (n >= p.N) continue;
+        *reinterpret_cast<float4*>(ws + (size_t)m * p.N + n) =
+            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+  } else if constexpr (EPI == 1) {
+    // weight rows are interleaved in 16-row blocks: even block = value rows, odd block = gate rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mrow + i * 16;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j + 1 < NT; j += 2) {
+        const int nv = ncol + j * 16;         // physical column of the value block
+        const int ng = nv + 16;               // physical column of the gate block
+        if (ng >= p.N) continue;
+        const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + nv) : make_float4(0, 0, 0, 0);
+        const float4 bg = p.bias ? *reinterpret_cast<const float4*>(p.bias + ng) : make_float4(0, 0, 0, 0);
+        const float o0 = (acc[i][j][0] + bv.x) * gelu_erf(acc[i][j + 1][0] + bg.x);
+        const float o1 = (acc[i][j][1] + bv.y) * gelu_erf(acc[i][j + 1][1] + bg.y);
+        const float o2 = (acc[i][j][2] + bv.z) * gelu_erf(acc[i][j + 1][2] + bg.z);
+        const float o3 = (acc[i][j][3] + bv.w) * gelu_erf(acc[i][j + 1][3] + bg.w);
+        const int no = (nv >> 5) * 16 + (nv & 15);  // logical output column
+        uint2 o; o.x = pack_bf2(o0, o1); o.y = pack_bf2(o2, o3);
+        *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + no) = o;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mrow + i * 16;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = ncol + j * 16;
+        if (n >= p.N) continue;
+        store4(p, m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+  }
+}
+
+// split-K reduction + epilogue
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs p) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
+  const int nq = p.N / 4;
+  if (q >= (int64_t)p.M * nq) return;
+  const int m = (int)(q / nq);
+  const int n = (int)(q - (int64_t)m * nq) * 4;
+  float4 s = make_float4(0, 0, 0, 0);
+  for (int z = 0; z < p.splitk; ++z) {
+    const float4 v = *reinterpret_cast<const float4*>(p.ws + ((size_t)z * p.M + m) * p.N + n);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  store4(p, m, n, s.x, s.y, s.z, s.w);
+}
+
+int gemm_pick_splitk(int M, int N, int K, int act) {
+  if (act == ACT_GEGLU) return 1;
+  const int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
+  const int tiles = cdiv(M, BM) * cdiv(N, bn);
+  const int ksteps = K / BK;
+  if (tiles >= 192 || ksteps < 8) return 1;
+  int s = 512 / tiles;              // aim for ~2 blocks per CU
+  if (s > ksteps / 4) s = ksteps / 4;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  return s;
+}
+
+template <int BN, bool CONV, int EPI>
+static int gemm_launch_inst(const GemmDev& d, dim3 grid, hipStream_t s) {
+  static bool attr_set = false;
+  constexpr int smem = 2 * (BM * BK + BN * BK) * (int)sizeof(bf16_t);
+  if (!attr_set) {
+    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<BN, CONV, EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<BN, CONV, EPI>), grid, dim3(GEMM_THREADS), smem, s, d);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int BN>
+static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
+  GemmDev d;
+  d.a = a;
+  d.zero = gill_zero_page();
+  GILL_REQUIRE(d.zero != nullptr, "zero page unavailable");
+  d.ksteps = a.K / BK;
+  const int sk = a.splitk > 1 ? a.splitk : 1;
+  d.a.splitk = sk;
+  d.ksteps_per_split = cdiv(d.ksteps, sk);
+  d.tiles_n = cdiv(a.N, BN);
+  const int tiles_m = cdiv(a.M, BM);
+  dim3 grid(tiles_m * d.tiles_n, sk, 1);
+  if (a.conv) {
+    if (sk > 1) GILL_TRY((gemm_launch_inst<BN, true, 2>(d, grid, s)));
+    else GILL_TRY((gemm_launch_inst<BN, true, 0>(d, grid, s)));
+  } else {
+    if (sk > 1) GILL_TRY((gemm_launch_inst<BN, false, 2>(d, grid, s)));
+    else if (a.act == ACT_GEGLU) GILL_TRY((gemm_launch_inst<BN, false, 1>(d, grid, s)));
+    else GILL_TRY((gemm_launch_inst<BN, false, 0>(d, grid, s)));
+  }
+  if (sk > 1) {
+    const int64_t n4 = (int64_t)a.M * (a.N / 4);
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, s, d.a);
+    GILL_CHECK_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+int gemm_launch(const GemmArgs& a, hipStream_t s) {
+  GILL_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "empty GEMM");
+  GILL_REQUIRE((int64_t)a.M * (a.lda > a.N ? a.lda : a.N) < (int64_t)1 << 31, "GEMM operand too large for 32-bit offsets");
+  GILL_REQUIRE(a.K % BK == 0, "K must be a multiple of 64");
+  GILL_REQUIRE(a.N % 4 == 0, "N must be a multiple of 4");
+  GILL_REQUIRE(a.A != nullptr && a.W != nullptr, "null operand");
+  if (a.conv) {
+    GILL_REQUIRE(a.Cin % BK == 0 && a.K == 9 * a.Cin, "conv: Cin must be a multiple of 64 and K == 9*Cin");
+    GILL_REQUIRE(a.K1 % BK == 0 && a.K1 <= a.Cin, "conv: source split must be a multiple of 64");
+    GILL_REQUIRE(a.K1 == a.Cin || a.A2 != nullptr, "conv: second source missing");
+    GILL_REQUIRE(!(a.ups && a.stride != 1), "conv: upsample needs stride 1");
+  } else {
+    GILL_REQUIRE(a.K1 % BK == 0 && a.K1 <= a.K, "K split must be a multiple of 64");
+    GILL_REQUIRE(a.K1 == a.K || a.A2 != nullptr, "second A source missing");
+  }
+  if (a.splitk > 1) {
+    GILL_REQUIRE(a.ws != nullptr, "split-K workspace missing");
+    GILL_REQUIRE(a.act != ACT_GEGLU, "split-K cannot be combined with GEGLU");
+  }
+  if (a.act == ACT_GEGLU) {
+    GILL_REQUIRE(a.N % 128 == 0 && a.out_mode == OUT_BF16, "GEGLU needs N % 128 == 0 and bf16 row-major output");
+    return gemm_launch_bn<128>(a, s);
+  }
+  if (a.out_mode == OUT_QKV) GILL_REQUIRE(a.dp % 4 == 0 && a.heads > 0 && a.ntok > 0, "bad QKV scatter geometry");
+  if (a.N % 160 == 0 && a.N % 128 != 0) return gemm_launch_bn<160>(a, s);
+  return gemm_launch_bn<128>(a, s);
+}

@@ -1,0 +1,216 @@
+// LayerNorm and GroupNorm(+SiLU) for gfx950: HBM-bound row reductions on 64-lane wavefronts
+// (shuffle trees, no LDS for LayerNorm), 16-byte vector loads, fp32 statistics.
+#include "ops.h"
+
+// ---------------------------------------------------------------- LayerNorm
+// one wave per row; C % 8 == 0
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, TOUT* __restrict__ y,
+                                                        int rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const TIN* xr = x + (size_t)row * C;
+  float s = 0.f, ss = 0.f;
+  for (int c = lane * 8; c < C; c += 64 * 8) {
+    float v[8];
+    if constexpr (sizeof(TIN) == 2) {
+      const uint4 u = *reinterpret_cast<const uint4*>(xr + c);
+      const uint32_t uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[2 * i] = bf2f((bf16_t)(uu[i] & 0xffff)); v[2 * i + 1] = bf2f((bf16_t)(uu[i] >> 16)); }
+    } else {
+      const float4 a = *reinterpret_cast<const float4*>(xr + c);
+      const float4 bq = *reinterpret_cast<const float4*>(xr + c + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s += v[i]; }
+  }
+  s = wave_sum(s);
+  const float mean = s / (float)C;
+  // second pass for the variance (two-pass: no cancellation; the row is L1/L2 resident)
+  for (int c = lane * 8; c < C; c += 64 * 8) {
+    float v[8];
+    if constexpr (sizeof(TIN) == 2) {
+      const uint4 u = *reinterpret_cast<const uint4*>(xr + c);
+      const uint32_t uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[2 * i] = bf2f((bf16_t)(uu[i] & 0xffff)); v[2 * i + 1] = bf2f((bf16_t)(uu[i] >> 16)); }
+    } else {
+      const float4 a = *reinterpret_cast<const float4*>(xr + c);
+      const float4 bq = *reinterpret_cast<const float4*>(xr + c + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float dlt = v[i] - mean; ss += dlt * dlt; }
+  }
+  ss = wave_sum(ss);
+  const float rstd = rsqrtf(ss / (float)C + eps);
+  TOUT* yr = y + (size_t)row * C;
+  for (int c = lane * 8; c < C; c += 64 * 8) {
+    float v[8];
+    if constexpr (sizeof(TIN) == 2) {
+      const uint4 u = *reinterpret_cast<const uint4*>(xr + c);
+      const uint32_t uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[2 * i] = bf2f((bf16_t)(uu[i] & 0xffff)); v[2 * i + 1] = bf2f((bf16_t)(uu[i] >> 16)); }
+    } else {
+      const float4 a = *reinterpret_cast<const float4*>(xr + c);
+      const float4 bq = *reinterpret_cast<const float4*>(xr + c + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
+    }
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 g1 = *reinterpret_cast<const float4*>(gamma + c + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + c);
+    const float4 b1 = *reinterpret_cast<const float4*>(beta + c + 4);
+    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (v[i] - mean) * rstd * g[i] + bb[i];
+    if constexpr (sizeof(TOUT) == 2) {
+      uint4 u;
+      u.x = pack_bf2(o[0], o[1]); u.y = pack_bf2(o[2], o[3]); u.z = pack_bf2(o[4], o[5]); u.w = pack_bf2(o[6], o[7]);
+      *reinterpret_cast<uint4*>(yr + c) = u;
+    } else {
+      *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(yr + c + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+  }
+}
+
+int layernorm_launch(const void* x, int x_f32, const float* gamma, const float* beta, bf16_t* y, int rows, int C,
+                     float eps, hipStream_t s) {
+  GILL_REQUIRE(C % 8 == 0 && rows > 0, "layernorm: C must be a multiple of 8");
+  dim3 grid(cdiv(rows, 4)), block(256);
+  if (x_f32)
+    hipLaunchKernelGGL((layernorm_kernel<float, bf16_t>), grid, block, 0, s, (const float*)x, gamma, beta, y, rows, C, eps);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, gamma, beta, y, rows, C, eps);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int layernorm_f32out_launch(const void* x, int x_f32, const float* gamma, const float* beta, float* y, int rows, int C,
+                            float eps, hipStream_t s) {
+  GILL_REQUIRE(C % 8 == 0 && rows > 0, "layernorm: C must be a multiple of 8");
+  dim3 grid(cdiv(rows, 4)), block(256);
+  if (x_f32)
+    hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, s, (const float*)x, gamma, beta, y, rows, C, eps);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)x, gamma, beta, y, rows, C, eps);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- GroupNorm over NHWC
+// Logical input x[b][p][c], c in [0, C1+C2): channels < C1 come from x1, the rest from x2.
+// Pass 1 (stats): each block owns (b, a slab of GN_ROWS pixels); a thread owns a pair of
+// adjacent channels (4-byte loads, coalesced across the row) and walks the slab's pixels;
+// per-group partial (sum, sumsq) are reduced through LDS and added atomically into stats.
+// The mean is shifted by the first pixel's value of the group to tame E[x^2]-E[x]^2
+// cancellation: stats hold sums of (x - ref[b][g]) with ref = bf16 value at pixel 0.
+#define GN_ROWS 64
+
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __restrict__ x1, int C1,
+                                                              const bf16_t* __restrict__ x2, int C2, int HW,
+                                                              int groups, float* __restrict__ stats) {
+  __shared__ float red[2 * 64];  // up to 64 groups
+  const int C = C1 + C2;
+  const int cg = C / groups;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * GN_ROWS;
+  int p1 = p0 + GN_ROWS;
+  if (p1 > HW) p1 = HW;
+  for (int i = threadIdx.x; i < 2 * groups; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  for (int cp = threadIdx.x; cp < C / 2; cp += blockDim.x) {
+    const int c = cp * 2;
+    const bf16_t* src; int cs, cc;
+    if (c < C1) { src = x1; cs = C1; cc = c; } else { src = x2; cs = C2; cc = c - C1; }
+    const bf16_t* base = src + (size_t)b * HW * cs + cc;
+    // reference value: pixel 0 of the first channel of each channel's group
+    const int g0 = c / cg, g1 = (c + 1) / cg;
+    float ref0, ref1;
+    {
+      const int cr0 = g0 * cg, cr1 = g1 * cg;
+      ref0 = (cr0 < C1) ? bf2f(x1[(size_t)b * HW * C1 + cr0]) : bf2f(x2[(size_t)b * HW * C2 + (cr0 - C1)]);
+      ref1 = (cr1 < C1) ? bf2f(x1[(size_t)b * HW * C1 + cr1]) : bf2f(x2[(size_t)b * HW * C2 + (cr1 - C1)]);
+    }
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    for (int p = p0; p < p1; ++p) {
+      const uint32_t u = *reinterpret_cast<const uint32_t*>(base + (size_t)p * cs);
+      const float a = bf2f((bf16_t)(u & 0xffff)) - ref0;
+      const float bq = bf2f((bf16_t)(u >> 16)) - ref1;
+      s0 += a; q0 += a * a; s1 += bq; q1 += bq * bq;
+    }
+    atomicAdd(&red[2 * g0], s0); atomicAdd(&red[2 * g0 + 1], q0);
+    atomicAdd(&red[2 * g1], s1); atomicAdd(&red[2 * g1 + 1], q1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * groups; i += blockDim.x) atomicAdd(&stats[(size_t)b * groups * 2 + i], red[i]);
+}
+
+// Pass 2: normalize + affine (+ SiLU), 8 channels (16 B) per thread.  cg % 2 == 0 is enough:
+// channel pairs never straddle a group.
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __restrict__ x1, int C1,
+                                                              const bf16_t* __restrict__ x2, int C2, int HW, int groups,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, int silu,
+                                                              const float* __restrict__ stats, bf16_t* __restrict__ y,
+                                                              int64_t total_vec) {
+  const int C = C1 + C2;
+  const int cg = C / groups;
+  const int vec_per_row = C / 8;
+  const float inv_n = 1.f / ((float)cg * (float)HW);
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total_vec; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = v / vec_per_row;             // b*HW + p
+    const int c = (int)(v - row * vec_per_row) * 8;
+    const int b = (int)(row / HW);
+    const bf16_t* src;
+    if (c < C1) src = x1 + row * C1 + c; else src = x2 + row * C2 + (c - C1);
+    const uint4 u = *reinterpret_cast<const uint4*>(src);
+    const uint32_t uu[4] = {u.x, u.y, u.z, u.w};
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = c + 2 * i;
+      const int g = ch / cg;
+      const int cr = g * cg;
+      const float ref = (cr < C1) ? bf2f(x1[(size_t)b * HW * C1 + cr]) : bf2f(x2[(size_t)b * HW * C2 + (cr - C1)]);
+      const float sm = stats[((size_t)b * groups + g) * 2] * inv_n;         // mean of (x - ref)
+      const float sq = stats[((size_t)b * groups + g) * 2 + 1] * inv_n;     // mean of (x - ref)^2
+      const float var = fmaxf(sq - sm * sm, 0.f);
+      const float rstd = rsqrtf(var + eps);
+      const float mean = sm + ref;
+      float a = (bf2f((bf16_t)(uu[i] & 0xffff)) - mean) * rstd * gamma[ch] + beta[ch];
+      float bq = (bf2f((bf16_t)(uu[i] >> 16)) - mean) * rstd * gamma[ch + 1] + beta[ch + 1];
+      if (silu) { a = silu_f(a); bq = silu_f(bq); }
+      o[2 * i] = a; o[2 * i + 1] = bq;
+    }
+    uint4 w;
+    w.x = pack_bf2(o[0], o[1]); w.y = pack_bf2(o[2], o[3]); w.z = pack_bf2(o[4], o[5]); w.w = pack_bf2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(y + row * C + c) = w;
+  }
+}
+
+int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups, const float* gamma,
+                     const float* beta, float eps, int silu, bf16_t* y, float* stats, hipStream_t s) {
+  const int C = C1 + C2;
+  GILL_REQUIRE(groups <= 64 && C % groups == 0 && (C / groups) % 2 == 0, "groupnorm: channels/group must be even");
+  GILL_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "groupnorm: channel counts must be multiples of 8");
+  GILL_REQUIRE(C2 == 0 || x2 != nullptr, "groupnorm: second source missing");
+  GILL_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(float) * 2 * groups * B, s));
+  dim3 g1(cdiv(HW, GN_ROWS), B);
+  hipLaunchKernelGGL(groupnorm_stats_kernel, g1, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, stats);
+  GILL_CHECK_HIP(hipGetLastError());
+  const int64_t total_vec = (int64_t)B * HW * (C / 8);
+  int blocks = (int)((total_vec + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(blocks), dim3(256), 0, s, x1, C1, x2, C2, HW, groups, gamma, beta, eps,
+                     silu, stats, y, total_vec);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}

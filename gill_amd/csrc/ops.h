@@ -1,0 +1,122 @@
+// Internal C++ operator layer of libgill_amd: every hot op of the generate_images path as a
+// stream-ordered launcher.  The engines (opt.hip / mapper.hip / unet.hip) are sequences of
+// these launches; capi.hip re-exports a subset 1:1 for the operator-level parity tests.
+#pragma once
+#include "common.h"
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_GEGLU = 4 };
+enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_QKV = 2 };
+
+// C[M,N] = epilogue( alpha * A[M,K] . W[N,K]^T )       (bf16 operands, fp32 MFMA accumulate)
+//  A is either a plain row-major matrix (optionally the K-concatenation of two matrices) or the
+//  implicit im2col view of an NHWC tensor for a 3x3 / pad 1 convolution (stride 1|2, optional
+//  fused nearest-2x upsample, optional channel-concatenation of two NHWC tensors).
+struct GemmArgs {
+  int M = 0, N = 0, K = 0;
+  const bf16_t* A = nullptr;  int lda = 0;
+  const bf16_t* A2 = nullptr; int lda2 = 0;
+  int K1 = 0;                 // plain: columns taken from A (K1 == K when single source); conv: channels of A
+  int conv = 0;               // 0 plain GEMM, 1 conv3x3 pad 1 over NHWC
+  int IH = 0, IW = 0, OH = 0, OW = 0, Cin = 0, stride = 1, ups = 0;
+  const bf16_t* W = nullptr;  // [N][K], K contiguous (conv: k = tap*Cin + c)
+  float alpha = 1.f;
+  const float* bias = nullptr;
+  const float* rowvec = nullptr; int rows_per_batch = 1; int rowvec_bstride = 0;  // + rowvec[(m/rows_per_batch)*bstride + n]
+  const void* resid = nullptr; int ldr = 0; int resid_f32 = 0;
+  int act = ACT_NONE;
+  int out_mode = OUT_BF16;
+  void* C = nullptr; int ldc = 0;
+  // OUT_QKV: scatter into head-major attention operands.
+  //   segment = seg_base + n / (heads*dp): 0 -> Q[b][h][t][dp], 1 -> K[b][h][t][dp], 2 -> Vt[b][h][dd][t]
+  bf16_t* Cq = nullptr; bf16_t* Ck = nullptr; bf16_t* Cvt = nullptr;
+  int heads = 0, dp = 0, dpv = 0, ntok = 0, ntok_pad_q = 0, ntok_pad_kv = 0, seg_base = 0;
+  // split-K (0/1 = off).  ws must hold splitk*M*N floats.
+  int splitk = 1; float* ws = nullptr;
+};
+int gemm_launch(const GemmArgs& a, hipStream_t s);
+// heuristic split-K factor for under-filled grids
+int gemm_pick_splitk(int M, int N, int K, int act);
+
+// Flash-style attention over head-major operands (see GemmArgs OUT_QKV):
+//   Q [B][H][nq_pad][dp], K [B][H][nkv_pad][dp], Vt [B][H][dpv][nkv_pad]  ->  O [B*nq][H*dp] (token-major)
+struct AttnArgs {
+  const bf16_t* Q = nullptr; const bf16_t* K = nullptr; const bf16_t* Vt = nullptr; bf16_t* O = nullptr;
+  int B = 0, H = 0, nq = 0, nkv = 0, nq_pad = 0, nkv_pad = 0, dp = 0, dpv = 0;
+  int ldo = 0;          // row stride of O in elements (>= H*dp)
+  float scale = 1.f;
+  int causal = 0;
+  int kv_bstride_zero = 0;  // 1: K/Vt have a single batch entry shared by every b (learned queries etc.)
+};
+int attention_launch(const AttnArgs& a, hipStream_t s);
+
+// LayerNorm over the last dim (eps inside sqrt), fp32 or bf16 rows in, bf16 rows out.
+int layernorm_launch(const void* x, int x_f32, const float* gamma, const float* beta, bf16_t* y,
+                     int rows, int C, float eps, hipStream_t s);
+// same but fp32 output (used for the final norms whose result is returned to the caller)
+int layernorm_f32out_launch(const void* x, int x_f32, const float* gamma, const float* beta, float* y,
+                            int rows, int C, float eps, hipStream_t s);
+
+// GroupNorm (+ optional SiLU) over NHWC bf16, input = channel-concat of up to two tensors.
+//   stats: [B][groups][2] fp32 scratch (zeroed inside).
+int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups,
+                     const float* gamma, const float* beta, float eps, int silu, bf16_t* y,
+                     float* stats, hipStream_t s);
+
+// ---- small elementwise / gather kernels ----
+int embed_tokens_launch(const int64_t* ids, const bf16_t* table, int vocab, const bf16_t* pos_table, int pos_offset,
+                        int B, int T, int D, float* out_f32, hipStream_t s);
+int gather_rows_launch(const void* src, int src_f32, const int32_t* row_idx, int nrows, int D, void* dst, int dst_f32,
+                       hipStream_t s);
+int add_cast_launch(const void* a, int a_f32, const void* b, int b_f32, int64_t n, int64_t b_period, bf16_t* out,
+                    hipStream_t s);  // out = bf16(a + b[i % b_period])
+int cast_f32_to_bf16_launch(const float* x, bf16_t* y, int64_t n, hipStream_t s);
+int cast_bf16_to_f32_launch(const bf16_t* x, float* y, int64_t n, hipStream_t s);
+int timestep_embed_launch(const float* t, int n, int dim, bf16_t* out, hipStream_t s);  // [n][dim] = [cos | sin]
+int silu_bf16_launch(const bf16_t* x, bf16_t* y, int64_t n, hipStream_t s);
+// conv_in: NCHW fp32 (B,Cin,H,W) -> NHWC bf16 (B,H,W,Cout), 3x3 pad 1, direct (Cin tiny)
+int conv_in_launch(const float* x, const bf16_t* w /*[Cout][9][Cin]*/, const float* bias, int B, int Cin, int H, int W,
+                   int Cout, bf16_t* y, hipStream_t s);
+// conv_out: NHWC bf16 (B,H,W,Cin) -> NCHW fp32 (B,Cout,H,W), 3x3 pad 1, direct (Cout tiny)
+int conv_out_launch(const bf16_t* x, const bf16_t* w /*[Cout][9][Cin]*/, const float* bias, int B, int Cin, int H, int W,
+                    int Cout, float* y, hipStream_t s);
+// skinny GEMV-ish: out[M][N] (f32) = x[M][K] (bf16) . W[N][K]^T ; M <= 8, any N (lm_head)
+int skinny_gemm_launch(const bf16_t* x, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s);
+// classifier-free guidance + PLMS update on fp32 NCHW latents (see unet.hip for the coefficient layout)
+struct PlmsStepArgs {
+  const float* eps;      // [2B][n] : uncond rows then cond rows
+  float* lat;            // [B][n] in/out
+  float* cur_sample;     // [B][n] saved sample (PLMS warm-up)
+  float* ets;            // [4][B][n] ring of past eps'
+  int B; int64_t n;      // n = C*H*W per sample
+  float guidance;
+  int mode;              // 0: first step, 1: repeated step, 2..4: multistep orders
+  int slot_new;          // ring slot to write the new guided eps into (-1: don't store)
+  int s1, s2, s3;        // ring slots of ets[-2], ets[-3], ets[-4] where needed (ets[-1] = new / slot of last)
+  float sample_coeff, eps_coeff;   // x_prev = sample_coeff * sample - eps_coeff * eps'
+};
+int plms_step_launch(const PlmsStepArgs& a, hipStream_t s);
+// weight re-layout helpers (run once at engine creation)
+int conv_weight_relayout_launch(const void* w, int dtype, int Cout, int Cin, bf16_t* out /*[Cout][9][Cin]*/, hipStream_t s);
+int convert_to_bf16_launch(const void* src, int dtype, int64_t n, bf16_t* dst, hipStream_t s);
+int convert_to_f32_launch(const void* src, int dtype, int64_t n, float* dst, hipStream_t s);
+// copy rows of a [rows][cols] matrix into a (possibly wider/padded/permuted) destination:
+//   dst[dst_row_of(r)][0..cols) = src[r][0..cols)   with dst_row index list on device
+int scatter_rows_bf16_launch(const bf16_t* src, int rows, int cols, const int32_t* dst_rows, bf16_t* dst, int dst_ld,
+                             hipStream_t s);
+
+int permute_f32_launch(const float* src, const int32_t* idx, int n, float* dst, hipStream_t s);
+int pack_heads_launch(const bf16_t* src, int B, int n, int H, int d, int n_pad, int dp, int dpv, int mode, bf16_t* dst,
+                      hipStream_t s);
+int unpad_heads_launch(const bf16_t* src, int64_t rows, int H, int d, int dp, bf16_t* dst, hipStream_t s);
+
+// padded head dim used by the attention kernel for a true head dim d (0 = unsupported)
+static inline int attn_padded_dim(int d) {
+  if (d <= 48) return 48;
+  if (d <= 64) return 64;
+  if (d <= 80) return 80;
+  if (d <= 128) return 128;
+  if (d <= 160) return 160;
+  return 0;
+}
+
+const bf16_t* gill_zero_page();   // >= 256 B of device zeros

@@ -1,0 +1,173 @@
+/* libgill_amd — C ABI of the MI355X-native GILL image-generation hot path.
+ *
+ * The reference (kohjingyu/gill) has no FFI seam: its "operator API" is the Python class surface
+ * gill.models.{load_gill, GILL, GILLModel} + gill.layers.TextFcLayer, and every FLOP runs inside
+ * transformers/diffusers/torch.  This header is the boundary the Python mirror (gill_amd/) binds
+ * with ctypes; each entry point names the reference call it replaces.
+ *
+ * Conventions
+ *  - All data pointers are DEVICE pointers borrowed for the duration of the call (torch tensors'
+ *    data_ptr()); the caller allocates every output.  Exceptions are marked "host".
+ *  - Work is enqueued on the caller-supplied stream (a hipStream_t passed as void*; NULL = the
+ *    default stream).  Nothing synchronises the device unless stated.
+ *  - Every function returns 0 on success; on failure a negative code, with a thread-local message
+ *    retrievable through gill_last_error().  No C++ exception crosses this boundary.
+ *  - bf16 tensors are raw uint16 bit patterns.  Shapes are row-major, last index fastest.
+ *  - Handles are not re-entrant (the reference serialises requests: demo/app_gradio.py:217).
+ */
+#ifndef GILL_AMD_H
+#define GILL_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GILL_DTYPE_BF16 0
+#define GILL_DTYPE_F32 1
+#define GILL_DTYPE_F16 2
+
+/* One named weight tensor (state-dict entry).  `data` is a device pointer; it is copied /
+ * re-laid-out into handle-owned HBM during *_create and not referenced afterwards. */
+typedef struct {
+  const char* name;
+  const void* data;
+  int32_t dtype; /* GILL_DTYPE_* */
+  int32_t ndim;
+  int64_t shape[4];
+} gill_tensor;
+
+const char* gill_last_error(void);
+int gill_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage 1 — frozen OPT decoder.  Replaces self.lm(inputs_embeds=..., output_hidden_states=True)
+ * of transformers OPTForCausalLM at gill/models.py:363-365 (batched) and :465 (generate loop).
+ * State-dict names are those of OPTForCausalLM ("model.decoder.layers.N.self_attn.q_proj.weight").
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gill_opt gill_opt;
+typedef struct {
+  int32_t vocab_size;   /* rows of embed_tokens after resize_token_embeddings (models.py:73) */
+  int32_t hidden_size;  /* == word_embed_proj_dim (no project_in/out: every OPT but 350m) */
+  int32_t num_layers;
+  int32_t num_heads;
+  int32_t ffn_dim;
+  int32_t max_positions; /* 2048; learned positions carry the +2 offset */
+  int32_t max_batch;     /* workspace sizing */
+  int32_t max_seq;
+} gill_opt_config;
+
+int gill_opt_create(gill_opt** out, const gill_opt_config* cfg, const gill_tensor* weights, int n_weights);
+void gill_opt_destroy(gill_opt* h);
+
+/* input_embeddings(ids): models.py:180 / :620.  ids (B*T) int64 -> out (B*T, D) bf16. */
+int gill_opt_embed(gill_opt* h, const int64_t* ids, int n, void* out_bf16, void* stream);
+
+/* Full causal forward over right-padded sequences, no attention mask (models.py:363-365).
+ *   inputs_embeds (B,T,D) bf16  ->  hidden_out (B,T,D) fp32 = hidden_states[-1] (post final LN).
+ * hidden_out may be NULL when only gathered rows are wanted (see gill_opt_img_hidden). */
+int gill_opt_forward(gill_opt* h, const void* inputs_embeds_bf16, int B, int T, float* hidden_out, void* stream);
+
+/* The fast path of GILLModel.forward(mode='generation') (models.py:180-183, 384-385):
+ *   ids (B,T) int64 right-padded, last_idx (B) int32 HOST array = caption_len-1;
+ *   raw_out (B,8,D) bf16 = hidden_states[-1][i, last-7:last+1];  emb_out (B,8,D) bf16 = input_embs slice. */
+int gill_opt_img_hidden(gill_opt* h, const int64_t* ids, const int32_t* last_idx_host, int B, int T, int num_tokens,
+                        void* raw_out_bf16, void* emb_out_bf16, void* stream);
+
+/* logits[:, -1, :] of the tied lm_head for the generate loop (models.py:470):
+ *   hidden (B,T,D) fp32 from gill_opt_forward -> logits_out (B, vocab) fp32.  B <= 8. */
+int gill_opt_last_logits(gill_opt* h, const float* hidden, int B, int T, float* logits_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage 2 — GILLMapper = gill.layers.TextFcLayer(mode='gill_mapper').forward (layers.py:28-53).
+ * State-dict names are TextFcLayer's ("fc.weight", "tfm.encoder.layers.0.self_attn.in_proj_weight",
+ * "query_embs", "model.weight", ...).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gill_mapper gill_mapper;
+typedef struct {
+  int32_t in_dim;         /* 4096 (opt-6.7b) / 768 (opt-125m) */
+  int32_t out_dim;        /* 768 */
+  int32_t hidden_dim;     /* 512 */
+  int32_t num_heads;      /* 4 */
+  int32_t ffn_dim;        /* 2048 */
+  int32_t num_enc_layers; /* 4 */
+  int32_t num_dec_layers; /* 4 */
+  int32_t num_input_tokens;  /* 8 */
+  int32_t num_output_tokens; /* 77 */
+  int32_t max_batch;
+} gill_mapper_config;
+
+int gill_mapper_create(gill_mapper** out, const gill_mapper_config* cfg, const gill_tensor* weights, int n_weights);
+void gill_mapper_destroy(gill_mapper* h);
+/* x (B,8,in_dim) bf16, input_embs (Be,8,in_dim) bf16 with Be in {1,B} (broadcast like torch)
+ *   -> out (B,77,out_dim) fp32 */
+int gill_mapper_forward(gill_mapper* h, const void* x_bf16, const void* input_embs_bf16, int B, int Be, float* out,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage 3 — Stable Diffusion UNet + PNDM/PLMS classifier-free-guidance loop.  Replaces
+ * self.sd_pipe(prompt_embeds=..., guidance_scale=..., num_inference_steps=...) at
+ * gill/models.py:730-731, whose driver is restated in-tree at gill/custom_sd.py:567-651.
+ * State-dict names are diffusers UNet2DConditionModel's ("down_blocks.0.resnets.0.conv1.weight").
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gill_unet gill_unet;
+typedef struct {
+  int32_t in_channels;          /* 4 */
+  int32_t out_channels;         /* 4 */
+  int32_t block_out_channels[4];/* 320,640,1280,1280 */
+  int32_t layers_per_block;     /* 2 */
+  int32_t cross_attention_dim;  /* 768 */
+  int32_t num_heads;            /* 8 (SD-1.5's "attention_head_dim" is the head COUNT) */
+  int32_t norm_num_groups;      /* 32 */
+  int32_t sample_size;          /* 64 latent pixels per side */
+  int32_t ctx_len;              /* 77 */
+  int32_t max_batch;            /* largest UNet batch (2 x prompts with CFG) */
+} gill_unet_config;
+
+int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, const gill_tensor* weights, int n_weights);
+void gill_unet_destroy(gill_unet* h);
+
+/* One UNet forward (custom_sd.py:633-638): sample (Bx,4,L,L) fp32 NCHW, timesteps (Bx) fp32 HOST,
+ * ctx (Bx,77,768) bf16 -> eps_out (Bx,4,L,L) fp32 NCHW. */
+int gill_unet_forward(gill_unet* h, const float* sample, const float* timesteps_host, const void* ctx_bf16, int Bx,
+                      float* eps_out, void* stream);
+
+/* The whole denoise loop (custom_sd.py:607-651 with PNDMScheduler(skip_prk_steps, steps_offset=1,
+ * scaled_linear 0.00085..0.012, 1000 train steps)):
+ *   cond (B,77,768) bf16, uncond (1,77,768) bf16, latents0 (B,4,L,L) fp32 (already * init_noise_sigma=1)
+ *   -> latents_out (B,4,L,L) fp32.  num_steps "inference steps" = num_steps+1 UNet calls of batch 2B.
+ *   guidance <= 1 disables CFG (batch B, uncond ignored) like do_classifier_free_guidance. */
+int gill_sd_denoise(gill_unet* h, const void* cond_bf16, const void* uncond_bf16, const float* latents0, int B,
+                    int num_steps, float guidance, float* latents_out, void* stream);
+
+/* PNDM schedule known-answers for tests (host arrays): timesteps_out must hold num_steps+1 ints;
+ * returns the number written.  alphas_cumprod_out (optional) must hold 1000 doubles. */
+int gill_pndm_schedule(int num_steps, int32_t* timesteps_out, double* alphas_cumprod_out);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator-level entry points (the kernels the three stages are built from), exported so the
+ * parity tests can pin each against the CPU oracle.  All bf16 unless noted.
+ * ------------------------------------------------------------------------------------------ */
+/* C[M,N] = act(alpha * A[M,K] . W[N,K]^T + bias[N] + resid[M,N]); act: 0 none 1 relu 2 gelu(erf) 3 silu.
+ * out_f32: C is fp32 instead of bf16.  splitk: 0 = auto. */
+int gill_op_gemm(const void* A, const void* W, const float* bias, const void* resid_bf16, void* C, int M, int N, int K,
+                 float alpha, int act, int out_f32, int splitk, void* stream);
+/* GEGLU projection: W (2*inner, K) in diffusers order [value rows | gate rows], bias (2*inner) ->
+ * C (M, inner) = (A.Wv^T + bv) * gelu(A.Wg^T + bg) */
+int gill_op_geglu(const void* A, const void* W, const float* bias, void* C, int M, int inner, int K, void* stream);
+/* 3x3 pad-1 convolution over NHWC: x1 (B,IH,IW,C1) [++ x2 (B,IH,IW,C2) channel-concat], w OIHW fp32 (Cout,C1+C2,3,3),
+ * stride 1|2, ups=1 -> nearest 2x upsample first.  rowvec (B,Cout) fp32 optional per-sample bias; resid NHWC optional. */
+int gill_op_conv3x3(const void* x1, int C1, const void* x2, int C2, const float* w_oihw, const float* bias,
+                    const float* rowvec, const void* resid, void* y, int B, int IH, int IW, int Cout, int stride, int ups,
+                    int splitk, void* stream);
+/* softmax(scale * q k^T [+causal]) v over token-major q (B,nq,H*d), k/v (B,nkv,H*d) -> o (B,nq,H*d) */
+int gill_op_attention(const void* q, const void* k, const void* v, void* o, int B, int H, int nq, int nkv, int d,
+                      float scale, int causal, void* stream);
+int gill_op_layernorm(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, int rows, int C,
+                      float eps, void* stream);
+int gill_op_groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, const float* gamma,
+                      const float* beta, float eps, int silu, void* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GILL_AMD_H */
