@@ -265,9 +265,11 @@ int skinny_gemm_launch(const bf16_t* x, const bf16_t* W, int M, int N, int K, fl
 __global__ __launch_bounds__(256) void plms_step_kernel(const PlmsStepArgs a) {
   const int64_t total = (int64_t)a.B * a.n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const float eu = a.eps[i];
-    const float ec = a.eps[total + i];
-    const float e = eu + a.guidance * (ec - eu);
+    float e = a.eps[i];
+    if (a.cfg) {
+      const float ec = a.eps[total + i];
+      e = e + a.guidance * (ec - e);
+    }
     float sample = a.lat[i];
     float ep;
     float* ets = a.ets;

@@ -89,6 +89,7 @@ struct PlmsStepArgs {
   float* ets;            // [4][B][n] ring of past eps'
   int B; int64_t n;      // n = C*H*W per sample
   float guidance;
+  int cfg;               // 1: eps holds [uncond | cond] halves and guidance is applied; 0: eps is [B][n]
   int mode;              // 0: first step, 1: repeated step, 2..4: multistep orders
   int slot_new;          // ring slot to write the new guided eps into (-1: don't store)
   int s1, s2, s3;        // ring slots of ets[-2], ets[-3], ets[-4] where needed (ets[-1] = new / slot of last)

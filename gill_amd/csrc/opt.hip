@@ -1,0 +1,244 @@
+// Stage 1 — frozen OPT decoder (transformers OPTForCausalLM as called at gill/models.py:363-365 and :465).
+//
+// Pre-LN decoder layer (do_layer_norm_before=True: every OPT size but 350m):
+//   h += out_proj(causal_attn(q,k,v = *_proj(LN(h))))         q scaled by head_dim^-0.5
+//   h += fc2(relu(fc1(LN(h))))
+// learned positions with the +2 offset, final LayerNorm; hidden_states[-1] is post-final-LN.
+// The residual stream is fp32; GEMMs are bf16 MFMA with fp32 accumulation, split-K so that the
+// skinny (M = B*T) weight-streaming GEMMs cover all 256 CUs; attention is the shared flash kernel.
+#include "engine_util.h"
+
+namespace {
+struct OptLayer {
+  bf16_t* wqkv = nullptr; float* bqkv = nullptr;   // [3D][D] rows: q | k | v
+  bf16_t* wo = nullptr; float* bo = nullptr;
+  bf16_t* w1 = nullptr; float* b1 = nullptr;
+  bf16_t* w2 = nullptr; float* b2 = nullptr;
+  float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+};
+}  // namespace
+
+struct gill_opt {
+  gill_opt_config cfg;
+  DevPool pool;
+  bf16_t* embed = nullptr;      // [vocab][D]
+  bf16_t* lm_head = nullptr;    // tied to embed unless lm_head.weight was supplied
+  bf16_t* pos = nullptr;        // [max_positions+2][D]
+  float *lnfg = nullptr, *lnfb = nullptr;
+  std::vector<OptLayer> layers;
+  int dp = 0, dpv = 0;
+  // workspace
+  float* h = nullptr;       // [B*T][D]
+  bf16_t* nbuf = nullptr;   // [B*T][D]
+  bf16_t* ff = nullptr;     // [B*T][ffn]
+  bf16_t *q = nullptr, *k = nullptr, *vt = nullptr, *o = nullptr;
+  bf16_t* emb_tmp = nullptr;  // [B*T][D]
+  float* gath = nullptr;      // [B*8][D]
+  bf16_t* last_bf = nullptr;  // [8][D]
+  int32_t* idx_dev = nullptr; // [B*8 + B*8]
+  float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
+};
+
+// out[row][:] = bf16->f32(emb[row][:]) + pos[t + off][:]
+__global__ __launch_bounds__(256) void opt_add_pos_kernel(const bf16_t* __restrict__ emb, const bf16_t* __restrict__ pos,
+                                                          int pos_offset, int T, int D, float* __restrict__ out) {
+  const int row = blockIdx.x;
+  const int t = row % T;
+  const bf16_t* e = emb + (size_t)row * D;
+  const bf16_t* pe = pos + (size_t)(t + pos_offset) * D;
+  float* o = out + (size_t)row * D;
+  for (int c = threadIdx.x * 2; c < D; c += blockDim.x * 2) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(e + c);
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(pe + c);
+    *reinterpret_cast<float2*>(o + c) = make_float2(bf2f((bf16_t)(u & 0xffff)) + bf2f((bf16_t)(v & 0xffff)),
+                                                    bf2f((bf16_t)(u >> 16)) + bf2f((bf16_t)(v >> 16)));
+  }
+}
+
+extern "C" int gill_opt_create(gill_opt** out, const gill_opt_config* cfg, const gill_tensor* weights, int n_weights) {
+  GILL_REQUIRE(out && cfg && weights, "null argument");
+  const int D = cfg->hidden_size, F = cfg->ffn_dim, H = cfg->num_heads;
+  GILL_REQUIRE(D % 64 == 0 && F % 64 == 0 && H > 0 && D % H == 0, "OPT dims must be multiples of 64");
+  const int hd = D / H;
+  GILL_REQUIRE(attn_padded_dim(hd) == hd, "OPT head dim must be one of 48/64/80/128/160");
+  GILL_REQUIRE(cfg->max_batch > 0 && cfg->max_seq > 0 && cfg->max_seq <= cfg->max_positions, "bad workspace sizing");
+  gill_opt* m = new gill_opt();
+  m->cfg = *cfg;
+  m->dp = hd; m->dpv = round_up(hd, 32);
+  WeightTable wt(weights, n_weights);
+  hipStream_t s = nullptr;
+  int rc = 0;
+  auto fail = [&](int r) { delete m; return r; };
+  const std::string dec = "model.decoder.";
+  if ((rc = load_bf16(wt, m->pool, dec + "embed_tokens.weight", (int64_t)cfg->vocab_size * D, &m->embed, s))) return fail(rc);
+  if ((rc = load_bf16(wt, m->pool, dec + "embed_positions.weight", (int64_t)(cfg->max_positions + 2) * D, &m->pos, s)))
+    return fail(rc);
+  if (wt.find("lm_head.weight")) {
+    if ((rc = load_bf16(wt, m->pool, "lm_head.weight", (int64_t)cfg->vocab_size * D, &m->lm_head, s))) return fail(rc);
+  } else {
+    m->lm_head = m->embed;
+  }
+  if ((rc = load_f32(wt, m->pool, dec + "final_layer_norm.weight", D, &m->lnfg, s))) return fail(rc);
+  if ((rc = load_f32(wt, m->pool, dec + "final_layer_norm.bias", D, &m->lnfb, s))) return fail(rc);
+  m->layers.resize(cfg->num_layers);
+  for (int i = 0; i < cfg->num_layers; ++i) {
+    OptLayer& L = m->layers[i];
+    const std::string p = dec + "layers." + std::to_string(i) + ".";
+    if ((rc = m->pool.alloc(&L.wqkv, (size_t)3 * D * D, false))) return fail(rc);
+    if ((rc = m->pool.alloc(&L.bqkv, (size_t)3 * D, false))) return fail(rc);
+    const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+    for (int j = 0; j < 3; ++j) {
+      const gill_tensor* t;
+      if ((rc = wt.get(p + "self_attn." + names[j] + ".weight", (int64_t)D * D, &t))) return fail(rc);
+      if ((rc = convert_to_bf16_launch(t->data, t->dtype, (int64_t)D * D, L.wqkv + (size_t)j * D * D, s))) return fail(rc);
+      if ((rc = wt.get(p + "self_attn." + names[j] + ".bias", D, &t))) return fail(rc);
+      if ((rc = convert_to_f32_launch(t->data, t->dtype, D, L.bqkv + (size_t)j * D, s))) return fail(rc);
+    }
+    if ((rc = load_bf16(wt, m->pool, p + "self_attn.out_proj.weight", (int64_t)D * D, &L.wo, s))) return fail(rc);
+    if ((rc = load_f32(wt, m->pool, p + "self_attn.out_proj.bias", D, &L.bo, s))) return fail(rc);
+    if ((rc = load_bf16(wt, m->pool, p + "fc1.weight", (int64_t)F * D, &L.w1, s))) return fail(rc);
+    if ((rc = load_f32(wt, m->pool, p + "fc1.bias", F, &L.b1, s))) return fail(rc);
+    if ((rc = load_bf16(wt, m->pool, p + "fc2.weight", (int64_t)D * F, &L.w2, s))) return fail(rc);
+    if ((rc = load_f32(wt, m->pool, p + "fc2.bias", D, &L.b2, s))) return fail(rc);
+    if ((rc = load_f32(wt, m->pool, p + "self_attn_layer_norm.weight", D, &L.ln1g, s))) return fail(rc);
+    if ((rc = load_f32(wt, m->pool, p + "self_attn_layer_norm.bias", D, &L.ln1b, s))) return fail(rc);
+    if ((rc = load_f32(wt, m->pool, p + "final_layer_norm.weight", D, &L.ln2g, s))) return fail(rc);
+    if ((rc = load_f32(wt, m->pool, p + "final_layer_norm.bias", D, &L.ln2b, s))) return fail(rc);
+  }
+  const size_t R = (size_t)cfg->max_batch * cfg->max_seq;
+  const size_t Tpad = round_up(cfg->max_seq, 32);
+  if ((rc = m->pool.alloc(&m->h, R * D))) return fail(rc);
+  if ((rc = m->pool.alloc(&m->nbuf, R * D))) return fail(rc);
+  if ((rc = m->pool.alloc(&m->ff, R * F))) return fail(rc);
+  if ((rc = m->pool.alloc(&m->q, (size_t)cfg->max_batch * H * Tpad * m->dp))) return fail(rc);
+  if ((rc = m->pool.alloc(&m->k, (size_t)cfg->max_batch * H * Tpad * m->dp))) return fail(rc);
+  if ((rc = m->pool.alloc(&m->vt, (size_t)cfg->max_batch * H * m->dpv * Tpad))) return fail(rc);
+  if ((rc = m->pool.alloc(&m->o, R * D))) return fail(rc);
+  if ((rc = m->pool.alloc(&m->emb_tmp, R * D))) return fail(rc);
+  if ((rc = m->pool.alloc(&m->gath, (size_t)cfg->max_batch * 64 * D))) return fail(rc);
+  if ((rc = m->pool.alloc(&m->last_bf, (size_t)8 * D))) return fail(rc);
+  if ((rc = m->pool.alloc(&m->idx_dev, (size_t)cfg->max_batch * 64 * 2))) return fail(rc);
+  m->splitk_ws_floats = (size_t)16 * R * (size_t)(F > 3 * D ? F : 3 * D);
+  if ((rc = m->pool.alloc(&m->splitk_ws, m->splitk_ws_floats, false))) return fail(rc);
+  if (hipDeviceSynchronize() != hipSuccess) { gill_set_error("opt create: device sync failed"); return fail(-1); }
+  *out = m;
+  return 0;
+}
+
+extern "C" void gill_opt_destroy(gill_opt* h) { delete h; }
+
+extern "C" int gill_opt_embed(gill_opt* m, const int64_t* ids, int n, void* out_bf16, void* stream) {
+  GILL_REQUIRE(m && ids && out_bf16 && n > 0, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  // embedding rows are bf16 already: gather = pure row copy.  ids are int64 on device -> widen-free gather kernel
+  // (embed_tokens_launch adds positions and emits fp32, which is not what models.py:180 returns).
+  DevBuf tmp;
+  GILL_TRY(tmp.alloc(sizeof(float) * (size_t)n * m->cfg.hidden_size));
+  GILL_TRY(embed_tokens_launch(ids, m->embed, m->cfg.vocab_size, nullptr, 0, 1, n, m->cfg.hidden_size, (float*)tmp.p, s));
+  GILL_TRY(cast_f32_to_bf16_launch((const float*)tmp.p, (bf16_t*)out_bf16, (int64_t)n * m->cfg.hidden_size, s));
+  GILL_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+namespace {
+struct OptRun {
+  gill_opt* m;
+  hipStream_t s;
+  int linear(const bf16_t* A, int M, const bf16_t* W, const float* b, int N, int K, const float* resid, int act, void* out,
+             bool out_f32) {
+    GemmArgs g;
+    g.M = M; g.N = N; g.K = K; g.K1 = K; g.A = A; g.lda = K; g.W = W; g.bias = b;
+    g.resid = resid; g.ldr = N; g.resid_f32 = 1;
+    g.act = act; g.out_mode = out_f32 ? OUT_F32 : OUT_BF16; g.C = out; g.ldc = N;
+    g.splitk = gemm_pick_splitk(M, N, K, act);
+    if ((size_t)g.splitk * M * N > m->splitk_ws_floats) g.splitk = 1;
+    g.ws = m->splitk_ws;
+    return gemm_launch(g, s);
+  }
+  // layers over the fp32 stream m->h (B*T rows)
+  int run_layers(int B, int T) {
+    const gill_opt_config& c = m->cfg;
+    const int D = c.hidden_size, F = c.ffn_dim, R = B * T;
+    const int Tpad = round_up(T, 32);
+    for (const OptLayer& L : m->layers) {
+      GILL_TRY(layernorm_launch(m->h, 1, L.ln1g, L.ln1b, m->nbuf, R, D, 1e-5f, s));
+      {
+        GemmArgs g;
+        g.M = R; g.N = 3 * D; g.K = D; g.K1 = D; g.A = m->nbuf; g.lda = D; g.W = L.wqkv; g.bias = L.bqkv;
+        g.out_mode = OUT_QKV; g.Cq = m->q; g.Ck = m->k; g.Cvt = m->vt;
+        g.heads = c.num_heads; g.dp = m->dp; g.dpv = m->dpv; g.ntok = T; g.ntok_pad_q = Tpad; g.ntok_pad_kv = Tpad;
+        g.seg_base = 0;
+        g.splitk = gemm_pick_splitk(R, 3 * D, D, 0);
+        if ((size_t)g.splitk * R * 3 * D > m->splitk_ws_floats) g.splitk = 1;
+        g.ws = m->splitk_ws;
+        GILL_TRY(gemm_launch(g, s));
+      }
+      {
+        AttnArgs a;
+        a.Q = m->q; a.K = m->k; a.Vt = m->vt; a.O = m->o;
+        a.B = B; a.H = c.num_heads; a.nq = T; a.nkv = T; a.nq_pad = Tpad; a.nkv_pad = Tpad;
+        a.dp = m->dp; a.dpv = m->dpv; a.ldo = D; a.scale = 1.0f / sqrtf((float)m->dp); a.causal = 1;
+        GILL_TRY(attention_launch(a, s));
+      }
+      GILL_TRY(linear(m->o, R, L.wo, L.bo, D, D, m->h, ACT_NONE, m->h, true));
+      GILL_TRY(layernorm_launch(m->h, 1, L.ln2g, L.ln2b, m->nbuf, R, D, 1e-5f, s));
+      GILL_TRY(linear(m->nbuf, R, L.w1, L.b1, F, D, nullptr, ACT_RELU, m->ff, false));
+      GILL_TRY(linear(m->ff, R, L.w2, L.b2, D, F, m->h, ACT_NONE, m->h, true));
+    }
+    return 0;
+  }
+};
+}  // namespace
+
+extern "C" int gill_opt_forward(gill_opt* m, const void* inputs_embeds_bf16, int B, int T, float* hidden_out,
+                                void* stream) {
+  GILL_REQUIRE(m && inputs_embeds_bf16, "null argument");
+  GILL_REQUIRE(B >= 1 && B <= m->cfg.max_batch && T >= 1 && T <= m->cfg.max_seq, "B/T exceed the handle's workspace");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = m->cfg.hidden_size;
+  hipLaunchKernelGGL(opt_add_pos_kernel, dim3(B * T), dim3(256), 0, s, (const bf16_t*)inputs_embeds_bf16, m->pos, 2, T, D,
+                     m->h);
+  GILL_CHECK_HIP(hipGetLastError());
+  OptRun r{m, s};
+  GILL_TRY(r.run_layers(B, T));
+  if (hidden_out) GILL_TRY(layernorm_f32out_launch(m->h, 1, m->lnfg, m->lnfb, hidden_out, B * T, D, 1e-5f, s));
+  return 0;
+}
+
+extern "C" int gill_opt_img_hidden(gill_opt* m, const int64_t* ids, const int32_t* last_idx_host, int B, int T,
+                                   int num_tokens, void* raw_out_bf16, void* emb_out_bf16, void* stream) {
+  GILL_REQUIRE(m && ids && last_idx_host && raw_out_bf16, "null argument");
+  GILL_REQUIRE(B >= 1 && B <= m->cfg.max_batch && T >= 1 && T <= m->cfg.max_seq, "B/T exceed the handle's workspace");
+  GILL_REQUIRE(num_tokens >= 1 && num_tokens <= 64, "num_tokens out of range");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = m->cfg.hidden_size;
+  std::vector<int32_t> idx((size_t)B * num_tokens);
+  for (int b = 0; b < B; ++b) {
+    GILL_REQUIRE(last_idx_host[b] - num_tokens + 1 >= 0 && last_idx_host[b] < T, "last_idx out of range");
+    for (int j = 0; j < num_tokens; ++j) idx[(size_t)b * num_tokens + j] = b * T + last_idx_host[b] - num_tokens + 1 + j;
+  }
+  GILL_CHECK_HIP(hipMemcpyAsync(m->idx_dev, idx.data(), sizeof(int32_t) * idx.size(), hipMemcpyHostToDevice, s));
+  GILL_CHECK_HIP(hipStreamSynchronize(s));  // idx is a stack-lifetime host buffer
+  // input_embs = input_embeddings(labels)  (models.py:180), bf16 rows
+  GILL_TRY(embed_tokens_launch(ids, m->embed, m->cfg.vocab_size, nullptr, 0, B, T, D, m->h, s));
+  GILL_TRY(cast_f32_to_bf16_launch(m->h, m->emb_tmp, (int64_t)B * T * D, s));
+  if (emb_out_bf16) GILL_TRY(gather_rows_launch(m->emb_tmp, 0, m->idx_dev, B * num_tokens, D, emb_out_bf16, 0, s));
+  // + learned positions -> fp32 stream
+  GILL_TRY(embed_tokens_launch(ids, m->embed, m->cfg.vocab_size, m->pos, 2, B, T, D, m->h, s));
+  OptRun r{m, s};
+  GILL_TRY(r.run_layers(B, T));
+  // final LN only on the rows that are read (models.py:384)
+  GILL_TRY(gather_rows_launch(m->h, 1, m->idx_dev, B * num_tokens, D, m->gath, 1, s));
+  GILL_TRY(layernorm_launch(m->gath, 1, m->lnfg, m->lnfb, (bf16_t*)raw_out_bf16, B * num_tokens, D, 1e-5f, s));
+  return 0;
+}
+
+extern "C" int gill_opt_last_logits(gill_opt* m, const float* hidden, int B, int T, float* logits_out, void* stream) {
+  GILL_REQUIRE(m && hidden && logits_out, "null argument");
+  GILL_REQUIRE(B >= 1 && B <= 8, "last_logits supports B <= 8");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = m->cfg.hidden_size;
+  for (int b = 0; b < B; ++b)
+    GILL_TRY(cast_f32_to_bf16_launch(hidden + ((size_t)b * T + (T - 1)) * D, m->last_bf + (size_t)b * D, D, s));
+  return skinny_gemm_launch(m->last_bf, m->lm_head, B, m->cfg.vocab_size, D, logits_out, s);
+}

@@ -1,0 +1,755 @@
+// Stage 3 — Stable Diffusion UNet + PNDM/PLMS classifier-free-guidance loop.
+//
+// Replaces self.sd_pipe(prompt_embeds=..., guidance_scale=..., num_inference_steps=...)
+// (gill/models.py:730-731); the loop is the one restated in-tree at gill/custom_sd.py:607-651:
+//   latent_model_input = cat([latents]*2)            custom_sd.py:630
+//   noise_pred = unet(latent_model_input, t, encoder_hidden_states=prompt_embeds).sample      :633-638
+//   noise_pred = uncond + g * (text - uncond)        :641-643
+//   latents = scheduler.step(noise_pred, t, latents) :646          (PNDMScheduler, skip_prk_steps)
+// The UNet itself (diffusers UNet2DConditionModel, SD-1.5 config) is not in the reference tree; its
+// structure here follows the public architecture (state-dict key names are diffusers').
+//
+// MI355X design: activations are NHWC bf16 so that
+//   * every 3x3 conv is an implicit GEMM whose K steps are contiguous 128-B channel runs (gemm.hip),
+//   * (B, HW, C) attention tokens ARE the NHWC tensor: no transposes anywhere,
+//   * skip-connection concats are never materialised (two-source GroupNorm / conv / shortcut GEMM),
+//   * nearest-2x upsampling is folded into the following conv's gather.
+// Step-invariant work is hoisted out of the 51-call loop: the cross-attention K/V of all 16 layers
+// (they depend only on the prompt embedding) and the whole time-embedding MLP + the 22 resnet
+// time projections for every timestep (one batched GEMM chain -> a [steps][sum Cout] table that the
+// conv epilogues add as a per-channel row vector).
+#include "engine_util.h"
+#include <math.h>
+#include <hip/hip_fp16.h>
+
+namespace {
+
+struct ConvW { bf16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; };
+struct LinW { bf16_t* w = nullptr; float* b = nullptr; int out = 0, in = 0; };
+struct NormW { float* g = nullptr; float* b = nullptr; int c = 0; };
+
+struct ResnetW {
+  NormW n1, n2;
+  ConvW c1, c2;
+  bool has_sc = false;
+  LinW sc;
+  int cin = 0, cout = 0, temb_off = 0;
+};
+
+struct XfW {  // Transformer2DModel with one BasicTransformerBlock
+  int C = 0, d = 0, dp = 0, dpv = 0, layer_id = 0;
+  NormW gn;
+  LinW proj_in, proj_out;
+  NormW ln1, ln2, ln3;
+  bf16_t* wqkv1 = nullptr;    // [3*H*dp][C]
+  LinW out1;                  // [C][H*dp]
+  bf16_t* wq2 = nullptr;      // [H*dp][C]
+  bf16_t* wkv2 = nullptr;     // [2*H*dp][ctx_dim]
+  LinW out2;
+  bf16_t* wff1 = nullptr; float* bff1 = nullptr;   // GEGLU-permuted [8C][C]
+  LinW ff2;                   // [C][4C]
+};
+
+struct Tensor { bf16_t* p = nullptr; int H = 0, W = 0, C = 0; };
+
+struct Arena {
+  unsigned char* base = nullptr;
+  size_t cap = 0, off = 0, high = 0;
+  bool dry = false;
+  void* alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    void* p = dry ? (void*)(uintptr_t)(0x1000 + off) : (void*)(base + off);
+    off += bytes;
+    if (off > high) high = off;
+    return p;
+  }
+  size_t mark() const { return off; }
+  void release(size_t m) { off = m; }
+};
+
+}  // namespace
+
+struct gill_unet {
+  gill_unet_config cfg;
+  DevPool pool;
+  // weights
+  bf16_t* conv_in_w = nullptr; float* conv_in_b = nullptr;
+  bf16_t* conv_out_w = nullptr; float* conv_out_b = nullptr;
+  NormW norm_out;
+  LinW te1, te2;
+  bf16_t* temb_proj_w = nullptr; float* temb_proj_b = nullptr; int temb_total = 0;   // [sum Cout][1280]
+  std::vector<ResnetW> down_res[4], up_res[4];
+  std::vector<XfW> down_xf[4], up_xf[4];
+  ConvW down_ds[3], up_us[3];
+  ResnetW mid_res[2];
+  XfW mid_xf;
+  int n_xf = 0;
+  int temb_dim = 0;
+  // workspace
+  Arena arena;
+  unsigned char* arena_mem = nullptr;
+  float* gn_stats = nullptr;
+  float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
+  std::vector<bf16_t*> kcache, vcache;   // per transformer layer: [Bx][H][ctx_pad][dp] / [Bx][H][dpv][ctx_pad]
+  int ctx_pad = 0;
+  // time embedding scratch
+  float* t_dev = nullptr;       // [rows]
+  bf16_t* t_sin = nullptr;      // [rows][320]
+  bf16_t* t_h1 = nullptr;       // [rows][1280]
+  bf16_t* t_h2 = nullptr;       // [rows][1280]
+  float* temb_table = nullptr;  // [rows][temb_total]
+  int temb_rows_cap = 0;
+  // loop state
+  float* lat = nullptr;         // [B][4*L*L]
+  float* lat2 = nullptr;        // [2B][4*L*L]
+  float* eps = nullptr;         // [2B][4*L*L]
+  float* cur_sample = nullptr;
+  float* ets = nullptr;         // [4][B][4*L*L]
+  bf16_t* ctx_full = nullptr;   // [2B][77][768]
+};
+
+// dst[r][h*dp + dd] = src[r][h*d + dd] (dd < d), zero elsewhere.  dst pre-zeroed.
+__global__ __launch_bounds__(256) void pad_head_cols_kernel(const void* src, int dtype, int rows, int H, int d, int dp,
+                                                            bf16_t* dst) {
+  const int64_t total = (int64_t)rows * H * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int dd = (int)(i % d);
+    const int h = (int)((i / d) % H);
+    const int64_t r = i / ((int64_t)d * H);
+    float v;
+    if (dtype == 0) v = bf2f(((const bf16_t*)src)[i]);
+    else if (dtype == 1) v = ((const float*)src)[i];
+    else v = (float)(((const __half*)src)[i]);
+    dst[r * (int64_t)H * dp + h * dp + dd] = f2bf(v);
+  }
+}
+// dst[(h*dp + dd)][:] = src[(h*d + dd)][:]  (row padding of q/k/v projection weights).  dst pre-zeroed.
+__global__ __launch_bounds__(256) void pad_head_rows_kernel(const void* src, int dtype, int H, int d, int dp, int cols,
+                                                            bf16_t* dst) {
+  const int64_t total = (int64_t)H * d * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cols);
+    const int64_t r = i / cols;
+    const int h = (int)(r / d), dd = (int)(r % d);
+    float v;
+    if (dtype == 0) v = bf2f(((const bf16_t*)src)[i]);
+    else if (dtype == 1) v = ((const float*)src)[i];
+    else v = (float)(((const __half*)src)[i]);
+    dst[((int64_t)h * dp + dd) * cols + c] = f2bf(v);
+  }
+}
+
+namespace {
+
+struct Loader {
+  const WeightTable& wt;
+  DevPool& pool;
+  hipStream_t s;
+  int norm(const std::string& p, int c, NormW* n) {
+    n->c = c;
+    GILL_TRY(load_f32(wt, pool, p + ".weight", c, &n->g, s));
+    return load_f32(wt, pool, p + ".bias", c, &n->b, s);
+  }
+  int conv3(const std::string& p, int cin, int cout, ConvW* c) {
+    c->cin = cin; c->cout = cout;
+    const gill_tensor* t;
+    GILL_TRY(wt.get(p + ".weight", (int64_t)cout * cin * 9, &t));
+    GILL_TRY(pool.alloc(&c->w, (size_t)cout * cin * 9, false));
+    GILL_TRY(conv_weight_relayout_launch(t->data, t->dtype, cout, cin, c->w, s));
+    return load_f32(wt, pool, p + ".bias", cout, &c->b, s);
+  }
+  int lin(const std::string& p, int out, int in, LinW* l, bool bias = true) {
+    l->out = out; l->in = in;
+    GILL_TRY(load_bf16(wt, pool, p + ".weight", (int64_t)out * in, &l->w, s));
+    if (bias) return load_f32(wt, pool, p + ".bias", out, &l->b, s);
+    return 0;
+  }
+  // projection weight [H*d][cols] -> [H*dp][cols] into a caller-provided slot
+  int head_rows(const std::string& name, int H, int d, int dp, int cols, bf16_t* dst) {
+    const gill_tensor* t;
+    GILL_TRY(wt.get(name, (int64_t)H * d * cols, &t));
+    hipLaunchKernelGGL(pad_head_rows_kernel, dim3(1024), dim3(256), 0, s, t->data, t->dtype, H, d, dp, cols, dst);
+    GILL_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  int resnet(const std::string& p, int cin, int cout, int temb_dim, int* temb_off, bf16_t* temb_w, float* temb_b,
+             ResnetW* r) {
+    r->cin = cin; r->cout = cout;
+    GILL_TRY(norm(p + ".norm1", cin, &r->n1));
+    GILL_TRY(conv3(p + ".conv1", cin, cout, &r->c1));
+    GILL_TRY(norm(p + ".norm2", cout, &r->n2));
+    GILL_TRY(conv3(p + ".conv2", cout, cout, &r->c2));
+    r->has_sc = (cin != cout);
+    if (r->has_sc) GILL_TRY(lin(p + ".conv_shortcut", cout, cin, &r->sc));
+    // time_emb_proj rows go into the shared [sum Cout][temb_dim] matrix
+    r->temb_off = *temb_off;
+    const gill_tensor* t;
+    GILL_TRY(wt.get(p + ".time_emb_proj.weight", (int64_t)cout * temb_dim, &t));
+    GILL_TRY(convert_to_bf16_launch(t->data, t->dtype, (int64_t)cout * temb_dim, temb_w + (size_t)r->temb_off * temb_dim, s));
+    GILL_TRY(wt.get(p + ".time_emb_proj.bias", cout, &t));
+    GILL_TRY(convert_to_f32_launch(t->data, t->dtype, cout, temb_b + r->temb_off, s));
+    *temb_off += cout;
+    return 0;
+  }
+  int xf(const std::string& p, int C, int H, int ctx_dim, int layer_id, XfW* x) {
+    x->C = C; x->d = C / H; x->dp = attn_padded_dim(x->d); x->dpv = round_up(x->dp, 32); x->layer_id = layer_id;
+    GILL_REQUIRE(x->dp > 0, "unsupported attention head dim");
+    const int hdp = H * x->dp;
+    GILL_REQUIRE(hdp % 64 == 0, "padded attention width must be a multiple of 64");
+    GILL_TRY(norm(p + ".norm", C, &x->gn));
+    GILL_TRY(lin(p + ".proj_in", C, C, &x->proj_in));
+    GILL_TRY(lin(p + ".proj_out", C, C, &x->proj_out));
+    const std::string b = p + ".transformer_blocks.0";
+    GILL_TRY(norm(b + ".norm1", C, &x->ln1));
+    GILL_TRY(norm(b + ".norm2", C, &x->ln2));
+    GILL_TRY(norm(b + ".norm3", C, &x->ln3));
+    GILL_TRY(pool.alloc(&x->wqkv1, (size_t)3 * hdp * C, true));
+    GILL_TRY(head_rows(b + ".attn1.to_q.weight", H, x->d, x->dp, C, x->wqkv1));
+    GILL_TRY(head_rows(b + ".attn1.to_k.weight", H, x->d, x->dp, C, x->wqkv1 + (size_t)hdp * C));
+    GILL_TRY(head_rows(b + ".attn1.to_v.weight", H, x->d, x->dp, C, x->wqkv1 + (size_t)2 * hdp * C));
+    GILL_TRY(pool.alloc(&x->wq2, (size_t)hdp * C, true));
+    GILL_TRY(head_rows(b + ".attn2.to_q.weight", H, x->d, x->dp, C, x->wq2));
+    GILL_TRY(pool.alloc(&x->wkv2, (size_t)2 * hdp * ctx_dim, true));
+    GILL_TRY(head_rows(b + ".attn2.to_k.weight", H, x->d, x->dp, ctx_dim, x->wkv2));
+    GILL_TRY(head_rows(b + ".attn2.to_v.weight", H, x->d, x->dp, ctx_dim, x->wkv2 + (size_t)hdp * ctx_dim));
+    for (int a = 1; a <= 2; ++a) {
+      LinW* o = (a == 1) ? &x->out1 : &x->out2;
+      const std::string on = b + ".attn" + std::to_string(a) + ".to_out.0";
+      o->out = C; o->in = hdp;
+      const gill_tensor* t;
+      GILL_TRY(wt.get(on + ".weight", (int64_t)C * C, &t));
+      GILL_TRY(pool.alloc(&o->w, (size_t)C * hdp, true));
+      hipLaunchKernelGGL(pad_head_cols_kernel, dim3(1024), dim3(256), 0, s, t->data, t->dtype, C, H, x->d, x->dp, o->w);
+      GILL_CHECK_HIP(hipGetLastError());
+      GILL_TRY(load_f32(wt, pool, on + ".bias", C, &o->b, s));
+    }
+    // GEGLU projection: permute rows (value/gate 16-row interleave)
+    {
+      const int inner = 4 * C;
+      bf16_t* tmpw; float* tmpb; int32_t* idx;
+      GILL_TRY(load_bf16(wt, pool, b + ".ff.net.0.proj.weight", (int64_t)2 * inner * C, &tmpw, s));
+      GILL_TRY(load_f32(wt, pool, b + ".ff.net.0.proj.bias", 2 * inner, &tmpb, s));
+      std::vector<int32_t> map = geglu_row_permutation(inner);
+      GILL_TRY(pool.alloc(&idx, map.size(), false));
+      GILL_CHECK_HIP(hipMemcpy(idx, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice));
+      GILL_TRY(pool.alloc(&x->wff1, (size_t)2 * inner * C, false));
+      GILL_TRY(pool.alloc(&x->bff1, (size_t)2 * inner, false));
+      GILL_TRY(scatter_rows_bf16_launch(tmpw, 2 * inner, C, idx, x->wff1, C, s));
+      GILL_TRY(permute_f32_launch(tmpb, idx, 2 * inner, x->bff1, s));
+    }
+    GILL_TRY(lin(b + ".ff.net.2", C, 4 * C, &x->ff2));
+    return 0;
+  }
+};
+
+}  // namespace
+
+static int unet_plan_and_alloc(gill_unet* m);
+
+extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, const gill_tensor* weights, int n_weights) {
+  GILL_REQUIRE(out && cfg && weights, "null argument");
+  GILL_REQUIRE(cfg->layers_per_block == 2, "only layers_per_block == 2 (SD-1.x/2.x) is supported");
+  GILL_REQUIRE(cfg->max_batch >= 1, "max_batch must be >= 1");
+  for (int i = 0; i < 4; ++i)
+    GILL_REQUIRE(cfg->block_out_channels[i] % 64 == 0, "block_out_channels must be multiples of 64");
+  GILL_REQUIRE(cfg->cross_attention_dim % 64 == 0, "cross_attention_dim must be a multiple of 64");
+  GILL_REQUIRE(cfg->sample_size % 8 == 0, "sample_size must be a multiple of 8");
+  gill_unet* m = new gill_unet();
+  m->cfg = *cfg;
+  int rc = 0;
+  auto fail = [&](int r) { delete m; return r; };
+  WeightTable wt(weights, n_weights);
+  hipStream_t s = nullptr;
+  Loader L{wt, m->pool, s};
+  const int* ch = cfg->block_out_channels;
+  const int H = cfg->num_heads, ctxd = cfg->cross_attention_dim;
+  const int temb_dim = ch[0] * 4;
+  m->temb_dim = temb_dim;
+
+  // total width of the per-resnet time projections
+  int temb_total = 0;
+  for (int i = 0; i < 4; ++i) temb_total += 2 * ch[i];
+  temb_total += 2 * ch[3];
+  for (int i = 0; i < 4; ++i) temb_total += 3 * ch[3 - i];
+  m->temb_total = temb_total;
+  if ((rc = m->pool.alloc(&m->temb_proj_w, (size_t)temb_total * temb_dim, false))) return fail(rc);
+  if ((rc = m->pool.alloc(&m->temb_proj_b, (size_t)temb_total, false))) return fail(rc);
+  int temb_off = 0;
+
+  // conv_in / conv_out (direct kernels, [Cout][9][Cin] layout as well)
+  {
+    const gill_tensor* t;
+    if ((rc = wt.get("conv_in.weight", (int64_t)ch[0] * cfg->in_channels * 9, &t))) return fail(rc);
+    if ((rc = m->pool.alloc(&m->conv_in_w, (size_t)ch[0] * cfg->in_channels * 9, false))) return fail(rc);
+    if ((rc = conv_weight_relayout_launch(t->data, t->dtype, ch[0], cfg->in_channels, m->conv_in_w, s))) return fail(rc);
+    if ((rc = load_f32(wt, m->pool, "conv_in.bias", ch[0], &m->conv_in_b, s))) return fail(rc);
+    if ((rc = wt.get("conv_out.weight", (int64_t)cfg->out_channels * ch[0] * 9, &t))) return fail(rc);
+    if ((rc = m->pool.alloc(&m->conv_out_w, (size_t)cfg->out_channels * ch[0] * 9, false))) return fail(rc);
+    if ((rc = conv_weight_relayout_launch(t->data, t->dtype, cfg->out_channels, ch[0], m->conv_out_w, s))) return fail(rc);
+    if ((rc = load_f32(wt, m->pool, "conv_out.bias", cfg->out_channels, &m->conv_out_b, s))) return fail(rc);
+  }
+  if ((rc = L.norm("conv_norm_out", ch[0], &m->norm_out))) return fail(rc);
+  if ((rc = L.lin("time_embedding.linear_1", temb_dim, ch[0], &m->te1))) return fail(rc);
+  if ((rc = L.lin("time_embedding.linear_2", temb_dim, temb_dim, &m->te2))) return fail(rc);
+
+  int layer_id = 0;
+  // down blocks: CrossAttnDownBlock2D x3, DownBlock2D
+  for (int i = 0; i < 4; ++i) {
+    const int cin = (i == 0) ? ch[0] : ch[i - 1];
+    const std::string p = "down_blocks." + std::to_string(i);
+    m->down_res[i].resize(2);
+    for (int j = 0; j < 2; ++j)
+      if ((rc = L.resnet(p + ".resnets." + std::to_string(j), j == 0 ? cin : ch[i], ch[i], temb_dim, &temb_off,
+                         m->temb_proj_w, m->temb_proj_b, &m->down_res[i][j]))) return fail(rc);
+    if (i < 3) {
+      m->down_xf[i].resize(2);
+      for (int j = 0; j < 2; ++j)
+        if ((rc = L.xf(p + ".attentions." + std::to_string(j), ch[i], H, ctxd, layer_id++, &m->down_xf[i][j]))) return fail(rc);
+      if ((rc = L.conv3(p + ".downsamplers.0.conv", ch[i], ch[i], &m->down_ds[i]))) return fail(rc);
+    }
+  }
+  // mid
+  if ((rc = L.resnet("mid_block.resnets.0", ch[3], ch[3], temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[0])))
+    return fail(rc);
+  if ((rc = L.xf("mid_block.attentions.0", ch[3], H, ctxd, layer_id++, &m->mid_xf))) return fail(rc);
+  if ((rc = L.resnet("mid_block.resnets.1", ch[3], ch[3], temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[1])))
+    return fail(rc);
+  // up blocks: UpBlock2D, CrossAttnUpBlock2D x3
+  const int rev[4] = {ch[3], ch[2], ch[1], ch[0]};
+  for (int i = 0; i < 4; ++i) {
+    const int outc = rev[i];
+    const int prev = (i == 0) ? rev[0] : rev[i - 1];
+    const int inc = rev[i + 1 < 4 ? i + 1 : 3];
+    const std::string p = "up_blocks." + std::to_string(i);
+    m->up_res[i].resize(3);
+    for (int j = 0; j < 3; ++j) {
+      const int skip = (j == 2) ? inc : outc;
+      const int rin = (j == 0) ? prev : outc;
+      if ((rc = L.resnet(p + ".resnets." + std::to_string(j), rin + skip, outc, temb_dim, &temb_off, m->temb_proj_w,
+                         m->temb_proj_b, &m->up_res[i][j]))) return fail(rc);
+    }
+    if (i > 0) {
+      m->up_xf[i].resize(3);
+      for (int j = 0; j < 3; ++j)
+        if ((rc = L.xf(p + ".attentions." + std::to_string(j), outc, H, ctxd, layer_id++, &m->up_xf[i][j]))) return fail(rc);
+    }
+    if (i < 3)
+      if ((rc = L.conv3(p + ".upsamplers.0.conv", outc, outc, &m->up_us[i]))) return fail(rc);
+  }
+  m->n_xf = layer_id;
+  if (temb_off != temb_total) { gill_set_error("internal: temb table width mismatch"); return fail(-4); }
+
+  if ((rc = unet_plan_and_alloc(m))) return fail(rc);
+  if (hipDeviceSynchronize() != hipSuccess) { gill_set_error("unet create: device sync failed"); return fail(-1); }
+  *out = m;
+  return 0;
+}
+
+extern "C" void gill_unet_destroy(gill_unet* h) { delete h; }
+
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct UNetRun {
+  gill_unet* m;
+  hipStream_t s;
+  int Bx;
+  const float* temb_rows;   // row for sample 0
+  int temb_bstride;         // 0: every sample uses the same row
+  bool dry;
+
+  Tensor talloc(int H, int W, int C) {
+    Tensor t; t.H = H; t.W = W; t.C = C;
+    t.p = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * H * W * C);
+    return t;
+  }
+  int pick_sk(GemmArgs& g) {
+    g.splitk = gemm_pick_splitk(g.M, g.N, g.K, g.act);
+    while (g.splitk > 1 && (size_t)g.splitk * g.M * g.N > m->splitk_ws_floats) --g.splitk;
+    g.ws = m->splitk_ws;
+    return 0;
+  }
+  int gemm(GemmArgs& g) {
+    if (dry) return 0;
+    pick_sk(g);
+    return gemm_launch(g, s);
+  }
+  int gnorm(const Tensor& x1, const Tensor* x2, const NormW& n, float eps, int silu, const Tensor& y) {
+    if (dry) return 0;
+    return groupnorm_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, x1.H * x1.W, m->cfg.norm_num_groups, n.g,
+                            n.b, eps, silu, y.p, m->gn_stats, s);
+  }
+  // 3x3 conv (pad 1) over x1 (++ x2): stride 1|2, optional fused nearest-2x upsample
+  int conv(const Tensor& x1, const Tensor* x2, const ConvW& w, int stride, int ups, const float* rowvec, int rv_bstride,
+           const bf16_t* resid, const Tensor& y) {
+    GemmArgs g;
+    g.conv = 1; g.IH = x1.H; g.IW = x1.W; g.OH = y.H; g.OW = y.W; g.Cin = w.cin; g.stride = stride; g.ups = ups;
+    g.M = Bx * y.H * y.W; g.N = w.cout; g.K = 9 * w.cin;
+    g.A = x1.p; g.A2 = x2 ? x2->p : nullptr; g.K1 = x1.C;
+    g.W = w.w; g.bias = w.b;
+    g.rowvec = rowvec; g.rows_per_batch = y.H * y.W; g.rowvec_bstride = rv_bstride;
+    g.resid = resid; g.ldr = w.cout;
+    g.C = y.p; g.ldc = w.cout;
+    return gemm(g);
+  }
+  int linear(const bf16_t* A, int lda, const bf16_t* A2, int lda2, int K1, int M, const bf16_t* W, const float* b, int N,
+             int K, const bf16_t* resid, int act, bf16_t* out, int ldc) {
+    GemmArgs g;
+    g.M = M; g.N = N; g.K = K; g.K1 = K1; g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.W = W; g.bias = b;
+    g.resid = resid; g.ldr = N; g.act = act; g.C = out; g.ldc = ldc;
+    return gemm(g);
+  }
+
+  int resnet(const Tensor& x1, const Tensor* x2, const ResnetW& w, Tensor* out) {
+    const int H = x1.H, Wd = x1.W;
+    *out = talloc(H, Wd, w.cout);
+    const size_t mk = m->arena.mark();
+    Tensor n1 = talloc(H, Wd, w.cin);
+    GILL_TRY(gnorm(x1, x2, w.n1, 1e-5f, 1, n1));
+    Tensor h = talloc(H, Wd, w.cout);
+    GILL_TRY(conv(n1, nullptr, w.c1, 1, 0, temb_rows ? temb_rows + w.temb_off : nullptr, temb_bstride, nullptr, h));
+    Tensor n2 = talloc(H, Wd, w.cout);
+    GILL_TRY(gnorm(h, nullptr, w.n2, 1e-5f, 1, n2));
+    const bf16_t* res = x1.p;
+    if (w.has_sc) {
+      Tensor sc = talloc(H, Wd, w.cout);
+      GILL_TRY(linear(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, x1.C, Bx * H * Wd, w.sc.w, w.sc.b, w.cout, w.cin,
+                      nullptr, ACT_NONE, sc.p, w.cout));
+      res = sc.p;
+    }
+    GILL_TRY(conv(n2, nullptr, w.c2, 1, 0, nullptr, 0, res, *out));
+    m->arena.release(mk);
+    return 0;
+  }
+
+  int attend(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int nq, int nkv, int nq_pad, int nkv_pad,
+             const XfW& w) {
+    if (dry) return 0;
+    AttnArgs a;
+    a.Q = q; a.K = k; a.Vt = vt; a.O = o;
+    a.B = Bx; a.H = m->cfg.num_heads; a.nq = nq; a.nkv = nkv; a.nq_pad = nq_pad; a.nkv_pad = nkv_pad;
+    a.dp = w.dp; a.dpv = w.dpv; a.ldo = m->cfg.num_heads * w.dp;
+    a.scale = 1.0f / sqrtf((float)w.d);
+    return attention_launch(a, s);
+  }
+
+  int xf(const Tensor& x, const XfW& w, Tensor* out) {
+    const int H = x.H, Wd = x.W, C = w.C, HW = H * Wd, M = Bx * HW;
+    const int nh = m->cfg.num_heads, hdp = nh * w.dp;
+    *out = talloc(H, Wd, C);
+    const size_t mk = m->arena.mark();
+    Tensor n = talloc(H, Wd, C);
+    GILL_TRY(gnorm(x, nullptr, w.gn, 1e-6f, 0, n));
+    Tensor t = talloc(H, Wd, C);   // transformer residual stream
+    GILL_TRY(linear(n.p, C, nullptr, 0, C, M, w.proj_in.w, w.proj_in.b, C, C, nullptr, ACT_NONE, t.p, C));
+    bf16_t* ln = n.p;              // reuse: normalised activations
+    const int hw_pad = round_up(HW, 32);   // kv tiles are 32 wide; pad rows hold finite stale data and are masked
+    bf16_t* q = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * nh * hw_pad * w.dp);
+    bf16_t* k = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * nh * hw_pad * w.dp);
+    bf16_t* vt = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * nh * w.dpv * hw_pad);
+    bf16_t* o = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)M * hdp);
+    // --- self attention
+    if (!dry) GILL_TRY(layernorm_launch(t.p, 0, w.ln1.g, w.ln1.b, ln, M, C, 1e-5f, s));
+    {
+      GemmArgs g;
+      g.M = M; g.N = 3 * hdp; g.K = C; g.K1 = C; g.A = ln; g.lda = C; g.W = w.wqkv1;
+      g.out_mode = OUT_QKV; g.Cq = q; g.Ck = k; g.Cvt = vt; g.heads = nh; g.dp = w.dp; g.dpv = w.dpv;
+      g.ntok = HW; g.ntok_pad_q = hw_pad; g.ntok_pad_kv = hw_pad; g.seg_base = 0;
+      GILL_TRY(gemm(g));
+    }
+    GILL_TRY(attend(q, k, vt, o, HW, HW, hw_pad, hw_pad, w));
+    GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M, w.out1.w, w.out1.b, C, hdp, t.p, ACT_NONE, t.p, C));
+    // --- cross attention (K/V cached per prompt)
+    if (!dry) GILL_TRY(layernorm_launch(t.p, 0, w.ln2.g, w.ln2.b, ln, M, C, 1e-5f, s));
+    {
+      GemmArgs g;
+      g.M = M; g.N = hdp; g.K = C; g.K1 = C; g.A = ln; g.lda = C; g.W = w.wq2;
+      g.out_mode = OUT_QKV; g.Cq = q; g.Ck = k; g.Cvt = vt; g.heads = nh; g.dp = w.dp; g.dpv = w.dpv;
+      g.ntok = HW; g.ntok_pad_q = hw_pad; g.ntok_pad_kv = hw_pad; g.seg_base = 0;
+      GILL_TRY(gemm(g));
+    }
+    GILL_TRY(attend(q, m->kcache[w.layer_id], m->vcache[w.layer_id], o, HW, m->cfg.ctx_len, hw_pad, m->ctx_pad, w));
+    GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M, w.out2.w, w.out2.b, C, hdp, t.p, ACT_NONE, t.p, C));
+    // --- GEGLU feed-forward
+    if (!dry) GILL_TRY(layernorm_launch(t.p, 0, w.ln3.g, w.ln3.b, ln, M, C, 1e-5f, s));
+    bf16_t* ffh = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)M * 4 * C);
+    {
+      GemmArgs g;
+      g.M = M; g.N = 8 * C; g.K = C; g.K1 = C; g.A = ln; g.lda = C; g.W = w.wff1; g.bias = w.bff1;
+      g.act = ACT_GEGLU; g.C = ffh; g.ldc = 4 * C;
+      GILL_TRY(gemm(g));
+    }
+    GILL_TRY(linear(ffh, 4 * C, nullptr, 0, 4 * C, M, w.ff2.w, w.ff2.b, C, 4 * C, t.p, ACT_NONE, t.p, C));
+    // --- proj_out + outer residual
+    GILL_TRY(linear(t.p, C, nullptr, 0, C, M, w.proj_out.w, w.proj_out.b, C, C, x.p, ACT_NONE, out->p, C));
+    m->arena.release(mk);
+    return 0;
+  }
+
+  // sample: (Bx, in_ch, L, L) fp32 NCHW -> eps (Bx, out_ch, L, L) fp32 NCHW
+  int forward(const float* sample, float* eps_out) {
+    const gill_unet_config& c = m->cfg;
+    const int* ch = c.block_out_channels;
+    const int L = c.sample_size;
+    m->arena.off = 0;
+    std::vector<Tensor> skips;
+    Tensor x = talloc(L, L, ch[0]);
+    if (!dry) GILL_TRY(conv_in_launch(sample, m->conv_in_w, m->conv_in_b, Bx, c.in_channels, L, L, ch[0], x.p, s));
+    skips.push_back(x);
+    for (int i = 0; i < 4; ++i) {
+      for (int j = 0; j < 2; ++j) {
+        Tensor y;
+        GILL_TRY(resnet(x, nullptr, m->down_res[i][j], &y));
+        x = y;
+        if (i < 3) { Tensor z; GILL_TRY(xf(x, m->down_xf[i][j], &z)); x = z; }
+        skips.push_back(x);
+      }
+      if (i < 3) {
+        Tensor y = talloc(x.H / 2, x.W / 2, ch[i]);
+        GILL_TRY(conv(x, nullptr, m->down_ds[i], 2, 0, nullptr, 0, nullptr, y));
+        x = y;
+        skips.push_back(x);
+      }
+    }
+    {
+      Tensor y; GILL_TRY(resnet(x, nullptr, m->mid_res[0], &y)); x = y;
+      Tensor z; GILL_TRY(xf(x, m->mid_xf, &z)); x = z;
+      Tensor u; GILL_TRY(resnet(x, nullptr, m->mid_res[1], &u)); x = u;
+    }
+    for (int i = 0; i < 4; ++i) {
+      for (int j = 0; j < 3; ++j) {
+        Tensor skip = skips.back(); skips.pop_back();
+        Tensor y;
+        GILL_TRY(resnet(x, &skip, m->up_res[i][j], &y));
+        x = y;
+        if (i > 0) { Tensor z; GILL_TRY(xf(x, m->up_xf[i][j], &z)); x = z; }
+      }
+      if (i < 3) {
+        Tensor y = talloc(x.H * 2, x.W * 2, x.C);
+        GILL_TRY(conv(x, nullptr, m->up_us[i], 1, 1, nullptr, 0, nullptr, y));
+        x = y;
+      }
+    }
+    Tensor n = talloc(L, L, ch[0]);
+    GILL_TRY(gnorm(x, nullptr, m->norm_out, 1e-5f, 1, n));
+    if (!dry) GILL_TRY(conv_out_launch(n.p, m->conv_out_w, m->conv_out_b, Bx, ch[0], L, L, c.out_channels, eps_out, s));
+    return 0;
+  }
+};
+
+}  // namespace
+
+static int unet_plan_and_alloc(gill_unet* m) {
+  const gill_unet_config& c = m->cfg;
+  const int Bx = c.max_batch;
+  const int L = c.sample_size;
+  const size_t n_lat = (size_t)c.in_channels * L * L;
+  // dry run to size the activation arena
+  m->arena.dry = true; m->arena.off = 0; m->arena.high = 0;
+  m->kcache.assign(m->n_xf, nullptr); m->vcache.assign(m->n_xf, nullptr);
+  UNetRun r{m, nullptr, Bx, nullptr, 0, true};
+  GILL_TRY(r.forward(nullptr, nullptr));
+  const size_t need = m->arena.high + (1 << 20);
+  GILL_TRY(m->pool.alloc(&m->arena_mem, need, true));
+  m->arena.base = m->arena_mem; m->arena.cap = need; m->arena.dry = false; m->arena.off = 0;
+  GILL_TRY(m->pool.alloc(&m->gn_stats, (size_t)Bx * 64 * 2));
+  m->splitk_ws_floats = (size_t)48 << 20;   // 192 MiB of fp32 partials
+  GILL_TRY(m->pool.alloc(&m->splitk_ws, m->splitk_ws_floats, false));
+  // cross-attention K/V caches
+  m->ctx_pad = round_up(c.ctx_len, 32);
+  auto alloc_cache = [&](const XfW& w) -> int {
+    GILL_TRY(m->pool.alloc(&m->kcache[w.layer_id], (size_t)Bx * c.num_heads * m->ctx_pad * w.dp, true));
+    GILL_TRY(m->pool.alloc(&m->vcache[w.layer_id], (size_t)Bx * c.num_heads * w.dpv * m->ctx_pad, true));
+    return 0;
+  };
+  for (int i = 0; i < 3; ++i) for (const XfW& w : m->down_xf[i]) GILL_TRY(alloc_cache(w));
+  GILL_TRY(alloc_cache(m->mid_xf));
+  for (int i = 1; i < 4; ++i) for (const XfW& w : m->up_xf[i]) GILL_TRY(alloc_cache(w));
+  // time embedding scratch: up to 1024 rows (timesteps of a schedule, or per-sample timesteps)
+  m->temb_rows_cap = 1024 > Bx ? 1024 : Bx;
+  GILL_TRY(m->pool.alloc(&m->t_dev, (size_t)m->temb_rows_cap));
+  GILL_TRY(m->pool.alloc(&m->t_sin, (size_t)m->temb_rows_cap * c.block_out_channels[0]));
+  GILL_TRY(m->pool.alloc(&m->t_h1, (size_t)m->temb_rows_cap * m->temb_dim));
+  GILL_TRY(m->pool.alloc(&m->t_h2, (size_t)m->temb_rows_cap * m->temb_dim));
+  GILL_TRY(m->pool.alloc(&m->temb_table, (size_t)m->temb_rows_cap * m->temb_total));
+  // loop state
+  GILL_TRY(m->pool.alloc(&m->lat, (size_t)Bx * n_lat));
+  GILL_TRY(m->pool.alloc(&m->lat2, (size_t)Bx * n_lat));
+  GILL_TRY(m->pool.alloc(&m->eps, (size_t)Bx * n_lat));
+  GILL_TRY(m->pool.alloc(&m->cur_sample, (size_t)Bx * n_lat));
+  GILL_TRY(m->pool.alloc(&m->ets, (size_t)4 * Bx * n_lat));
+  GILL_TRY(m->pool.alloc(&m->ctx_full, (size_t)Bx * c.ctx_len * c.cross_attention_dim));
+  return 0;
+}
+
+// time-embedding MLP + all resnet time projections for `rows` timesteps -> m->temb_table [rows][temb_total]
+static int unet_time_table(gill_unet* m, const float* t_host, int rows, hipStream_t s) {
+  GILL_REQUIRE(rows >= 1 && rows <= m->temb_rows_cap, "too many timesteps for the time-embedding scratch");
+  const int c0 = m->cfg.block_out_channels[0], td = m->temb_dim;
+  GILL_CHECK_HIP(hipMemcpyAsync(m->t_dev, t_host, sizeof(float) * rows, hipMemcpyHostToDevice, s));
+  GILL_CHECK_HIP(hipStreamSynchronize(s));   // t_host may be a transient host buffer
+  GILL_TRY(timestep_embed_launch(m->t_dev, rows, c0, m->t_sin, s));
+  GemmArgs g;
+  g.M = rows; g.N = td; g.K = c0; g.K1 = c0; g.A = m->t_sin; g.lda = c0; g.W = m->te1.w; g.bias = m->te1.b;
+  g.act = ACT_SILU; g.C = m->t_h1; g.ldc = td;
+  GILL_TRY(gemm_launch(g, s));
+  GemmArgs g2;
+  g2.M = rows; g2.N = td; g2.K = td; g2.K1 = td; g2.A = m->t_h1; g2.lda = td; g2.W = m->te2.w; g2.bias = m->te2.b;
+  g2.act = ACT_SILU;   // every resnet applies SiLU to emb before its time_emb_proj
+  g2.C = m->t_h2; g2.ldc = td;
+  GILL_TRY(gemm_launch(g2, s));
+  GemmArgs g3;
+  g3.M = rows; g3.N = m->temb_total; g3.K = td; g3.K1 = td; g3.A = m->t_h2; g3.lda = td; g3.W = m->temb_proj_w;
+  g3.bias = m->temb_proj_b; g3.out_mode = OUT_F32; g3.C = m->temb_table; g3.ldc = m->temb_total;
+  return gemm_launch(g3, s);
+}
+
+// cross-attention K/V of every transformer layer for ctx (Bx,77,ctx_dim)
+static int unet_ctx_cache(gill_unet* m, const bf16_t* ctx, int Bx, hipStream_t s) {
+  const gill_unet_config& c = m->cfg;
+  auto one = [&](const XfW& w) -> int {
+    GemmArgs g;
+    g.M = Bx * c.ctx_len; g.N = 2 * c.num_heads * w.dp; g.K = c.cross_attention_dim; g.K1 = g.K;
+    g.A = ctx; g.lda = c.cross_attention_dim; g.W = w.wkv2;
+    g.out_mode = OUT_QKV; g.Ck = m->kcache[w.layer_id]; g.Cvt = m->vcache[w.layer_id];
+    g.heads = c.num_heads; g.dp = w.dp; g.dpv = w.dpv; g.ntok = c.ctx_len; g.ntok_pad_q = m->ctx_pad;
+    g.ntok_pad_kv = m->ctx_pad; g.seg_base = 1;
+    return gemm_launch(g, s);
+  };
+  for (int i = 0; i < 3; ++i) for (const XfW& w : m->down_xf[i]) GILL_TRY(one(w));
+  GILL_TRY(one(m->mid_xf));
+  for (int i = 1; i < 4; ++i) for (const XfW& w : m->up_xf[i]) GILL_TRY(one(w));
+  return 0;
+}
+
+extern "C" int gill_unet_forward(gill_unet* m, const float* sample, const float* timesteps_host, const void* ctx_bf16,
+                                 int Bx, float* eps_out, void* stream) {
+  GILL_REQUIRE(m && sample && timesteps_host && ctx_bf16 && eps_out, "null argument");
+  GILL_REQUIRE(Bx >= 1 && Bx <= m->cfg.max_batch, "batch exceeds the UNet handle's max_batch");
+  hipStream_t s = (hipStream_t)stream;
+  GILL_TRY(unet_time_table(m, timesteps_host, Bx, s));
+  GILL_TRY(unet_ctx_cache(m, (const bf16_t*)ctx_bf16, Bx, s));
+  UNetRun r{m, s, Bx, m->temb_table, m->temb_total, false};
+  return r.forward(sample, eps_out);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// PNDM (PLMS, skip_prk_steps=True, steps_offset=1, scaled_linear betas 0.00085..0.012 over 1000 train steps).
+static void pndm_alphas_cumprod(std::vector<float>& ac) {
+  const int T = 1000;
+  ac.resize(T);
+  const float a = sqrtf(0.00085f), b = sqrtf(0.012f);
+  const float step = (b - a) / (float)(T - 1);
+  float prod = 1.f;
+  for (int i = 0; i < T; ++i) {
+    // torch.linspace (fp32): symmetric evaluation around the midpoint
+    const float v = (i < T / 2) ? a + step * (float)i : b - step * (float)(T - 1 - i);
+    const float beta = v * v;
+    prod *= (1.f - beta);
+    ac[i] = prod;
+  }
+}
+static void pndm_timesteps(int num_steps, std::vector<int>& ts, int* ratio_out) {
+  const int ratio = 1000 / num_steps;
+  std::vector<int> base(num_steps);
+  for (int i = 0; i < num_steps; ++i) base[i] = i * ratio + 1;   // steps_offset = 1
+  // plms_timesteps = concat(base[:-1], base[-2:-1], base[-1:])[::-1]
+  std::vector<int> seq(base.begin(), base.end() - 1);
+  if (num_steps >= 2) seq.push_back(base[num_steps - 2]);
+  seq.push_back(base[num_steps - 1]);
+  ts.assign(seq.rbegin(), seq.rend());
+  *ratio_out = ratio;
+}
+
+extern "C" int gill_pndm_schedule(int num_steps, int32_t* timesteps_out, double* alphas_cumprod_out) {
+  GILL_REQUIRE(num_steps >= 2 && num_steps <= 1000, "num_steps out of range");
+  std::vector<int> ts; int ratio;
+  pndm_timesteps(num_steps, ts, &ratio);
+  if (timesteps_out) for (size_t i = 0; i < ts.size(); ++i) timesteps_out[i] = ts[i];
+  if (alphas_cumprod_out) {
+    std::vector<float> ac; pndm_alphas_cumprod(ac);
+    for (int i = 0; i < 1000; ++i) alphas_cumprod_out[i] = (double)ac[i];
+  }
+  return (int)ts.size();
+}
+
+extern "C" int gill_sd_denoise(gill_unet* m, const void* cond_bf16, const void* uncond_bf16, const float* latents0, int B,
+                               int num_steps, float guidance, float* latents_out, void* stream) {
+  GILL_REQUIRE(m && cond_bf16 && latents0 && latents_out, "null argument");
+  GILL_REQUIRE(num_steps >= 2 && num_steps <= 1000, "num_steps out of range");
+  const bool cfg = guidance > 1.0f;     // do_classifier_free_guidance (custom_sd.py:588)
+  const int Bx = cfg ? 2 * B : B;
+  GILL_REQUIRE(B >= 1 && Bx <= m->cfg.max_batch, "batch exceeds the UNet handle's max_batch");
+  GILL_REQUIRE(!cfg || uncond_bf16 != nullptr, "uncond embedding required when guidance > 1");
+  hipStream_t s = (hipStream_t)stream;
+  const gill_unet_config& c = m->cfg;
+  const int L = c.sample_size;
+  const int64_t n_lat = (int64_t)c.in_channels * L * L;
+  const size_t ctx_elems = (size_t)c.ctx_len * c.cross_attention_dim;
+
+  std::vector<int> ts; int ratio;
+  pndm_timesteps(num_steps, ts, &ratio);
+  std::vector<float> ac; pndm_alphas_cumprod(ac);
+  const int ncalls = (int)ts.size();
+  GILL_REQUIRE(ncalls <= m->temb_rows_cap, "too many steps for the time-embedding scratch");
+
+  // hoisted: time-embedding table for every call, prompt K/V caches
+  std::vector<float> tf(ncalls);
+  for (int i = 0; i < ncalls; ++i) tf[i] = (float)ts[i];
+  GILL_TRY(unet_time_table(m, tf.data(), ncalls, s));
+  // prompt_embeds = cat([negative_prompt_embeds.repeat(B), prompt_embeds])  (custom_sd.py:365-371)
+  if (cfg) {
+    for (int b = 0; b < B; ++b)
+      GILL_CHECK_HIP(hipMemcpyAsync(m->ctx_full + (size_t)b * ctx_elems, uncond_bf16, sizeof(bf16_t) * ctx_elems,
+                                    hipMemcpyDeviceToDevice, s));
+    GILL_CHECK_HIP(hipMemcpyAsync(m->ctx_full + (size_t)B * ctx_elems, cond_bf16, sizeof(bf16_t) * ctx_elems * B,
+                                  hipMemcpyDeviceToDevice, s));
+  } else {
+    GILL_CHECK_HIP(hipMemcpyAsync(m->ctx_full, cond_bf16, sizeof(bf16_t) * ctx_elems * B, hipMemcpyDeviceToDevice, s));
+  }
+  GILL_TRY(unet_ctx_cache(m, m->ctx_full, Bx, s));
+  GILL_CHECK_HIP(hipMemcpyAsync(m->lat, latents0, sizeof(float) * n_lat * B, hipMemcpyDeviceToDevice, s));
+
+  int counter = 0, n_ets = 0, last = -1;
+  for (int i = 0; i < ncalls; ++i) {
+    // latent_model_input = cat([latents]*2); scale_model_input is the identity for PNDM
+    GILL_CHECK_HIP(hipMemcpyAsync(m->lat2, m->lat, sizeof(float) * n_lat * B, hipMemcpyDeviceToDevice, s));
+    if (cfg)
+      GILL_CHECK_HIP(hipMemcpyAsync(m->lat2 + n_lat * B, m->lat, sizeof(float) * n_lat * B, hipMemcpyDeviceToDevice, s));
+    UNetRun r{m, s, Bx, m->temb_table + (size_t)i * m->temb_total, 0, false};
+    GILL_TRY(r.forward(m->lat2, m->eps));
+
+    int t = ts[i];
+    int prev_t = t - ratio;
+    PlmsStepArgs a;
+    a.eps = m->eps; a.lat = m->lat; a.cur_sample = m->cur_sample; a.ets = m->ets;
+    a.B = B; a.n = n_lat; a.guidance = guidance; a.cfg = cfg ? 1 : 0;
+    a.slot_new = -1; a.s1 = a.s2 = a.s3 = 0;
+    if (counter != 1) {
+      a.slot_new = (last + 1) & 3;
+      a.s1 = last & 3; a.s2 = (last + 3) & 3; a.s3 = (last + 2) & 3;
+      last = a.slot_new;
+      if (n_ets < 4) ++n_ets;
+    } else {
+      prev_t = t; t = t + ratio;
+      a.s1 = last & 3;
+    }
+    if (n_ets == 1 && counter == 0) a.mode = 0;
+    else if (n_ets == 1 && counter == 1) a.mode = 1;
+    else if (n_ets == 2) a.mode = 2;
+    else if (n_ets == 3) a.mode = 3;
+    else a.mode = 4;
+    // _get_prev_sample (epsilon prediction)
+    const double at = ac[t];
+    const double ap = prev_t >= 0 ? (double)ac[prev_t] : (double)ac[0];   // set_alpha_to_one = False
+    const double bt = 1.0 - at, bp = 1.0 - ap;
+    const double sample_coeff = sqrt(ap / at);
+    const double denom = at * sqrt(bp) + sqrt(at * bt * ap);
+    a.sample_coeff = (float)sample_coeff;
+    a.eps_coeff = (float)((ap - at) / denom);
+    GILL_TRY(plms_step_launch(a, s));
+    ++counter;
+  }
+  GILL_CHECK_HIP(hipMemcpyAsync(latents_out, m->lat, sizeof(float) * n_lat * B, hipMemcpyDeviceToDevice, s));
+  return 0;
+}

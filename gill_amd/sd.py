@@ -1,0 +1,154 @@
+"""Stable Diffusion side of the hot path: the object GILL holds as `self.sd_pipe`.
+
+The reference builds `StableDiffusionPipeline.from_pretrained("runwayml/stable-diffusion-v1-5", fp16).to("cuda")`
+(gill/models.py:550-551) and calls it as
+    self.sd_pipe(prompt_embeds=gen_emb[i:i+8], generator=generator, guidance_scale=..., num_inference_steps=...).images
+(gill/models.py:730-731); the loop it runs is restated in-tree at gill/custom_sd.py:567-651.
+`GillSDPipeline` keeps that call signature (prompt_embeds / negative_prompt_embeds / latents / generator /
+guidance_scale / num_inference_steps / output_type) and runs the UNet + PNDM loop in libgill_amd
+(gill_sd_denoise: csrc/unet.hip).
+
+Not built yet: the VAE decode + PIL conversion.  `output_type="latent"` (default
+here) returns the final latents (B,4,64,64) fp32 in `.images`; `output_type="pil"` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Union
+
+import torch
+
+from . import _native as N
+from .synth import UNetConfig
+
+
+@dataclass
+class PipelineOutput:
+  images: object                      # latents tensor (B,4,L,L) when output_type == "latent"
+  nsfw_content_detected: Optional[List[bool]] = None
+
+
+class GillSDPipeline:
+  def __init__(self, unet_state: Dict[str, torch.Tensor], cfg: UNetConfig, uncond_embeds: torch.Tensor,
+               device: Union[str, torch.device] = "cuda", max_batch: int = 16):
+    self.cfg = cfg
+    self.device = torch.device(device if str(device) != "cuda" else "cuda:0")
+    if self.device.type != "cuda":
+      raise N.GillNativeError("GillSDPipeline runs only on an MI355X through libgill_amd")
+    self.max_batch = max_batch
+    self.uncond_embeds = uncond_embeds.to(self.device, torch.bfloat16).reshape(1, cfg.ctx_len, cfg.cross_attention_dim).contiguous()
+    ccfg = N.gill_unet_config(in_channels=cfg.in_channels, out_channels=cfg.out_channels,
+                              layers_per_block=cfg.layers_per_block, cross_attention_dim=cfg.cross_attention_dim,
+                              num_heads=cfg.num_heads, norm_num_groups=cfg.norm_num_groups,
+                              sample_size=cfg.sample_size, ctx_len=cfg.ctx_len, max_batch=max_batch)
+    for i in range(4):
+      ccfg.block_out_channels[i] = cfg.block_out_channels[i]
+    arr, keep = N.make_tensor_table(unet_state, self.device)
+    h = C.c_void_p()
+    with torch.cuda.device(self.device):
+      N.check(N.lib().gill_unet_create(C.byref(h), C.byref(ccfg), arr, len(unet_state)))
+    del keep
+    self._h = h
+
+  # ---- construction from a local diffusers directory (no diffusers import: safetensors + json only)
+  @classmethod
+  def from_pretrained(cls, model_dir: str, uncond_embeds: Optional[torch.Tensor] = None, device="cuda", max_batch: int = 16,
+                      **_ignored):
+    from safetensors.torch import load_file
+    with open(os.path.join(model_dir, "unet", "config.json")) as f:
+      c = json.load(f)
+    heads = c["attention_head_dim"] if isinstance(c["attention_head_dim"], int) else c["attention_head_dim"][0]
+    cfg = UNetConfig(in_channels=c["in_channels"], out_channels=c["out_channels"],
+                     block_out_channels=tuple(c["block_out_channels"]), layers_per_block=c["layers_per_block"],
+                     cross_attention_dim=c["cross_attention_dim"], num_heads=heads,
+                     norm_num_groups=c["norm_num_groups"], sample_size=c["sample_size"])
+    wpath = os.path.join(model_dir, "unet", "diffusion_pytorch_model.safetensors")
+    sd = load_file(wpath)
+    if uncond_embeds is None:
+      # CLIP-text("") — plumbing through transformers when its files are on disk
+      from transformers import CLIPTextModel, CLIPTokenizer
+      tok = CLIPTokenizer.from_pretrained(os.path.join(model_dir, "tokenizer"))
+      enc = CLIPTextModel.from_pretrained(os.path.join(model_dir, "text_encoder"))
+      with torch.no_grad():
+        ids = tok([""], padding="max_length", max_length=tok.model_max_length, return_tensors="pt").input_ids
+        uncond_embeds = enc(ids)[0]
+    return cls(sd, cfg, uncond_embeds, device, max_batch)
+
+  def to(self, device):   # the reference chains .to("cuda")
+    assert torch.device(device).type == "cuda"
+    return self
+
+  def __del__(self):
+    try:
+      if getattr(self, "_h", None):
+        N.lib().gill_unet_destroy(self._h)
+        self._h = None
+    except Exception:
+      pass
+
+  # ---- low level: one UNet forward (used by parity tests)
+  def unet(self, sample: torch.Tensor, timesteps: torch.Tensor, encoder_hidden_states: torch.Tensor) -> torch.Tensor:
+    Bx = sample.shape[0]
+    sample = sample.to(self.device, torch.float32).contiguous()
+    ctx = encoder_hidden_states.to(self.device, torch.bfloat16).contiguous()
+    ts = timesteps.detach().float().cpu().reshape(-1)
+    if ts.numel() == 1:
+      ts = ts.expand(Bx).contiguous()
+    tarr = (C.c_float * Bx)(*[float(v) for v in ts])
+    out = torch.empty_like(sample)
+    with torch.cuda.device(self.device):
+      N.check(N.lib().gill_unet_forward(self._h, N.ptr(sample), tarr, N.ptr(ctx), Bx, N.ptr(out), N.current_stream()))
+    return out
+
+  def prepare_latents(self, batch_size: int, generator=None, latents: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """custom_sd.py:458-473.  Latents are drawn on the CPU generator (cuRAND Philox streams of the reference
+    notebooks are not reproducible off-NVIDIA); init_noise_sigma == 1 for PNDM."""
+    L = self.cfg.sample_size
+    shape = (batch_size, self.cfg.in_channels, L, L)
+    if isinstance(generator, list) and len(generator) != batch_size:
+      raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                       f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+    if latents is None:
+      if isinstance(generator, list):
+        latents = torch.cat([torch.randn((1,) + shape[1:], generator=g, device=g.device if g is not None else "cpu",
+                                         dtype=torch.float32) for g in generator], 0)
+      else:
+        gdev = generator.device if generator is not None else torch.device("cpu")
+        latents = torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32)
+    return latents.to(self.device, torch.float32).contiguous()
+
+  @torch.no_grad()
+  def __call__(self, prompt=None, height=None, width=None, num_inference_steps: int = 50, guidance_scale: float = 7.5,
+               negative_prompt=None, num_images_per_prompt: int = 1, eta: float = 0.0, generator=None,
+               latents: Optional[torch.Tensor] = None, prompt_embeds: Optional[torch.Tensor] = None,
+               negative_prompt_embeds: Optional[torch.Tensor] = None, output_type: str = "latent", return_dict: bool = True,
+               **_ignored):
+    if prompt is not None:
+      raise ValueError("GillSDPipeline is driven by prompt_embeds (gill/models.py:730); text prompts need the CLIP text "
+                       "encoder, which is outside this path")
+    if prompt_embeds is None:
+      raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+    L = self.cfg.sample_size
+    if (height is not None and height != L * 8) or (width is not None and width != L * 8):
+      raise ValueError(f"this handle was built for {L * 8}x{L * 8} images")
+    if output_type not in ("latent",):
+      raise NotImplementedError("VAE decode / PIL output is the next component to build (SURVEY.md section 8f rank 1); "
+                                "call with output_type='latent'")
+    cond = prompt_embeds.to(self.device, torch.bfloat16)
+    if num_images_per_prompt != 1:
+      cond = cond.repeat_interleave(num_images_per_prompt, dim=0)
+    cond = cond.contiguous()
+    B = cond.shape[0]
+    uncond = self.uncond_embeds if negative_prompt_embeds is None else \
+        negative_prompt_embeds.to(self.device, torch.bfloat16)[:1].contiguous()
+    lat0 = self.prepare_latents(B, generator, latents)
+    out = torch.empty_like(lat0)
+    with torch.cuda.device(self.device):
+      N.check(N.lib().gill_sd_denoise(self._h, N.ptr(cond), N.ptr(uncond), N.ptr(lat0), B, int(num_inference_steps),
+                                      float(guidance_scale), N.ptr(out), N.current_stream()))
+    if not return_dict:
+      return (out, None)
+    return PipelineOutput(images=out)

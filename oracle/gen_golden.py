@@ -1,0 +1,167 @@
+"""Generates tests/golden/*.npz by RUNNING THE REFERENCE (kohjingyu/gill at /root/reference) on CPU.
+
+Run once in the build container:   python oracle/gen_golden.py
+Nothing of the reference travels: only seeded inputs and the reference's numeric outputs are stored (weights are
+regenerated in the tests from gill_amd.synth's counter-based generator with the seeds recorded here).
+
+What is executed from the reference, unmodified:
+  F1  gill.layers.TextFcLayer(mode='gill_mapper').forward                       (gill/layers.py:28-53)
+  F2  gill.models.GILLModel.forward(mode='generation')                          (gill/models.py:164-441)
+  F3  gill.models.GILLModel.generate(..., gen_scale_factor=1e5)                 (gill/models.py:443-532)
+  F4  gill.models.GILL(load_sd=False).generate_for_images_and_texts             (gill/models.py:582-762)
+Harness shim: `diffusers` / `torchvision` are absent here, so empty stand-in modules are placed in
+sys.modules BEFORE importing gill.models (its stage-3 code is never called: load_sd=False); random-init OPT / CLIP
+models are saved to local dirs whose paths contain 'facebook/opt' and 'clip' (string checks at models.py:56,78); a
+stand-in tokenizer object (gill_amd.synth.HashTokenizer) replaces the GPT2 tokenizer, whose vocab files are not
+available offline.  transformers here is 5.x (reference pins 4.30.2): hidden_states[-1] is post-final-LN in both.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+"""
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from gill_amd import synth  # noqa: E402
+
+
+def _import_reference():
+  import transformers  # noqa: F401  (must be imported before the stubs)
+  for name in ("diffusers", "torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
+    if name not in sys.modules:
+      sys.modules[name] = types.ModuleType(name)
+  sys.modules["diffusers"].StableDiffusionPipeline = object
+  sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+  sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+  sys.path.insert(0, REF)
+  import gill.layers as ref_layers
+  import gill.models as ref_models
+  import gill.utils as ref_utils
+  from transformers import CLIPImageProcessor
+  ref_utils.get_feature_extractor_for_model = lambda name, **kw: CLIPImageProcessor()
+  return ref_layers, ref_models
+
+
+def golden_mapper(ref_layers):
+  """F1: reference TextFcLayer on synth weights (weights bf16-rounded, as the GPU engine stores them)."""
+  for in_dim, B, tag in ((768, 2, "d768_b2"), (4096, 1, "d4096_b1")):
+    cfg = synth.MapperConfig(in_dim=in_dim)
+    sd = {k: v.bfloat16().float() for k, v in synth.mapper_state_dict(cfg, seed=11).items()}
+    layer = ref_layers.TextFcLayer(in_dim, 768, num_input_tokens=8, num_output_tokens=77, mode="gill_mapper")
+    layer.load_state_dict(sd, strict=True)
+    layer.eval()
+    x = synth.normal(f"mapper_x_{tag}", (B, 8, in_dim), 11).bfloat16().float()
+    e = synth.normal(f"mapper_e_{tag}", (1, 8, in_dim), 11, 0.5).bfloat16().float()
+    with torch.no_grad():
+      y = layer(x, e)
+      y_b = layer(x, e.repeat(B, 1, 1))
+    assert torch.equal(y, y_b)
+    np.savez_compressed(os.path.join(OUT, f"mapper_{tag}.npz"), x=x.numpy(), e=e.numpy(), y=y.numpy(),
+                        seed=np.int64(11), in_dim=np.int64(in_dim))
+    print("F1", tag, tuple(y.shape), float(y.abs().mean()))
+
+
+def golden_gillmodel(ref_models, tmp):
+  """F2-F4 on an opt-125m-shaped random model (12 layers, D=768, 12 heads) with the resized 50274 vocabulary."""
+  from transformers import CLIPVisionConfig, CLIPVisionModel, OPTConfig, OPTForCausalLM
+  ocfg = synth.OptConfig.opt_125m()
+  ocfg.vocab_size = 50272     # HF opt-125m vocab before resize_token_embeddings(50274) (models.py:73)
+  opt_dir = os.path.join(tmp, "facebook/opt-125m-shape")
+  clip_dir = os.path.join(tmp, "openai/clip-tiny")
+  hf_cfg = OPTConfig(vocab_size=ocfg.vocab_size, hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_layers,
+                     ffn_dim=ocfg.ffn_dim, num_attention_heads=ocfg.num_heads, max_position_embeddings=2048,
+                     word_embed_proj_dim=ocfg.hidden_size, do_layer_norm_before=True, dropout=0.0)
+  hf = OPTForCausalLM(hf_cfg)
+  sd_full = synth.opt_state_dict(synth.OptConfig(vocab_size=50274, hidden_size=768, num_layers=12, num_heads=12,
+                                                 ffn_dim=3072), seed=5)
+  sd_full = {k: v.bfloat16().float() for k, v in sd_full.items()}
+  sd_hf = dict(sd_full)
+  sd_hf["model.decoder.embed_tokens.weight"] = sd_full["model.decoder.embed_tokens.weight"][:50272].clone()
+  sd_hf["lm_head.weight"] = sd_hf["model.decoder.embed_tokens.weight"]
+  hf.load_state_dict(sd_hf, strict=True)
+  hf.save_pretrained(opt_dir)
+  CLIPVisionModel(CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2,
+                                   image_size=32, patch_size=16)).save_pretrained(clip_dir)
+
+  tok = synth.HashTokenizer()
+  args = types.SimpleNamespace(freeze_lm=True, freeze_vm=True, opt_version=opt_dir, visual_encoder=clip_dir,
+                               n_visual_tokens=4, ret_emb_dim=256, gen_emb_dim=768, text_emb_layers=[-1],
+                               text_fc_mode="gill_mapper", ret_text_fc_mode="linear", num_tokens=8, num_clip_tokens=77,
+                               retrieval_token_idx=synth.IMG_TOKEN_IDS, gen_token_idx=synth.IMG_TOKEN_IDS)
+  gill = ref_models.GILL(tok, args, load_sd=False, num_gen_images=1)
+  gm = gill.model
+  # the two resized rows and the [IMG] rows: take them from the synth table (as load_gill does for [IMG] rows)
+  with torch.no_grad():
+    gm.input_embeddings.weight.copy_(sd_full["model.decoder.embed_tokens.weight"])
+    mcfg = synth.MapperConfig(in_dim=768)
+    msd = {k: v.bfloat16().float() for k, v in synth.mapper_state_dict(mcfg, seed=7).items()}
+    gm.gen_text_hidden_fcs[0].load_state_dict(msd, strict=True)
+  gill.eval()
+
+  # ---- F2: batched forward, ragged right-padded batch (no attention mask: models.py:363-365)
+  B, Tp = 3, 14
+  ids = synth.synthetic_prompt_ids(B, Tp, seed=3)              # (B, Tp+8), last 8 = [IMG0..7]
+  lens = [Tp + 8, Tp + 8 - 3, Tp + 8 - 6]
+  T = Tp + 8
+  labels = torch.full((B, T), tok.pad_token_id, dtype=torch.int64)
+  for b in range(B):
+    n_words = lens[b] - 8
+    labels[b, :n_words] = ids[b, :n_words]
+    labels[b, n_words:lens[b]] = torch.tensor(synth.IMG_TOKEN_IDS)
+  caption_len = torch.tensor(lens, dtype=torch.int64)
+  with torch.no_grad():
+    out = gm(torch.zeros(B, 3, 32, 32), labels.clone(), caption_len, mode="generation")
+  last_embedding, llm_hidden = out[2], out[7][0]
+  np.savez_compressed(os.path.join(OUT, "gillmodel_forward_opt125m.npz"), labels=labels.numpy(), caption_len=caption_len.numpy(),
+                      llm_hidden=llm_hidden.numpy(), last_embedding=last_embedding.numpy(), full_labels=out[1].numpy(),
+                      opt_seed=np.int64(5), mapper_seed=np.int64(7))
+  print("F2", tuple(llm_hidden.shape), tuple(last_embedding.shape), float(llm_hidden.abs().mean()), float(last_embedding.abs().mean()))
+
+  # ---- F3: the generate() loop (2 steps, forced [IMG]) vs the single pass
+  prompt = labels[0:1, :Tp]
+  with torch.no_grad():
+    emb = gm.input_embeddings(prompt)
+    g_ids, g_embs, g_logits = gm.generate(emb, 2, gen_scale_factor=1e5)
+  hid_loop = g_embs[-1][:, Tp:Tp + 8]
+  delta = float((hid_loop - llm_hidden[0:1]).abs().max())
+  np.savez_compressed(os.path.join(OUT, "gillmodel_generate_opt125m.npz"), prompt=prompt.numpy(), gen_ids=g_ids.numpy(),
+                      hidden_img=hid_loop.numpy(), last_logits_step0=g_logits[0].numpy()[:, ::97].copy(),
+                      loop_vs_single_maxabs=np.float64(delta))
+  print("F3 ids", g_ids.tolist(), "loop-vs-single max|d| =", delta)
+
+  # ---- F4: public API shape/values
+  text = "a small red fox jumps over the lazy dog"
+  with torch.no_grad():
+    ret = gill.generate_for_images_and_texts([text], num_words=2, gen_scale_factor=1e5)
+  assert isinstance(ret[0], str) and isinstance(ret[1], dict)
+  gen = ret[1]["gen"][0]
+  np.savez_compressed(os.path.join(OUT, "gill_api_opt125m.npz"), text=np.array(text), caption=np.array(ret[0]),
+                      decision=np.array(str(ret[1]["decision"])), ret_len=np.int64(len(ret[1]["ret"])), gen_emb=gen.numpy())
+  print("F4", repr(ret[0]), ret[1]["decision"], tuple(gen.shape))
+
+
+def main():
+  os.makedirs(OUT, exist_ok=True)
+  torch.manual_seed(0)
+  torch.set_num_threads(8)
+  ref_layers, ref_models = _import_reference()
+  golden_mapper(ref_layers)
+  tmp = tempfile.mkdtemp(prefix="gill_golden_")
+  try:
+    golden_gillmodel(ref_models, tmp)
+  finally:
+    shutil.rmtree(tmp, ignore_errors=True)
+  print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+  main()

@@ -1,0 +1,200 @@
+"""Stage-level parity on the MI355X, through the C ABI (ctypes -> libgill_amd.so):
+
+  stage 1+2  OPT [IMG] hidden states + GILLMapper  vs  the REFERENCE outputs in tests/golden (bar: SD-embedding MSE < 1e-4)
+  stage 3    UNet forward / CFG+PLMS loop          vs  the CPU oracle (parity unpinned: diffusers is absent, see oracle/)
+
+Weights are bf16-rounded before they reach either side, so the comparison measures the arithmetic, not the storage
+rounding the reference's own .bfloat16() model has as well.  Tolerances are stated next to each assert."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from gill_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _bfw(sd):
+  return {k: v.bfloat16().float() for k, v in sd.items()}
+
+
+def _stats(name, got, ref):
+  got, ref = got.float().cpu(), ref.float().cpu()
+  mse = ((got - ref) ** 2).mean().item()
+  rel = ((got - ref).norm() / ref.norm().clamp_min(1e-12)).item()
+  cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
+  print(f"[{name}] mse={mse:.3e} rel_l2={rel:.3e} cos={cos:.6f} max_abs={(got - ref).abs().max().item():.3e} ref_rms={ref.pow(2).mean().sqrt().item():.3f}")
+  return mse, rel, cos
+
+
+# ------------------------------------------------------------------------------------------------ stage 2
+@pytest.mark.parametrize("tag,in_dim", [("d768_b2", 768), ("d4096_b1", 4096)])
+def test_mapper_vs_reference_golden(cuda, tag, in_dim):
+  from gill_amd.layers import TextFcLayer
+  g = np.load(os.path.join(GOLD, f"mapper_{tag}.npz"))
+  layer = TextFcLayer(in_dim, 768, num_input_tokens=8, num_output_tokens=77, mode="gill_mapper")
+  layer.load_state_dict(_bfw(synth.mapper_state_dict(synth.MapperConfig(in_dim=in_dim), seed=int(g["seed"]))), strict=True)
+  layer = layer.to(cuda)
+  x, e = torch.from_numpy(g["x"]).to(cuda), torch.from_numpy(g["e"]).to(cuda)
+  y = layer(x, e)
+  mse, rel, cos = _stats(f"mapper {tag}", y, torch.from_numpy(g["y"]))
+  assert y.shape == (x.shape[0], 77, 768)
+  assert mse < 1e-4          # north_star bar: SD-embedding MSE vs reference < 1e-4
+  assert rel < 2e-2
+  # broadcasting of input_embs (B vs 1) is numerically the same call
+  y2 = layer(x, e.repeat(x.shape[0], 1, 1))
+  assert torch.equal(y, y2)
+
+
+# ------------------------------------------------------------------------------------------------ stage 1 (+2)
+def _gill_opt125m(cuda, load_sd=False, sd_pipe=None):
+  from gill_amd.models import GILL
+  tok = synth.HashTokenizer()
+  ocfg = synth.OptConfig(vocab_size=50274, hidden_size=768, num_layers=12, num_heads=12, ffn_dim=3072)
+  args = SimpleNamespace(freeze_lm=True, freeze_vm=True, opt_version="facebook/opt-125m", visual_encoder="openai/clip-vit-base-patch16",
+                         n_visual_tokens=4, ret_emb_dim=256, gen_emb_dim=768, text_emb_layers=[-1], text_fc_mode="gill_mapper",
+                         ret_text_fc_mode="linear", num_tokens=8, num_clip_tokens=77, retrieval_token_idx=synth.IMG_TOKEN_IDS,
+                         gen_token_idx=synth.IMG_TOKEN_IDS, opt_state_dict=_bfw(synth.opt_state_dict(ocfg, seed=5)))
+  g = GILL(tok, args, load_sd=load_sd, sd_pipe=sd_pipe)
+  g.model.gen_text_hidden_fcs[0].load_state_dict(_bfw(synth.mapper_state_dict(synth.MapperConfig(in_dim=768), seed=7)), strict=True)
+  g = g.eval()
+  g = g.bfloat16()        # the chain load_gill applies (models.py:875-877)
+  g = g.cuda()
+  return g
+
+
+@pytest.fixture(scope="module")
+def gill125(cuda):
+  return _gill_opt125m(cuda)
+
+
+def test_gillmodel_forward_vs_reference_golden(cuda, gill125):
+  """GILLModel.forward(mode='generation') on the ragged right-padded batch of the golden fixture."""
+  g = np.load(os.path.join(GOLD, "gillmodel_forward_opt125m.npz"))
+  labels, cap = torch.from_numpy(g["labels"]), torch.from_numpy(g["caption_len"])
+  out = gill125(torch.zeros(labels.shape[0], 3, 32, 32, device=cuda), labels.to(cuda), cap, mode="generation")
+  assert len(out) == 8
+  llm_hidden, last_embedding = out[7][0], out[2]
+  assert torch.equal(out[1].cpu(), torch.from_numpy(g["full_labels"]))
+  mse_h, rel_h, _ = _stats("opt125m [IMG] hidden", llm_hidden, torch.from_numpy(g["llm_hidden"]))
+  mse_e, rel_e, _ = _stats("opt125m SD embedding", last_embedding, torch.from_numpy(g["last_embedding"]))
+  assert rel_h < 3e-2        # bf16 GEMM operands vs the reference's fp32 CPU run, 12 layers
+  assert mse_e < 1e-4        # north_star bar
+  assert last_embedding.shape == (labels.shape[0], 77, 768)
+
+
+def test_generate_loop_and_public_api_vs_reference_golden(cuda, gill125):
+  g = np.load(os.path.join(GOLD, "gillmodel_generate_opt125m.npz"))
+  prompt = torch.from_numpy(g["prompt"]).to(cuda)
+  emb = gill125.model.input_embeddings(prompt)
+  ids, embs, logits = gill125.model.generate(emb, 2, gen_scale_factor=1e5)
+  assert ids.cpu().tolist() == g["gen_ids"].tolist()                        # [IMG0..7] forced, twice
+  T0 = prompt.shape[1]
+  _, rel, _ = _stats("generate() hidden at [IMG]", embs[-1][:, T0:T0 + 8], torch.from_numpy(g["hidden_img"]))
+  assert rel < 3e-2
+  assert logits[0].shape == (1, 50274) and logits[0].device.type == "cpu"   # models.py:471-472
+  a = np.load(os.path.join(GOLD, "gill_api_opt125m.npz"))
+  ret = gill125.generate_for_images_and_texts([str(a["text"])], num_words=2, gen_scale_factor=1e5)
+  assert ret[0] == str(a["caption"]) and str(ret[1]["decision"]) == str(a["decision"]) and ret[1]["ret"] == []
+  gen = ret[1]["gen"][0]
+  mse, _, _ = _stats("public API gen_emb", gen, torch.from_numpy(a["gen_emb"]))
+  assert gen.shape == (1, 77, 768) and mse < 1e-4
+
+
+def test_opt_forward_vs_oracle_causal_lengths(cuda, gill125):
+  """Single OPT pass at several sequence lengths (kv tile edges 31/32/33, 64, 100) against the oracle."""
+  from oracle import opt_ref
+  cfg = gill125.model.opt_cfg
+  sd = {k: v.float().cpu() for k, v in gill125.model.lm.state_dict().items()}
+  for T in (5, 31, 32, 33, 64, 100):
+    ids = synth.synthetic_prompt_ids(2, T, seed=T)[:, :T]
+    emb = opt_ref.opt_embed(sd, ids)
+    ref = opt_ref.opt_hidden_states(sd, cfg.num_layers, cfg.num_heads, emb)
+    got = gill125.model._lm_forward_hidden(emb.to(cuda))
+    _, rel, _ = _stats(f"opt forward T={T}", got, ref)
+    assert rel < 3e-2
+
+
+# ------------------------------------------------------------------------------------------------ stage 3
+def _tiny_pipe(cuda, sample_size=16, max_batch=8):
+  from gill_amd.sd import GillSDPipeline
+  cfg = synth.UNetConfig.tiny(sample_size)
+  sd = _bfw(synth.unet_state_dict(cfg, seed=3))
+  uncond = synth.uncond_context(cfg.ctx_len, cfg.cross_attention_dim, seed=3).bfloat16().float()
+  return cfg, sd, uncond, GillSDPipeline(sd, cfg, uncond, cuda, max_batch=max_batch)
+
+
+def test_unet_forward_tiny_vs_oracle(cuda):
+  from oracle import unet_ref
+  cfg, sd, _, pipe = _tiny_pipe(cuda)
+  B = 3
+  x = synth.normal("unet_x", (B, 4, 16, 16), 9)
+  ctx = synth.normal("unet_ctx", (B, 77, cfg.cross_attention_dim), 9).bfloat16().float()
+  t = torch.tensor([981.0, 501.0, 1.0])
+  ref = unet_ref.unet_forward(sd, x, t, ctx, cfg.block_out_channels, cfg.num_heads, cfg.norm_num_groups)
+  got = pipe.unet(x, t, ctx)
+  mse, rel, cos = _stats("unet tiny forward", got, ref)
+  assert got.shape == ref.shape
+  assert rel < 5e-2 and cos > 0.998     # ~60 bf16 layers against an fp32 oracle
+
+
+def test_denoise_tiny_vs_oracle(cuda):
+  """Whole CFG + PLMS loop (10 steps = 11 UNet calls of batch 2B) incl. the repeated warm-up step."""
+  from oracle import pipeline_ref
+  cfg, sd, uncond, pipe = _tiny_pipe(cuda)
+  B = 2
+  cond = synth.normal("dn_cond", (B, 77, cfg.cross_attention_dim), 4).bfloat16().float()
+  lat0 = synth.initial_latents(B, 4, 16, seed=1337)
+  ref = pipeline_ref.denoise(sd, cond, uncond, lat0, 10, 7.5, cfg.block_out_channels, cfg.num_heads, cfg.norm_num_groups)
+  got = pipe(prompt_embeds=cond, latents=lat0, guidance_scale=7.5, num_inference_steps=10).images
+  mse, rel, cos = _stats("denoise tiny 10 steps", got, ref)
+  assert rel < 8e-2 and cos > 0.995     # 11 recurrent bf16 UNet calls; guidance 7.5 amplifies eps differences
+  # no-CFG path (guidance <= 1: custom_sd.py:588)
+  ref1 = pipeline_ref.denoise(sd, cond, None, lat0, 5, 1.0, cfg.block_out_channels, cfg.num_heads, cfg.norm_num_groups)
+  got1 = pipe(prompt_embeds=cond, latents=lat0, guidance_scale=1.0, num_inference_steps=5).images
+  _, rel1, cos1 = _stats("denoise tiny no-CFG 5 steps", got1, ref1)
+  assert rel1 < 5e-2 and cos1 > 0.998
+  # batch invariance: prompts are independent end to end (what multi-GPU sharding relies on)
+  got_b0 = pipe(prompt_embeds=cond[:1], latents=lat0[:1], guidance_scale=7.5, num_inference_steps=10).images
+  _, relb, _ = _stats("batch invariance", got_b0, got[:1])
+  assert relb < 2e-2
+
+
+@pytest.mark.skipif(os.environ.get("GILL_SKIP_SLOW") == "1", reason="slow CPU oracle")
+def test_unet_forward_sd15_vs_oracle(cuda):
+  """Full-size SD-1.5 UNet (860 M parameters, 64x64 latents), one forward of batch 2 against the CPU oracle."""
+  from gill_amd.sd import GillSDPipeline
+  from oracle import unet_ref
+  cfg = synth.UNetConfig.sd15()
+  sd = _bfw(synth.unet_state_dict(cfg, seed=0))
+  uncond = synth.uncond_context(seed=0)
+  pipe = GillSDPipeline(sd, cfg, uncond, cuda, max_batch=2)
+  x = synth.initial_latents(2, 4, 64, seed=1337)
+  ctx = torch.cat([uncond, synth.normal("sd15_ctx", (1, 77, 768), 2)], 0).bfloat16().float()
+  t = torch.tensor([961.0, 961.0])
+  torch.set_num_threads(max(1, os.cpu_count() or 1))
+  ref = unet_ref.unet_forward(sd, x, t, ctx)
+  got = pipe.unet(x, t, ctx)
+  mse, rel, cos = _stats("unet SD-1.5 forward", got, ref)
+  assert rel < 5e-2 and cos > 0.998
+
+
+def test_generate_images_end_to_end_tiny(cuda):
+  """NEW batched entry: token ids -> OPT -> mapper -> UNet loop, against the composed oracle."""
+  from oracle import pipeline_ref
+  cfg, usd, uncond, pipe = _tiny_pipe(cuda)
+  # the tiny UNet takes a 128-wide context: give the mapper a 128-d output via gen_emb_dim... the shipped mapper
+  # hard-codes 768 (layers.py:52), so run stages 1-2 at 768 and check stage 3 separately on its own embedding.
+  g = _gill_opt125m(cuda, load_sd=False)
+  ids = synth.synthetic_prompt_ids(4, 12, seed=8)[:, :12]
+  embs = g.generate_images(ids, distributed=False)
+  osd = {k: v.float().cpu() for k, v in g.model.lm.state_dict().items()}
+  msd = {k: v.float().cpu() for k, v in g.model.gen_text_hidden_fcs[0].state_dict().items()}
+  full = torch.cat([ids, torch.tensor([synth.IMG_TOKEN_IDS] * 4)], 1)
+  ref = pipeline_ref.sd_embedding(osd, msd, 12, 12, full, torch.full((4,), full.shape[1] - 1))
+  mse, _, _ = _stats("generate_images SD embedding (B=4)", embs, ref)
+  assert embs.shape == (4, 77, 768) and mse < 1e-4
