@@ -4,31 +4,62 @@
 //   Q  [B][H][nq_pad ][DP]      K [B][H][nkv_pad][DP]      Vt [B][H][dpv][nkv_pad]
 // Output O is token-major [B*nq][ldo] so the out-projection GEMM consumes it directly.
 //
-// One wave owns 32 query rows; everything is computed transposed so each lane owns ONE query
-// column of the 32x32 tiles:
-//   S^T[kv][q] = sum_d K[kv][d] Q[q][d]          (A = K fragment, B = Q fragment)
-//   O^T[d][q]  = sum_kv Vt[d][kv] P[q][kv]       (A = Vt fragment, B = P in registers)
-// so the running max / sum / rescale are lane-local (one xor-32 shuffle joins the two half
-// waves that share a query).  P never leaves registers: the S^T accumulator registers r=0..7 /
-// 8..15 of a lane are, as they are, the k-slots of the B operand of the two PV MFMAs, provided
-// the Vt fragment is gathered with the same kv permutation
-//   kv(h2, hi, j) = 16*h2 + 8*(j>>2) + 4*hi + (j&3)
-// (two 8-byte loads per fragment from the kv-contiguous Vt rows).
+// Workgroup = 8 waves = 256 queries of one (batch, head); each wave owns 32 query rows.  K/V are walked in tiles
+// of 64 keys that all 8 waves share through LDS (coalesced 16-B global loads -> registers -> padded LDS rows,
+// register-staged double buffer: the next tile's global loads are in flight while the current one is consumed;
+// one barrier per tile).  Row strides are padded (+16 B for K rows, +8 B for Vt rows) so every ds_read lane
+// group hits distinct banks.
 //
-// DP (padded head dim, multiple of 16): 48 (d=40), 64, 80, 128, 160.  Padding columns of Q/K are
-// exact zeros (zero weight rows), padding rows of Vt (up to dpv = roundup(DP,32)) only feed
-// output rows that are never stored.
+// Everything is computed transposed so each lane owns ONE query column of the 32x32 tiles:
+//   S^T[kv][q] = sum_d K[kv][d] Q[q][d]          (A = K fragment, B = Q fragment held in registers)
+//   O^T[d][q]  = sum_kv Vt[d][kv] P[q][kv]       (A = Vt fragment, B = P in registers)
+// so the running max / sum / rescale are lane-local (one xor-32 shuffle joins the two half waves that share a
+// query).  P never leaves registers: the S^T accumulator registers r=0..7 / 8..15 of a lane are, as they are, the
+// k-slots of the B operand of the PV MFMAs, provided the Vt fragment is gathered with the same kv permutation
+//   kv(h, hi, j) = 16*h + 8*(j>>2) + 4*hi + (j&3)          (two 8-byte LDS reads per fragment).
+//
+// DP (padded head dim, multiple of 16): 48 (d=40), 64, 80, 128, 160.  Padding columns of Q/K are exact zeros
+// (zero weight rows); padding rows of Vt (up to dpv = roundup(DP,32)) only feed output rows that are never stored.
 #include "ops.h"
 
+#define ATT_THREADS 512
+#define ATT_QB 256     // queries per workgroup
+#define ATT_KVT 64     // keys per tile
+
 template <int DP>
-__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
-  constexpr int KS = DP / 16;          // QK^T k-steps
-  constexpr int NDT = (DP + 31) / 32;  // 32-row d tiles of O^T
-  const int lane = threadIdx.x & 63;
-  const int w = threadIdx.x >> 6;
+struct AttCfg {
+  static constexpr int KS = DP / 16;              // QK^T k-steps per 32-key half
+  static constexpr int NDT = (DP + 31) / 32;      // 32-row d tiles of O^T
+  static constexpr int DPV = NDT * 32;
+  static constexpr int KSTR = DP + 8;             // K row stride in elements (+16 B)
+  static constexpr int VSTR = ATT_KVT + 4;        // Vt row stride in elements (+8 B)
+  static constexpr int K_CHUNKS = ATT_KVT * DP / 8;       // 16-B chunks of a K tile
+  static constexpr int V_CHUNKS = DPV * ATT_KVT / 8;      // 16-B chunks of a Vt tile
+  static constexpr int K_PER_THR = (K_CHUNKS + ATT_THREADS - 1) / ATT_THREADS;
+  static constexpr int V_PER_THR = (V_CHUNKS + ATT_THREADS - 1) / ATT_THREADS;
+  // every thread loads AND stores K_PER_THR / V_PER_THR chunks unconditionally (branch-free staging keeps the
+  // prefetch registers out of scratch); the LDS regions are over-allocated to absorb the surplus chunks
+  static constexpr int K_ROWS = (K_PER_THR * ATT_THREADS + DP / 8 - 1) / (DP / 8);
+  static constexpr int V_ROWS = K_PER_THR * 0 + V_PER_THR * ATT_THREADS / 8;
+  static constexpr int K_ELEMS = K_ROWS * KSTR;
+  static constexpr int V_ELEMS = V_ROWS * VSTR;
+  static constexpr int BUF_ELEMS = K_ELEMS + V_ELEMS;
+  static constexpr int SMEM_BYTES = 2 * BUF_ELEMS * 2;
+};
+
+template <int DP>
+__global__ __launch_bounds__(ATT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_kernel(const AttnArgs p) {
+  using Cfg = AttCfg<DP>;
+  constexpr int KS = Cfg::KS, NDT = Cfg::NDT, KSTR = Cfg::KSTR, VSTR = Cfg::VSTR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(att_smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + w * 32;
-  if (q0 >= p.nq) return;
+  const int q0 = blockIdx.x * ATT_QB + w * 32;
+  const bool wave_active = q0 < p.nq;
   const int lq = lane & 31;
   const int hi = lane >> 5;
   const int kvb = p.kv_bstride_zero ? 0 : b;
@@ -39,7 +70,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
 
   int qrow = q0 + lq;
   const bool qvalid = qrow < p.nq;
-  if (!qvalid) qrow = p.nq - 1;
+  if (qrow > p.nq - 1) qrow = p.nq - 1;
 
   bf16x8 qf[KS];
 #pragma unroll
@@ -54,76 +85,152 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
   const float sl2 = p.scale * 1.4426950408889634f;  // scores are tracked in the log2 domain
   float m_run = -1e30f, l_run = 0.f;
 
-  // causal: query i attends kv <= i + (nkv - nq)
+  // causal: query i attends kv <= i + (nkv - nq).  The tile loop bound is uniform per workgroup.
   const int coff = p.nkv - p.nq;
-  int kv_end = p.nkv;
+  int kv_end_blk = p.nkv;
   if (p.causal) {
-    int lim = q0 + 31 + coff + 1;
-    if (lim < kv_end) kv_end = lim;
-    if (kv_end < 1) kv_end = 1;
+    int lim = blockIdx.x * ATT_QB + ATT_QB - 1 + coff + 1;
+    if (lim < kv_end_blk) kv_end_blk = lim;
+    if (kv_end_blk < 1) kv_end_blk = 1;
   }
+  const int ntiles = (kv_end_blk + ATT_KVT - 1) / ATT_KVT;
   const int qidx = qrow + coff;
+  const int wave_kv_end = p.causal ? min(p.nkv, q0 + 31 + coff + 1) : p.nkv;   // keys this wave can see at all
 
-  for (int kv0 = 0; kv0 < kv_end; kv0 += 32) {
-    f32x16 s;
+  // ---- tile staging (all 512 threads): global -> registers -> LDS
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in registers (HIP's uint4 struct did not)
+  u32x4 kreg[Cfg::K_PER_THR];
+  u32x4 vreg[Cfg::V_PER_THR];
+  auto gload = [&](int tile) {
+    const int kv0 = tile * ATT_KVT;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-    const bf16_t* krow = Kb + (size_t)(kv0 + lq) * DP + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + ks * 16);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+    for (int i = 0; i < Cfg::K_PER_THR; ++i) {
+      int c = tid + i * ATT_THREADS;
+      if (c > Cfg::K_CHUNKS - 1) c = Cfg::K_CHUNKS - 1;   // surplus threads re-load the last chunk (never stored)
+      // K tile rows are contiguous in global memory: 64 rows * DP elements
+      int row = c / (DP / 8);
+      const int col = c - row * (DP / 8);
+      if (kv0 + row > p.nkv_pad - 1) row = p.nkv_pad - 1 - kv0;   // stay inside the allocation (masked anyway)
+      kreg[i] = *reinterpret_cast<const u32x4*>(Kb + (size_t)(kv0 + row) * DP + col * 8);
     }
-    float mx = -1e30f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      float v = s[r] * sl2;
-      const bool masked = (kv >= p.nkv) || (p.causal && kv > qidx);
-      v = masked ? -1e30f : v;
-      s[r] = v;
-      mx = fmaxf(mx, v);
+    for (int i = 0; i < Cfg::V_PER_THR; ++i) {
+      int c = tid + i * ATT_THREADS;
+      if (c > Cfg::V_CHUNKS - 1) c = Cfg::V_CHUNKS - 1;
+      const int row = c >> 3;
+      int col = (c & 7) * 8;
+      if (kv0 + col > p.nkv_pad - 8) col = p.nkv_pad - 8 - kv0;   // nkv_pad is a multiple of 32, tiles are 64 wide
+      vreg[i] = *reinterpret_cast<const u32x4*>(Vb + (size_t)row * p.nkv_pad + kv0 + col);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float rs = 0.f;
+  };
+  auto lstore = [&](int buf) {
+    bf16_t* Ks = smem + buf * Cfg::BUF_ELEMS;
+    bf16_t* Vs = Ks + Cfg::K_ELEMS;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float e = __builtin_amdgcn_exp2f(s[r] - m_new);
-      s[r] = e;
-      rs += e;
+    for (int i = 0; i < Cfg::K_PER_THR; ++i) {
+      const int c = tid + i * ATT_THREADS;
+      const int row = c / (DP / 8);
+      const int col = c - row * (DP / 8);
+      *reinterpret_cast<u32x4*>(Ks + row * KSTR + col * 8) = kreg[i];
     }
-    rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
 #pragma unroll
-    for (int t = 0; t < NDT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+    for (int i = 0; i < Cfg::V_PER_THR; ++i) {
+      const int c = tid + i * ATT_THREADS;
+      const int row = c >> 3;
+      const int col = (c & 7) * 8;
+      uint2* d = reinterpret_cast<uint2*>(Vs + row * VSTR + col);   // rows are 8-B aligned (VSTR*2 = 136 B)
+      d[0] = make_uint2(vreg[i][0], vreg[i][1]);
+      d[1] = make_uint2(vreg[i][2], vreg[i][3]);
+    }
+  };
 
-    bf16x8 pa[2];
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int kv0 = tile * ATT_KVT;
+    if (tile + 1 < ntiles) gload(tile + 1);
+    const bf16_t* Ks = smem + (tile & 1) * Cfg::BUF_ELEMS;
+    const bf16_t* Vs = Ks + Cfg::K_ELEMS;
+
+    if (wave_active && kv0 < wave_kv_end) {
+      // ---- S^T for the two 32-key halves
+      f32x16 s[2];
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-      union { bf16x8 v; uint32_t u[4]; } pk;
+      for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) pk.u[j] = pack_bf2(s[h2 * 8 + 2 * j], s[h2 * 8 + 2 * j + 1]);
-      pa[h2] = pk.v;
-    }
+        for (int r = 0; r < 16; ++r) s[hh][r] = 0.f;
+        const bf16_t* krow = Ks + (hh * 32 + lq) * KSTR + hi * 8;
 #pragma unroll
-    for (int t = 0; t < NDT; ++t) {
-      const bf16_t* vrow = Vb + (size_t)(t * 32 + lq) * p.nkv_pad + kv0 + 4 * hi;
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + ks * 16);
+          s[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[hh], 0, 0, 0);
+        }
+      }
+      // ---- masking only where the tile is not entirely visible (wave-uniform test)
+      const bool need_mask = (kv0 + ATT_KVT > p.nkv) || (p.causal && (kv0 + ATT_KVT - 1 > q0 + coff));
+      if (need_mask) {
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        union { bf16x8 v; uint2 u[2]; } vf;
-        vf.u[0] = *reinterpret_cast<const uint2*>(vrow + 16 * h2);
-        vf.u[1] = *reinterpret_cast<const uint2*>(vrow + 16 * h2 + 8);
-        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pa[h2], oacc[t], 0, 0, 0);
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv = kv0 + hh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const bool masked = (kv >= p.nkv) || (p.causal && kv > qidx);
+            s[hh][r] = masked ? -INFINITY : s[hh][r];
+          }
+      }
+      float mx = s[0][0];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[hh][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      // masked entries are -inf (exp2 -> exactly 0); the running max lives in the scaled log2 domain and stays finite
+      const float m_new = fmaxf(m_run, mx > -1e29f ? mx * sl2 : -1e30f);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(s[hh][r], sl2, -m_new));
+          s[hh][r] = e;
+          rs += e;
+        }
+      rs += __shfl_xor(rs, 32, 64);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int t = 0; t < NDT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+
+      bf16x8 pa[4];
+#pragma unroll
+      for (int h4 = 0; h4 < 4; ++h4) {
+        union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk.u[j] = pack_bf2(s[h4 >> 1][(h4 & 1) * 8 + 2 * j], s[h4 >> 1][(h4 & 1) * 8 + 2 * j + 1]);
+        pa[h4] = pk.v;
+      }
+#pragma unroll
+      for (int t = 0; t < NDT; ++t) {
+        const bf16_t* vrow = Vs + (t * 32 + lq) * VSTR + 4 * hi;
+#pragma unroll
+        for (int h4 = 0; h4 < 4; ++h4) {
+          union { bf16x8 v; uint2 u[2]; } vf;
+          vf.u[0] = *reinterpret_cast<const uint2*>(vrow + 16 * h4);
+          vf.u[1] = *reinterpret_cast<const uint2*>(vrow + 16 * h4 + 8);
+          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pa[h4], oacc[t], 0, 0, 0);
+        }
       }
     }
+    if (tile + 1 < ntiles) lstore((tile + 1) & 1);
+    __syncthreads();
   }
 
-  if (!qvalid) return;
+  if (!wave_active || !qvalid) return;
   const float inv = 1.f / l_run;
   bf16_t* orow = p.O + (size_t)(b * p.nq + qrow) * p.ldo + h * DP;
 #pragma unroll
@@ -141,24 +248,34 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
   }
 }
 
+template <int DP>
+static int attention_launch_dp(const AttnArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  constexpr int smem = AttCfg<DP>::SMEM_BYTES;
+  if (!attr_set) {
+    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.nq, ATT_QB), a.H, a.B);
+  hipLaunchKernelGGL(attention_kernel<DP>, grid, dim3(ATT_THREADS), smem, s, a);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int attention_launch(const AttnArgs& a, hipStream_t s) {
   GILL_REQUIRE(a.B > 0 && a.H > 0 && a.nq > 0 && a.nkv > 0, "empty attention");
   GILL_REQUIRE(a.nkv_pad % 32 == 0 && a.nkv_pad >= a.nkv, "nkv_pad must be a multiple of 32 covering nkv");
   GILL_REQUIRE(a.nq_pad >= a.nq, "nq_pad must cover nq");
   GILL_REQUIRE(a.dpv >= round_up(a.dp, 32), "dpv must cover roundup(dp, 32)");
   GILL_REQUIRE(a.ldo >= a.H * a.dp, "ldo too small");
-  dim3 grid(cdiv(a.nq, 128), a.H, a.B);
-  dim3 block(256);
   switch (a.dp) {
-    case 48:  hipLaunchKernelGGL(attention_kernel<48>, grid, block, 0, s, a); break;
-    case 64:  hipLaunchKernelGGL(attention_kernel<64>, grid, block, 0, s, a); break;
-    case 80:  hipLaunchKernelGGL(attention_kernel<80>, grid, block, 0, s, a); break;
-    case 128: hipLaunchKernelGGL(attention_kernel<128>, grid, block, 0, s, a); break;
-    case 160: hipLaunchKernelGGL(attention_kernel<160>, grid, block, 0, s, a); break;
+    case 48:  return attention_launch_dp<48>(a, s);
+    case 64:  return attention_launch_dp<64>(a, s);
+    case 80:  return attention_launch_dp<80>(a, s);
+    case 128: return attention_launch_dp<128>(a, s);
+    case 160: return attention_launch_dp<160>(a, s);
     default:
       gill_set_error("attention: unsupported padded head dim (supported: 48, 64, 80, 128, 160)");
       return -2;
   }
-  GILL_CHECK_HIP(hipGetLastError());
-  return 0;
 }

@@ -178,6 +178,37 @@ int conv_in_launch(const float* x, const bf16_t* w, const float* bias, int B, in
   return 0;
 }
 
+__global__ __launch_bounds__(256) void im2col_nchw_kernel(const float* __restrict__ x, int B, int Cin, int H, int W, int kpad,
+                                                          bf16_t* __restrict__ out) {
+  const int64_t total = (int64_t)B * H * W * (kpad / 8);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int oct = (int)(i % (kpad / 8));
+    const int64_t pix = i / (kpad / 8);
+    const int xw = (int)(pix % W);
+    const int yh = (int)((pix / W) % H);
+    const int b = (int)(pix / ((int64_t)W * H));
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = oct * 8 + j;
+      const int tap = k / Cin, c = k - tap * Cin;
+      const int iy = yh + tap / 3 - 1, ix = xw + tap % 3 - 1;
+      const bool ok = (k < 9 * Cin) && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      v[j] = ok ? x[(((size_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
+    }
+    uint4 u;
+    u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(out + pix * kpad + oct * 8) = u;
+  }
+}
+int im2col_nchw_launch(const float* x, int B, int Cin, int H, int W, int kpad, bf16_t* out, hipStream_t s) {
+  GILL_REQUIRE(kpad % 64 == 0 && 9 * Cin <= kpad, "im2col: kpad must be a multiple of 64 covering 9*Cin");
+  const int64_t total = (int64_t)B * H * W * (kpad / 8);
+  hipLaunchKernelGGL(im2col_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, B, Cin, H, W, kpad, out);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // conv_out: one wave per output pixel; lanes stride over (tap, channel-chunk), shuffle-reduce the Cout (<=8) sums.
 __global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                        const float* __restrict__ bias, int B, int Cin, int H, int W,

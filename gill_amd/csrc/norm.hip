@@ -112,42 +112,65 @@ int layernorm_f32out_launch(const void* x, int x_f32, const float* gamma, const 
 // per-group partial (sum, sumsq) are reduced through LDS and added atomically into stats.
 // The mean is shifted by the first pixel's value of the group to tame E[x^2]-E[x]^2
 // cancellation: stats hold sums of (x - ref[b][g]) with ref = bf16 value at pixel 0.
-#define GN_ROWS 64
+#define GN_ROWS 32
 
+typedef __attribute__((ext_vector_type(4))) unsigned int gn_u32x4;
+
+__device__ __forceinline__ float gn_ref_value(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int b, int HW, int ch) {
+  return (ch < C1) ? bf2f(x1[(size_t)b * HW * C1 + ch]) : bf2f(x2[(size_t)b * HW * C2 + (ch - C1)]);
+}
+
+// Pass 1 (stats).  Block = (b, slab of GN_ROWS pixels).  A thread owns one 8-channel octet (16-B loads, a wave
+// covers 1 KiB of a row) and walks the slab's pixels with a stride of (256 / octets-per-row) row lanes; its four
+// channel pairs are reduced into per-group LDS bins, then one global atomic per (group, moment) per block.
+// `stats` must be zero on entry.
 __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __restrict__ x1, int C1,
                                                               const bf16_t* __restrict__ x2, int C2, int HW,
                                                               int groups, float* __restrict__ stats) {
   __shared__ float red[2 * 64];  // up to 64 groups
   const int C = C1 + C2;
   const int cg = C / groups;
+  const int nvec = C / 8;
   const int b = blockIdx.y;
   const int p0 = blockIdx.x * GN_ROWS;
   int p1 = p0 + GN_ROWS;
   if (p1 > HW) p1 = HW;
   for (int i = threadIdx.x; i < 2 * groups; i += blockDim.x) red[i] = 0.f;
   __syncthreads();
-  for (int cp = threadIdx.x; cp < C / 2; cp += blockDim.x) {
-    const int c = cp * 2;
+  for (int obase = 0; obase < nvec; obase += 256) {
+    const int ow = (nvec - obase) < 256 ? (nvec - obase) : 256;
+    const int lanes = 256 / ow;
+    const int rl = threadIdx.x / ow;
+    if (rl >= lanes) continue;
+    const int o = obase + threadIdx.x - rl * ow;
+    const int c = o * 8;
     const bf16_t* src; int cs, cc;
     if (c < C1) { src = x1; cs = C1; cc = c; } else { src = x2; cs = C2; cc = c - C1; }
     const bf16_t* base = src + (size_t)b * HW * cs + cc;
-    // reference value: pixel 0 of the first channel of each channel's group
-    const int g0 = c / cg, g1 = (c + 1) / cg;
-    float ref0, ref1;
-    {
-      const int cr0 = g0 * cg, cr1 = g1 * cg;
-      ref0 = (cr0 < C1) ? bf2f(x1[(size_t)b * HW * C1 + cr0]) : bf2f(x2[(size_t)b * HW * C2 + (cr0 - C1)]);
-      ref1 = (cr1 < C1) ? bf2f(x1[(size_t)b * HW * C1 + cr1]) : bf2f(x2[(size_t)b * HW * C2 + (cr1 - C1)]);
+    int g[4]; float ref[4], sm[4], sq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      g[j] = (c + 2 * j) / cg;
+      ref[j] = gn_ref_value(x1, C1, x2, C2, b, HW, g[j] * cg);
+      sm[j] = 0.f; sq[j] = 0.f;
     }
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-    for (int p = p0; p < p1; ++p) {
-      const uint32_t u = *reinterpret_cast<const uint32_t*>(base + (size_t)p * cs);
-      const float a = bf2f((bf16_t)(u & 0xffff)) - ref0;
-      const float bq = bf2f((bf16_t)(u >> 16)) - ref1;
-      s0 += a; q0 += a * a; s1 += bq; q1 += bq * bq;
+#pragma unroll 4
+    for (int p = p0 + rl; p < p1; p += lanes) {
+      const gn_u32x4 u = *reinterpret_cast<const gn_u32x4*>(base + (size_t)p * cs);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = bf2f((bf16_t)(u[j] & 0xffff)) - ref[j];
+        const float bq = bf2f((bf16_t)(u[j] >> 16)) - ref[j];
+        sm[j] += a + bq;
+        sq[j] += a * a + bq * bq;
+      }
     }
-    atomicAdd(&red[2 * g0], s0); atomicAdd(&red[2 * g0 + 1], q0);
-    atomicAdd(&red[2 * g1], s1); atomicAdd(&red[2 * g1 + 1], q1);
+    // merge pairs that share a group before touching LDS
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < 3 && g[j] == g[j + 1]) { sm[j + 1] += sm[j]; sq[j + 1] += sq[j]; }
+      else { atomicAdd(&red[2 * g[j]], sm[j]); atomicAdd(&red[2 * g[j] + 1], sq[j]); }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * groups; i += blockDim.x) atomicAdd(&stats[(size_t)b * groups * 2 + i], red[i]);
@@ -197,12 +220,12 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
 }
 
 int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups, const float* gamma,
-                     const float* beta, float eps, int silu, bf16_t* y, float* stats, hipStream_t s) {
+                     const float* beta, float eps, int silu, bf16_t* y, float* stats, hipStream_t s, int stats_prezeroed) {
   const int C = C1 + C2;
   GILL_REQUIRE(groups <= 64 && C % groups == 0 && (C / groups) % 2 == 0, "groupnorm: channels/group must be even");
   GILL_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "groupnorm: channel counts must be multiples of 8");
   GILL_REQUIRE(C2 == 0 || x2 != nullptr, "groupnorm: second source missing");
-  GILL_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(float) * 2 * groups * B, s));
+  if (!stats_prezeroed) GILL_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(float) * 2 * groups * B, s));
   dim3 g1(cdiv(HW, GN_ROWS), B);
   hipLaunchKernelGGL(groupnorm_stats_kernel, g1, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, stats);
   GILL_CHECK_HIP(hipGetLastError());

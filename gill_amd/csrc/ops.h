@@ -60,7 +60,7 @@ int layernorm_f32out_launch(const void* x, int x_f32, const float* gamma, const 
 //   stats: [B][groups][2] fp32 scratch (zeroed inside).
 int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups,
                      const float* gamma, const float* beta, float eps, int silu, bf16_t* y,
-                     float* stats, hipStream_t s);
+                     float* stats, hipStream_t s, int stats_prezeroed = 0);
 
 // ---- small elementwise / gather kernels ----
 int embed_tokens_launch(const int64_t* ids, const bf16_t* table, int vocab, const bf16_t* pos_table, int pos_offset,
@@ -76,6 +76,8 @@ int silu_bf16_launch(const bf16_t* x, bf16_t* y, int64_t n, hipStream_t s);
 // conv_in: NCHW fp32 (B,Cin,H,W) -> NHWC bf16 (B,H,W,Cout), 3x3 pad 1, direct (Cin tiny)
 int conv_in_launch(const float* x, const bf16_t* w /*[Cout][9][Cin]*/, const float* bias, int B, int Cin, int H, int W,
                    int Cout, bf16_t* y, hipStream_t s);
+// im2col of a tiny-Cin NCHW fp32 tensor for conv_in: out [B*H*W][kpad] bf16, k = tap*Cin + c (zero beyond 9*Cin)
+int im2col_nchw_launch(const float* x, int B, int Cin, int H, int W, int kpad, bf16_t* out, hipStream_t s);
 // conv_out: NHWC bf16 (B,H,W,Cin) -> NCHW fp32 (B,Cout,H,W), 3x3 pad 1, direct (Cout tiny)
 int conv_out_launch(const bf16_t* x, const bf16_t* w /*[Cout][9][Cin]*/, const float* bias, int B, int Cin, int H, int W,
                     int Cout, float* y, hipStream_t s);

@@ -88,7 +88,8 @@ struct gill_unet {
   // workspace
   Arena arena;
   unsigned char* arena_mem = nullptr;
-  float* gn_stats = nullptr;
+  float* gn_stats = nullptr;      // pool of pre-zeroed [Bx][groups][2] slots, one per GroupNorm call of a forward
+  int gn_slots = 0, gn_slot_floats = 0, gn_next = 0;
   float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
   std::vector<bf16_t*> kcache, vcache;   // per transformer layer: [Bx][H][ctx_pad][dp] / [Bx][H][dpv][ctx_pad]
   int ctx_pad = 0;
@@ -279,9 +280,21 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
   // conv_in / conv_out (direct kernels, [Cout][9][Cin] layout as well)
   {
     const gill_tensor* t;
+    GILL_REQUIRE(cfg->in_channels * 9 <= 64, "conv_in: in_channels * 9 must fit one 64-wide K step");
     if ((rc = wt.get("conv_in.weight", (int64_t)ch[0] * cfg->in_channels * 9, &t))) return fail(rc);
-    if ((rc = m->pool.alloc(&m->conv_in_w, (size_t)ch[0] * cfg->in_channels * 9, false))) return fail(rc);
-    if ((rc = conv_weight_relayout_launch(t->data, t->dtype, ch[0], cfg->in_channels, m->conv_in_w, s))) return fail(rc);
+    {
+      // conv_in runs as im2col (K = 36 zero-padded to 64) + the MFMA GEMM: weights [Cout][tap*Cin + c] padded to [Cout][64]
+      bf16_t* tmp; int32_t* idx;
+      const int kk = cfg->in_channels * 9;
+      if ((rc = m->pool.alloc(&tmp, (size_t)ch[0] * kk, false))) return fail(rc);
+      if ((rc = conv_weight_relayout_launch(t->data, t->dtype, ch[0], cfg->in_channels, tmp, s))) return fail(rc);
+      if ((rc = m->pool.alloc(&m->conv_in_w, (size_t)ch[0] * 64, true))) return fail(rc);
+      std::vector<int32_t> rows(ch[0]);
+      for (int i = 0; i < ch[0]; ++i) rows[i] = i;
+      if ((rc = m->pool.alloc(&idx, (size_t)ch[0], false))) return fail(rc);
+      if (hipMemcpy(idx, rows.data(), sizeof(int32_t) * ch[0], hipMemcpyHostToDevice) != hipSuccess) return fail(-1);
+      if ((rc = scatter_rows_bf16_launch(tmp, ch[0], kk, idx, m->conv_in_w, 64, s))) return fail(rc);
+    }
     if ((rc = load_f32(wt, m->pool, "conv_in.bias", ch[0], &m->conv_in_b, s))) return fail(rc);
     if ((rc = wt.get("conv_out.weight", (int64_t)cfg->out_channels * ch[0] * 9, &t))) return fail(rc);
     if ((rc = m->pool.alloc(&m->conv_out_w, (size_t)cfg->out_channels * ch[0] * 9, false))) return fail(rc);
@@ -375,9 +388,11 @@ struct UNetRun {
     return gemm_launch(g, s);
   }
   int gnorm(const Tensor& x1, const Tensor* x2, const NormW& n, float eps, int silu, const Tensor& y) {
-    if (dry) return 0;
+    if (dry) { ++m->gn_next; return 0; }
+    GILL_REQUIRE(m->gn_next < m->gn_slots, "internal: GroupNorm stats pool exhausted");
+    float* stats = m->gn_stats + (size_t)(m->gn_next++) * m->gn_slot_floats;   // zeroed once per forward
     return groupnorm_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, x1.H * x1.W, m->cfg.norm_num_groups, n.g,
-                            n.b, eps, silu, y.p, m->gn_stats, s);
+                            n.b, eps, silu, y.p, stats, s, 1);
   }
   // 3x3 conv (pad 1) over x1 (++ x2): stride 1|2, optional fused nearest-2x upsample
   int conv(const Tensor& x1, const Tensor* x2, const ConvW& w, int stride, int ups, const float* rowvec, int rv_bstride,
@@ -492,9 +507,18 @@ struct UNetRun {
     const int* ch = c.block_out_channels;
     const int L = c.sample_size;
     m->arena.off = 0;
+    m->gn_next = 0;
+    if (!dry) GILL_CHECK_HIP(hipMemsetAsync(m->gn_stats, 0, sizeof(float) * (size_t)m->gn_slots * m->gn_slot_floats, s));
     std::vector<Tensor> skips;
     Tensor x = talloc(L, L, ch[0]);
-    if (!dry) GILL_TRY(conv_in_launch(sample, m->conv_in_w, m->conv_in_b, Bx, c.in_channels, L, L, ch[0], x.p, s));
+    {
+      // conv_in: im2col (K = 9*Cin padded to 64) + MFMA GEMM
+      const size_t mk = m->arena.mark();
+      bf16_t* col = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * L * L * 64);
+      if (!dry) GILL_TRY(im2col_nchw_launch(sample, Bx, c.in_channels, L, L, 64, col, s));
+      GILL_TRY(linear(col, 64, nullptr, 0, 64, Bx * L * L, m->conv_in_w, m->conv_in_b, ch[0], 64, nullptr, ACT_NONE, x.p, ch[0]));
+      m->arena.release(mk);
+    }
     skips.push_back(x);
     for (int i = 0; i < 4; ++i) {
       for (int j = 0; j < 2; ++j) {
@@ -552,7 +576,9 @@ static int unet_plan_and_alloc(gill_unet* m) {
   const size_t need = m->arena.high + (1 << 20);
   GILL_TRY(m->pool.alloc(&m->arena_mem, need, true));
   m->arena.base = m->arena_mem; m->arena.cap = need; m->arena.dry = false; m->arena.off = 0;
-  GILL_TRY(m->pool.alloc(&m->gn_stats, (size_t)Bx * 64 * 2));
+  m->gn_slots = m->gn_next + 1;             // counted by the dry run
+  m->gn_slot_floats = Bx * 64 * 2;
+  GILL_TRY(m->pool.alloc(&m->gn_stats, (size_t)m->gn_slots * m->gn_slot_floats));
   m->splitk_ws_floats = (size_t)48 << 20;   // 192 MiB of fp32 partials
   GILL_TRY(m->pool.alloc(&m->splitk_ws, m->splitk_ws_floats, false));
   // cross-attention K/V caches

@@ -1,0 +1,41 @@
+"""Summarise a rocprofv3 rocpd SQLite database (kernel trace) into a per-kernel table:
+  python tools/rocpd_summary.py gpurun_out/prof/bench_results.db [out.md]
+"""
+import re
+import sqlite3
+import sys
+
+
+def short(name: str) -> str:
+  name = re.sub(r"\(.*$", "", name)
+  name = name.replace("void ", "")
+  return name[:110]
+
+
+def main():
+  db = sqlite3.connect(sys.argv[1])
+  cur = db.cursor()
+  cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+  # the `kernels` view carries name / start / end per dispatch
+  namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+  rows = cur.execute(f"select {namecol}, start, end from kernels").fetchall()
+  agg = {}
+  t_min, t_max = min(r[1] for r in rows), max(r[2] for r in rows)
+  for n, s, e in rows:
+    a = agg.setdefault(short(n), [0, 0, 10 ** 18, 0])
+    d = e - s
+    a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+  total = sum(a[1] for a in agg.values())
+  lines = [f"# rocprofv3 kernel summary: {sys.argv[1]}", "",
+           f"dispatches {len(rows)}, summed kernel time {total / 1e6:.2f} ms, first-start to last-end span {(t_max - t_min) / 1e6:.2f} ms", "",
+           "| kernel | calls | total ms | % | avg us | min us | max us |", "|---|---|---|---|---|---|---|"]
+  for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    lines.append(f"| `{k}` | {a[0]} | {a[1] / 1e6:.2f} | {100.0 * a[1] / total:.1f} | {a[1] / a[0] / 1e3:.1f} | {a[2] / 1e3:.1f} | {a[3] / 1e3:.1f} |")
+  out = "\n".join(lines) + "\n"
+  if len(sys.argv) > 2:
+    open(sys.argv[2], "w").write(out)
+  print(out)
+
+
+if __name__ == "__main__":
+  main()
