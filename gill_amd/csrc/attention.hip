@@ -48,7 +48,7 @@ struct AttCfg {
 };
 
 template <int DP>
-__global__ __launch_bounds__(ATT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_kernel(const AttnArgs p) {
   using Cfg = AttCfg<DP>;
   constexpr int KS = Cfg::KS, NDT = Cfg::NDT, KSTR = Cfg::KSTR, VSTR = Cfg::VSTR;
   extern __shared__ __attribute__((aligned(16))) unsigned char att_smem_raw[];

@@ -5,15 +5,21 @@
 // Tile: 128 x BN x 64 per 256-thread workgroup (4 waves as 2x2, each wave 64 x BN/2 via
 // v_mfma_f32_16x16x32_bf16).  Both operands are K-contiguous, so both LDS tiles are
 // [rows][64 bf16] = 128 B rows filled by direct-to-LDS DMA (global_load_lds_dwordx4: one
-// wave instruction = 1 KiB = 8 tile rows).  The DMA destination is lane-linear, so the
-// bank-conflict swizzle (16-B slot ^= row&7) is applied on the per-lane SOURCE address and
-// again on the ds_read_b128 address (conflict-free for the 16-lane read groups).
+// wave instruction = 1 KiB = 8 tile rows) into a 2-deep ring: the DMA of K step i+1 flies while
+// step i is multiplied.  The DMA destination is lane-linear, so the bank-conflict swizzle
+// (16-B slot ^= row&7) is applied on the per-lane SOURCE address and again on the ds_read_b128
+// address (conflict-free for the 16-lane read groups).
 // The MFMA is issued "swapped" (W fragment as the A operand) so every lane ends up with 4
 // consecutive N columns of one M row: bias/residual/activation run on float4s and the
 // store is 8 B of bf16 per lane.
 //
 // The conv path computes the im2col row pointers on the fly: NHWC activations make each
-// 64-wide K step a contiguous 128-B run inside one (tap, pixel); padding taps read a zero page.
+// 64-wide K step a contiguous 128-B run inside one (tap, pixel); per K step the tap offset is a
+// wave-uniform scalar added to a per-row centre offset, padding taps read a zero page.
+//
+// Workgroup -> tile mapping is XCD-aware: the dispatcher places workgroup b on XCD b % 8, so ids are
+// remapped (bijectively) to give every XCD a contiguous range of tiles — the N tiles of one M range
+// and the 3x3 halo rows of neighbouring M ranges then hit the same 4 MiB L2.
 #include "ops.h"
 
 #define BM 128
@@ -51,7 +57,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-// Final epilogue for 4 consecutive columns n..n+3 of row m (n % 4 == 0, n + 3 < N).
+// Generic epilogue for 4 consecutive columns n..n+3 of row m (n % 4 == 0, n + 3 < N): used by the split-K reducer.
 __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0, float v1, float v2, float v3) {
   float v[4] = {v0 * p.alpha, v1 * p.alpha, v2 * p.alpha, v3 * p.alpha};
   if (p.bias) {
@@ -101,8 +107,9 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0
   }
 }
 
-// EPI: 0 = row-major / QKV epilogue through store4, 1 = GEGLU, 2 = raw fp32 split-K partials
-template <int BN, bool CONV, int EPI>
+// CONV: 0 plain GEMM, 1 conv3x3, 2 conv3x3 with fused nearest-2x upsample
+// EPI : 0 row-major (bf16 / fp32) epilogue, 1 GEGLU, 2 raw fp32 split-K partials, 3 QKV head-major scatter
+template <int BN, int CONV, int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
   constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -116,7 +123,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = blockIdx.x;
+  // XCD-aware (bijective) remap of the workgroup id
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
   const int tn = tile % d.tiles_n;
   const int tm = tile / d.tiles_n;
   const int m0 = tm * BM;
@@ -131,18 +145,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
   const int srow = lane >> 3;                 // row within the 8-row group == (tile row & 7)
   const int schunk = (lane & 7) ^ srow;       // logical 16-B chunk this lane fetches (source-side swizzle)
 
-  // A rows (4 per lane).  plain: element offsets of the row start in each source.
-  // conv: centre input pixel index + flag bits {1: dy=-1 in range, 2: dy=+1, 4: dx=-1, 8: dx=+1,
-  // 16: oy odd, 32: ox odd} (the parity bits drive the fused nearest-2x upsample).
-  int a_off1[4], a_off2[4];
-  int a_pc[4], a_fl[4];
+  // A rows (4 per lane): element offset of the row start (plain) / of the centre input pixel (conv) in each source,
+  // plus conv flag bits {1: dy=-1 in range, 2: dy=+1, 4: dx=-1, 8: dx=+1, 16: oy odd, 32: ox odd}
+  int a_off1[4], a_off2[4], a_fl[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int row = (i * 4 + w) * 8 + srow;
     int m = m0 + row;
     if (m > p.M - 1) m = p.M - 1;
-    a_off1[i] = a_off2[i] = a_pc[i] = a_fl[i] = 0;
-    if constexpr (!CONV) {
+    a_fl[i] = 0;
+    if constexpr (CONV == 0) {
       a_off1[i] = m * p.lda + schunk * 8;
       a_off2[i] = m * p.lda2 + schunk * 8;
     } else {
@@ -151,19 +163,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
       const int r = m - b * ohw;
       const int oy = r / p.OW;
       const int ox = r - oy * p.OW;
-      int fl = 0;
-      if (p.ups) {
-        a_pc[i] = (b * p.IH + (oy >> 1)) * p.IW + (ox >> 1);
+      int fl = 0, pc;
+      if constexpr (CONV == 2) {
+        pc = (b * p.IH + (oy >> 1)) * p.IW + (ox >> 1);
         fl |= (oy - 1 >= 0) ? 1 : 0; fl |= (oy + 1 < p.OH) ? 2 : 0;
         fl |= (ox - 1 >= 0) ? 4 : 0; fl |= (ox + 1 < p.OW) ? 8 : 0;
         fl |= (oy & 1) << 4; fl |= (ox & 1) << 5;
       } else {
         const int cy = oy * p.stride, cx = ox * p.stride;
-        a_pc[i] = (b * p.IH + cy) * p.IW + cx;
+        pc = (b * p.IH + cy) * p.IW + cx;
         fl |= (cy - 1 >= 0) ? 1 : 0; fl |= (cy + 1 < p.IH) ? 2 : 0;
         fl |= (cx - 1 >= 0) ? 4 : 0; fl |= (cx + 1 < p.IW) ? 8 : 0;
       }
       a_fl[i] = fl;
+      a_off1[i] = pc * p.K1 + schunk * 8;
+      a_off2[i] = pc * (p.Cin - p.K1) + schunk * 8;
     }
   }
   // W rows: BN/32 instructions per wave (BN rows / 8 rows per instr / 4 waves)
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
     const int k0 = kt * BK;
     bf16_t* As = smem + buf * BUF_ELEMS;
     bf16_t* Bs = As + A_ELEMS;
-    if constexpr (!CONV) {
+    if constexpr (CONV == 0) {
       const bool first = (k0 < p.K1);
       const bf16_t* src = first ? p.A : p.A2;
       const int kk = first ? k0 : k0 - p.K1;
@@ -194,6 +208,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
                                          (__attribute__((address_space(3))) void*)l, 16, 0, 0);
       }
     } else {
+      // all wave-uniform: tap, source tensor, channel offset, tap displacement
       const int tap = k0 / p.Cin;
       const int c0 = k0 - tap * p.Cin;
       const int ty = tap / 3;
@@ -202,15 +217,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
       const bool first = (c0 < p.K1);
       const bf16_t* src = first ? p.A : p.A2;
       const int cs = first ? p.K1 : (p.Cin - p.K1);
-      const int cc = (first ? c0 : c0 - p.K1) + schunk * 8;
+      const int cc = first ? c0 : c0 - p.K1;
+      const int delta = (dy * p.IW + dx) * cs + cc;   // used when CONV == 1
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        int ddy = dy, ddx = dx;
-        if (p.ups) { ddy = (dy + ((a_fl[i] >> 4) & 1)) >> 1; ddx = (dx + ((a_fl[i] >> 5) & 1)) >> 1; }
+        int off = (first ? a_off1[i] : a_off2[i]);
+        if constexpr (CONV == 2) {
+          const int ddy = (dy + ((a_fl[i] >> 4) & 1)) >> 1, ddx = (dx + ((a_fl[i] >> 5) & 1)) >> 1;
+          off += (ddy * p.IW + ddx) * cs + cc;
+        } else {
+          off += delta;
+        }
         const bool ok = (a_fl[i] & need) == need;
-        const int pix = a_pc[i] + ddy * p.IW + ddx;
-        const bf16_t* g = src + (size_t)(ok ? pix : 0) * cs + cc;
-        g = ok ? g : zero_lane;
+        const bf16_t* g = ok ? src + off : zero_lane;
         bf16_t* l = As + (i * 4 + w) * 8 * BK;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -286,35 +305,112 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
   } else if constexpr (EPI == 1) {
     // weight rows are interleaved in 16-row blocks: even block = value rows, odd block = gate rows
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = mrow + i * 16;
-      if (m >= p.M) continue;
+    for (int j = 0; j + 1 < NT; j += 2) {
+      const int nv = ncol + j * 16;         // physical column of the value block
+      const int ng = nv + 16;               // physical column of the gate block
+      if (ng >= p.N) continue;
+      const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + nv) : make_float4(0, 0, 0, 0);
+      const float4 bg = p.bias ? *reinterpret_cast<const float4*>(p.bias + ng) : make_float4(0, 0, 0, 0);
+      const int no = (nv >> 5) * 16 + (nv & 15);  // logical output column
 #pragma unroll
-      for (int j = 0; j + 1 < NT; j += 2) {
-        const int nv = ncol + j * 16;         // physical column of the value block
-        const int ng = nv + 16;               // physical column of the gate block
-        if (ng >= p.N) continue;
-        const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + nv) : make_float4(0, 0, 0, 0);
-        const float4 bg = p.bias ? *reinterpret_cast<const float4*>(p.bias + ng) : make_float4(0, 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        const int m = mrow + i * 16;
+        if (m >= p.M) continue;
         const float o0 = (acc[i][j][0] + bv.x) * gelu_erf(acc[i][j + 1][0] + bg.x);
         const float o1 = (acc[i][j][1] + bv.y) * gelu_erf(acc[i][j + 1][1] + bg.y);
         const float o2 = (acc[i][j][2] + bv.z) * gelu_erf(acc[i][j + 1][2] + bg.z);
         const float o3 = (acc[i][j][3] + bv.w) * gelu_erf(acc[i][j + 1][3] + bg.w);
-        const int no = (nv >> 5) * 16 + (nv & 15);  // logical output column
         uint2 o; o.x = pack_bf2(o0, o1); o.y = pack_bf2(o2, o3);
         *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + no) = o;
       }
     }
-  } else {
+  } else if constexpr (EPI == 3) {
+    // head-major scatter; all divisions hoisted: per-row (b, t) once, per-column (segment, head, dd) once
+    int rq[4], rk[4], rv[4]; bool mok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = mrow + i * 16;
-      if (m >= p.M) continue;
+      mok[i] = m < p.M;
+      const int b = m / p.ntok, t = m - b * p.ntok;
+      rq[i] = (b * p.heads * p.ntok_pad_q + t) * p.dp;
+      rk[i] = (b * p.heads * p.ntok_pad_kv + t) * p.dp;
+      rv[i] = b * p.heads * p.dpv * p.ntok_pad_kv + t;
+    }
+    const int hd = p.heads * p.dp;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = ncol + j * 16;
-        if (n >= p.N) continue;
-        store4(p, m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    for (int j = 0; j < NT; ++j) {
+      const int n = ncol + j * 16;
+      if (n >= p.N) continue;
+      const int segl = n / hd;
+      const int within = n - segl * hd;
+      const int h = within / p.dp, dd = within - h * p.dp;
+      const int seg = p.seg_base + segl;
+      const float4 bz = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (!mok[i]) continue;
+        const float v0 = acc[i][j][0] * p.alpha + bz.x, v1 = acc[i][j][1] * p.alpha + bz.y;
+        const float v2 = acc[i][j][2] * p.alpha + bz.z, v3 = acc[i][j][3] * p.alpha + bz.w;
+        if (seg == 0) {
+          uint2 o; o.x = pack_bf2(v0, v1); o.y = pack_bf2(v2, v3);
+          *reinterpret_cast<uint2*>(p.Cq + (size_t)rq[i] + (size_t)h * p.ntok_pad_q * p.dp + dd) = o;
+        } else if (seg == 1) {
+          uint2 o; o.x = pack_bf2(v0, v1); o.y = pack_bf2(v2, v3);
+          *reinterpret_cast<uint2*>(p.Ck + (size_t)rk[i] + (size_t)h * p.ntok_pad_kv * p.dp + dd) = o;
+        } else {
+          bf16_t* base = p.Cvt + (size_t)rv[i] + (size_t)(h * p.dpv + dd) * p.ntok_pad_kv;
+          base[0] = f2bf(v0);
+          base[(size_t)p.ntok_pad_kv] = f2bf(v1);
+          base[(size_t)2 * p.ntok_pad_kv] = f2bf(v2);
+          base[(size_t)3 * p.ntok_pad_kv] = f2bf(v3);
+        }
+      }
+    }
+  } else {
+    // row-major epilogue; per-row offsets (incl. the batch index of the row vector) hoisted out of the column loop
+    size_t crow[4], rrow[4]; int vrow[4]; bool mok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mrow + i * 16;
+      mok[i] = m < p.M;
+      crow[i] = (size_t)m * p.ldc;
+      rrow[i] = (size_t)m * p.ldr;
+      vrow[i] = p.rowvec ? (m / p.rows_per_batch) * p.rowvec_bstride : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = ncol + j * 16;
+      if (n >= p.N) continue;
+      const float4 bz = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (!mok[i]) continue;
+        float v[4] = {acc[i][j][0] * p.alpha + bz.x, acc[i][j][1] * p.alpha + bz.y, acc[i][j][2] * p.alpha + bz.z,
+                      acc[i][j][3] * p.alpha + bz.w};
+        if (p.rowvec) {
+          const float4 b = *reinterpret_cast<const float4*>(p.rowvec + vrow[i] + n);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (p.resid) {
+          if (p.resid_f32) {
+            const float4 r = *reinterpret_cast<const float4*>((const float*)p.resid + rrow[i] + n);
+            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+          } else {
+            const uint2 r = *reinterpret_cast<const uint2*>((const bf16_t*)p.resid + rrow[i] + n);
+            v[0] += bf2f((bf16_t)(r.x & 0xffff)); v[1] += bf2f((bf16_t)(r.x >> 16));
+            v[2] += bf2f((bf16_t)(r.y & 0xffff)); v[3] += bf2f((bf16_t)(r.y >> 16));
+          }
+        }
+        if (p.act != ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+        }
+        if (p.out_mode == OUT_F32) {
+          *reinterpret_cast<float4*>((float*)p.C + crow[i] + n) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+          *reinterpret_cast<uint2*>((bf16_t*)p.C + crow[i] + n) = o;
+        }
       }
     }
   }
@@ -348,7 +444,7 @@ int gemm_pick_splitk(int M, int N, int K, int act) {
   return s;
 }
 
-template <int BN, bool CONV, int EPI>
+template <int BN, int CONV, int EPI>
 static int gemm_launch_inst(const GemmDev& d, dim3 grid, hipStream_t s) {
   static bool attr_set = false;
   constexpr int smem = 2 * (BM * BK + BN * BK) * (int)sizeof(bf16_t);
@@ -376,12 +472,18 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   const int tiles_m = cdiv(a.M, BM);
   dim3 grid(tiles_m * d.tiles_n, sk, 1);
   if (a.conv) {
-    if (sk > 1) GILL_TRY((gemm_launch_inst<BN, true, 2>(d, grid, s)));
-    else GILL_TRY((gemm_launch_inst<BN, true, 0>(d, grid, s)));
+    if (a.ups) {
+      if (sk > 1) GILL_TRY((gemm_launch_inst<BN, 2, 2>(d, grid, s)));
+      else GILL_TRY((gemm_launch_inst<BN, 2, 0>(d, grid, s)));
+    } else {
+      if (sk > 1) GILL_TRY((gemm_launch_inst<BN, 1, 2>(d, grid, s)));
+      else GILL_TRY((gemm_launch_inst<BN, 1, 0>(d, grid, s)));
+    }
   } else {
-    if (sk > 1) GILL_TRY((gemm_launch_inst<BN, false, 2>(d, grid, s)));
-    else if (a.act == ACT_GEGLU) GILL_TRY((gemm_launch_inst<BN, false, 1>(d, grid, s)));
-    else GILL_TRY((gemm_launch_inst<BN, false, 0>(d, grid, s)));
+    if (sk > 1) GILL_TRY((gemm_launch_inst<BN, 0, 2>(d, grid, s)));
+    else if (a.act == ACT_GEGLU) GILL_TRY((gemm_launch_inst<BN, 0, 1>(d, grid, s)));
+    else if (a.out_mode == OUT_QKV) GILL_TRY((gemm_launch_inst<BN, 0, 3>(d, grid, s)));
+    else GILL_TRY((gemm_launch_inst<BN, 0, 0>(d, grid, s)));
   }
   if (sk > 1) {
     const int64_t n4 = (int64_t)a.M * (a.N / 4);
@@ -402,6 +504,8 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
     GILL_REQUIRE(a.K1 % BK == 0 && a.K1 <= a.Cin, "conv: source split must be a multiple of 64");
     GILL_REQUIRE(a.K1 == a.Cin || a.A2 != nullptr, "conv: second source missing");
     GILL_REQUIRE(!(a.ups && a.stride != 1), "conv: upsample needs stride 1");
+    GILL_REQUIRE(a.out_mode != OUT_QKV && a.act != ACT_GEGLU, "conv: row-major epilogue only");
+    GILL_REQUIRE((int64_t)(a.M / (a.OH * a.OW)) * a.IH * a.IW * a.Cin < (int64_t)1 << 31, "conv input too large for 32-bit offsets");
   } else {
     GILL_REQUIRE(a.K1 % BK == 0 && a.K1 <= a.K, "K split must be a multiple of 64");
     GILL_REQUIRE(a.K1 == a.K || a.A2 != nullptr, "second A source missing");
