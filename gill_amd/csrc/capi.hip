@@ -4,6 +4,7 @@
 #include "../../include/gill_amd.h"
 #include "ops.h"
 #include "engine_util.h"
+#include <stdlib.h>
 #include <vector>
 
 static thread_local std::string g_last_error;
@@ -11,6 +12,13 @@ void gill_set_error(const std::string& msg) { g_last_error = msg; }
 
 extern "C" const char* gill_last_error(void) { return g_last_error.c_str(); }
 extern "C" int gill_version(void) { return 100; }
+
+// GILL_OP_REPEAT=n makes the operator entry points launch their kernel n times per call (tools/bench_ops.py: amortises
+// the wrapper's allocation / re-layout so the kernel itself can be timed); default 1.
+static int op_repeat() {
+  static const int r = [] { const char* v = getenv("GILL_OP_REPEAT"); int n = v ? atoi(v) : 1; return n < 1 ? 1 : n; }();
+  return r;
+}
 
 extern "C" int gill_op_gemm(const void* A, const void* W, const float* bias, const void* resid_bf16, void* C, int M, int N,
                             int K, float alpha, int act, int out_f32, int splitk, void* stream) {
@@ -30,7 +38,7 @@ extern "C" int gill_op_gemm(const void* A, const void* W, const float* bias, con
     GILL_TRY(ws.alloc(sizeof(float) * (size_t)g.splitk * M * N));
     g.ws = (float*)ws.p;
   }
-  GILL_TRY(gemm_launch(g, s));
+  for (int r = 0; r < op_repeat(); ++r) GILL_TRY(gemm_launch(g, s));
   if (g.splitk > 1) GILL_CHECK_HIP(hipStreamSynchronize(s));  // ws is freed on return
   return 0;
 }
@@ -84,7 +92,7 @@ extern "C" int gill_op_conv3x3(const void* x1, int C1, const void* x2, int C2, c
     GILL_TRY(ws.alloc(sizeof(float) * (size_t)g.splitk * g.M * g.N));
     g.ws = (float*)ws.p;
   }
-  GILL_TRY(gemm_launch(g, s));
+  for (int r = 0; r < op_repeat(); ++r) GILL_TRY(gemm_launch(g, s));
   GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
 }
@@ -108,7 +116,7 @@ extern "C" int gill_op_attention(const void* q, const void* k, const void* v, vo
   a.Q = (const bf16_t*)Q.p; a.K = (const bf16_t*)K.p; a.Vt = (const bf16_t*)Vt.p; a.O = (bf16_t*)O.p;
   a.B = B; a.H = H; a.nq = nq; a.nkv = nkv; a.nq_pad = nq_pad; a.nkv_pad = nkv_pad; a.dp = dp; a.dpv = dpv;
   a.ldo = H * dp; a.scale = scale; a.causal = causal;
-  GILL_TRY(attention_launch(a, s));
+  for (int r = 0; r < op_repeat(); ++r) GILL_TRY(attention_launch(a, s));
   GILL_TRY(unpad_heads_launch((const bf16_t*)O.p, (int64_t)B * nq, H, d, dp, (bf16_t*)o, s));
   GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;

@@ -21,6 +21,7 @@
 // remapped (bijectively) to give every XCD a contiguous range of tiles — the N tiles of one M range
 // and the 3x3 halo rows of neighbouring M ranges then hit the same 4 MiB L2.
 #include "ops.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BK 64
@@ -109,7 +110,10 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0
 
 // CONV: 0 plain GEMM, 1 conv3x3, 2 conv3x3 with fused nearest-2x upsample
 // EPI : 0 row-major (bf16 / fp32) epilogue, 1 GEGLU, 2 raw fp32 split-K partials, 3 QKV head-major scatter
-template <int BN, int CONV, int EPI>
+// STAGES: depth of the LDS ring.  2: two workgroups per CU hide each other's DMA waits.  3: one workgroup per CU,
+//         the DMA of K steps i+1 AND i+2 is in flight while step i is multiplied (counted s_waitcnt vmcnt(N), raw
+//         s_barrier) — for grids of ~one workgroup per CU where co-residency cannot do the hiding.
+template <int BN, int CONV, int EPI, int STAGES>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
   constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -254,13 +258,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
   const int frow = lane & 15;       // fragment row within a 16-row sub-tile
   const int fkc = lane >> 4;        // 16-B k chunk within the 32-wide MFMA k step
 
-  if (nsteps > 0) issue(kt_beg, 0);
+  constexpr int LOADS = 4 + WI;     // LDS-DMA instructions one wave issues per K step
+  static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nsteps) issue(kt_beg + s, s);
+  int buf = 0, buf_issue = STAGES - 1;
   for (int it = 0; it < nsteps; ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // wait for stage `it` only: with a 3-deep ring stage it+1 (the youngest LOADS instructions) stays in flight
+    if (STAGES == 3 && it + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (it + 1 < nsteps) issue(kt_beg + it + 1, (it + 1) & 1);
-    const bf16_t* As = smem + (it & 1) * BUF_ELEMS;
+    if (it + STAGES - 1 < nsteps) issue(kt_beg + it + STAGES - 1, buf_issue);
+    const bf16_t* As = smem + buf * BUF_ELEMS;
     const bf16_t* Bs = As + A_ELEMS;
+    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+    buf_issue = (buf_issue + 1 == STAGES) ? 0 : buf_issue + 1;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[4];
@@ -444,18 +457,30 @@ int gemm_pick_splitk(int M, int N, int K, int act) {
   return s;
 }
 
-template <int BN, int CONV, int EPI>
+template <int BN, int CONV, int EPI, int STAGES>
 static int gemm_launch_inst(const GemmDev& d, dim3 grid, hipStream_t s) {
   static bool attr_set = false;
-  constexpr int smem = 2 * (BM * BK + BN * BK) * (int)sizeof(bf16_t);
+  constexpr int smem = STAGES * (BM * BK + BN * BK) * (int)sizeof(bf16_t);
   if (!attr_set) {
-    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<BN, CONV, EPI>,
+    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<BN, CONV, EPI, STAGES>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<BN, CONV, EPI>), grid, dim3(GEMM_THREADS), smem, s, d);
+  hipLaunchKernelGGL((gemm_kernel<BN, CONV, EPI, STAGES>), grid, dim3(GEMM_THREADS), smem, s, d);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+template <int BN, int CONV, int EPI>
+static int gemm_launch_stages(const GemmDev& d, dim3 grid, int stages, hipStream_t s) {
+  if (stages == 3) return gemm_launch_inst<BN, CONV, EPI, 3>(d, grid, s);
+  return gemm_launch_inst<BN, CONV, EPI, 2>(d, grid, s);
+}
+
+// tuning knobs (tests / tools): GILL_GEMM_STAGES = 2|3 forces the ring depth, GILL_GEMM_BN = 128|160 the tile width
+static int env_int(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
 }
 
 template <int BN>
@@ -471,19 +496,23 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   d.tiles_n = cdiv(a.N, BN);
   const int tiles_m = cdiv(a.M, BM);
   dim3 grid(tiles_m * d.tiles_n, sk, 1);
+  static const int forced = env_int("GILL_GEMM_STAGES");
+  int stages = a.stages;
+  if (forced == 2 || forced == 3) stages = forced;
+  if (stages != 3) stages = 2;
   if (a.conv) {
     if (a.ups) {
-      if (sk > 1) GILL_TRY((gemm_launch_inst<BN, 2, 2>(d, grid, s)));
-      else GILL_TRY((gemm_launch_inst<BN, 2, 0>(d, grid, s)));
+      if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 2, 2>(d, grid, stages, s)));
+      else GILL_TRY((gemm_launch_stages<BN, 2, 0>(d, grid, stages, s)));
     } else {
-      if (sk > 1) GILL_TRY((gemm_launch_inst<BN, 1, 2>(d, grid, s)));
-      else GILL_TRY((gemm_launch_inst<BN, 1, 0>(d, grid, s)));
+      if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 1, 2>(d, grid, stages, s)));
+      else GILL_TRY((gemm_launch_stages<BN, 1, 0>(d, grid, stages, s)));
     }
   } else {
-    if (sk > 1) GILL_TRY((gemm_launch_inst<BN, 0, 2>(d, grid, s)));
-    else if (a.act == ACT_GEGLU) GILL_TRY((gemm_launch_inst<BN, 0, 1>(d, grid, s)));
-    else if (a.out_mode == OUT_QKV) GILL_TRY((gemm_launch_inst<BN, 0, 3>(d, grid, s)));
-    else GILL_TRY((gemm_launch_inst<BN, 0, 0>(d, grid, s)));
+    if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 0, 2>(d, grid, stages, s)));
+    else if (a.act == ACT_GEGLU) GILL_TRY((gemm_launch_stages<BN, 0, 1>(d, grid, stages, s)));
+    else if (a.out_mode == OUT_QKV) GILL_TRY((gemm_launch_stages<BN, 0, 3>(d, grid, stages, s)));
+    else GILL_TRY((gemm_launch_stages<BN, 0, 0>(d, grid, stages, s)));
   }
   if (sk > 1) {
     const int64_t n4 = (int64_t)a.M * (a.N / 4);
@@ -519,6 +548,10 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
     return gemm_launch_bn<128>(a, s);
   }
   if (a.out_mode == OUT_QKV) GILL_REQUIRE(a.dp % 4 == 0 && a.heads > 0 && a.ntok > 0, "bad QKV scatter geometry");
-  if (a.N % 160 == 0 && a.N % 128 != 0) return gemm_launch_bn<160>(a, s);
+  static const int forced_bn = env_int("GILL_GEMM_BN");
+  int bn = a.bn;
+  if (forced_bn == 128 || forced_bn == 160) bn = forced_bn;
+  if (bn != 128 && bn != 160) bn = (a.N % 160 == 0 && a.N % 128 != 0) ? 160 : 128;
+  if (bn == 160) return gemm_launch_bn<160>(a, s);
   return gemm_launch_bn<128>(a, s);
 }

@@ -32,6 +32,8 @@ struct GemmArgs {
   int heads = 0, dp = 0, dpv = 0, ntok = 0, ntok_pad_q = 0, ntok_pad_kv = 0, seg_base = 0;
   // split-K (0/1 = off).  ws must hold splitk*M*N floats.
   int splitk = 1; float* ws = nullptr;
+  // tuning: LDS ring depth (2|3, 0 = default 2) and tile width (128|160, 0 = by divisibility)
+  int stages = 0; int bn = 0;
 };
 int gemm_launch(const GemmArgs& a, hipStream_t s);
 // heuristic split-K factor for under-filled grids
