@@ -446,12 +446,16 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs 
 
 int gemm_pick_splitk(int M, int N, int K, int act) {
   if (act == ACT_GEGLU) return 1;
-  const int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
+  const int bn = (N % 160 == 0) ? 160 : 128;
   const int tiles = cdiv(M, BM) * cdiv(N, bn);
   const int ksteps = K / BK;
-  if (tiles >= 192 || ksteps < 8) return 1;
-  int s = 512 / tiles;              // aim for ~2 blocks per CU
-  if (s > ksteps / 4) s = ksteps / 4;
+  if (tiles >= 384 || ksteps < 8) return 1;
+  int s = (512 + tiles / 2) / tiles;   // aim for ~2 workgroups per CU (512 resident slots)
+  // each split pays an fp32 partial write + a reduce pass: keep >= 24 K steps per split (measured: K = 1280 GEMMs lose
+  // from any split, K >= 5120 convs win up to 4-8 ways), except for skinny weight-streaming GEMMs (OPT, M <= 256)
+  // where filling every CU with HBM requests matters more than the tiny partials
+  const int min_steps = (M <= 256) ? 4 : 24;
+  if (s > ksteps / min_steps) s = ksteps / min_steps;
   if (s > 16) s = 16;
   if (s < 1) s = 1;
   return s;
@@ -551,7 +555,9 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   static const int forced_bn = env_int("GILL_GEMM_BN");
   int bn = a.bn;
   if (forced_bn == 128 || forced_bn == 160) bn = forced_bn;
-  if (bn != 128 && bn != 160) bn = (a.N % 160 == 0 && a.N % 128 != 0) ? 160 : 128;
+  // measured on MI355X (profiles/r01_sweep_gemm_tiles.md): the 128x160 tile (5 N sub-tiles per wave: more MFMAs per LDS
+  // byte) beats 128x128 by 15-40 % on every UNet width, all of which are multiples of 160
+  if (bn != 128 && bn != 160) bn = (a.N % 160 == 0) ? 160 : 128;
   if (bn == 160) return gemm_launch_bn<160>(a, s);
   return gemm_launch_bn<128>(a, s);
 }
