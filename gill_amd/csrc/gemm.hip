@@ -454,7 +454,7 @@ int gemm_pick_splitk(int M, int N, int K, int act) {
   // each split pays an fp32 partial write + a reduce pass: keep >= 24 K steps per split (measured: K = 1280 GEMMs lose
   // from any split, K >= 5120 convs win up to 4-8 ways), except for skinny weight-streaming GEMMs (OPT, M <= 256)
   // where filling every CU with HBM requests matters more than the tiny partials
-  const int min_steps = (M <= 256) ? 4 : 24;
+  const int min_steps = (M <= 256 || tiles < 64) ? 4 : 24;
   if (s > ksteps / min_steps) s = ksteps / min_steps;
   if (s > 16) s = 16;
   if (s < 1) s = 1;

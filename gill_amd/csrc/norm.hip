@@ -81,12 +81,70 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ 
   }
 }
 
+// bf16 -> bf16 rows of C <= MAXV*512: the row is read from HBM once and stays in registers (one wave per row,
+// lane l owns octets l, l+64, ...); exact two-pass mean / variance on the registers.
+typedef __attribute__((ext_vector_type(4))) unsigned int ln_u32x4;
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_reg_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                            int rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = C >> 3;
+  const bf16_t* xr = x + (size_t)row * C;
+  float v[MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int o = lane + k * 64;
+    if (o < nv) {
+      const ln_u32x4 u = *reinterpret_cast<const ln_u32x4*>(xr + o * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[k][2 * i] = bf2f((bf16_t)(u[i] & 0xffff)); v[k][2 * i + 1] = bf2f((bf16_t)(u[i] >> 16)); }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[k][i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[k][i] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k)
+    if (lane + k * 64 < nv) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float dlt = v[k][i] - mean; ss += dlt * dlt; }
+    }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+  bf16_t* yr = y + (size_t)row * C;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int o = lane + k * 64;
+    if (o < nv) {
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + o * 8), g1 = *reinterpret_cast<const float4*>(gamma + o * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(beta + o * 8), b1 = *reinterpret_cast<const float4*>(beta + o * 8 + 4);
+      ln_u32x4 w;
+      w[0] = pack_bf2((v[k][0] - mean) * rstd * g0.x + b0.x, (v[k][1] - mean) * rstd * g0.y + b0.y);
+      w[1] = pack_bf2((v[k][2] - mean) * rstd * g0.z + b0.z, (v[k][3] - mean) * rstd * g0.w + b0.w);
+      w[2] = pack_bf2((v[k][4] - mean) * rstd * g1.x + b1.x, (v[k][5] - mean) * rstd * g1.y + b1.y);
+      w[3] = pack_bf2((v[k][6] - mean) * rstd * g1.z + b1.z, (v[k][7] - mean) * rstd * g1.w + b1.w);
+      *reinterpret_cast<ln_u32x4*>(yr + o * 8) = w;
+    }
+  }
+}
+
 int layernorm_launch(const void* x, int x_f32, const float* gamma, const float* beta, bf16_t* y, int rows, int C,
                      float eps, hipStream_t s) {
   GILL_REQUIRE(C % 8 == 0 && rows > 0, "layernorm: C must be a multiple of 8");
   dim3 grid(cdiv(rows, 4)), block(256);
   if (x_f32)
     hipLaunchKernelGGL((layernorm_kernel<float, bf16_t>), grid, block, 0, s, (const float*)x, gamma, beta, y, rows, C, eps);
+  else if (C <= 512)
+    hipLaunchKernelGGL((layernorm_reg_kernel<1>), grid, block, 0, s, (const bf16_t*)x, gamma, beta, y, rows, C, eps);
+  else if (C <= 1536)
+    hipLaunchKernelGGL((layernorm_reg_kernel<3>), grid, block, 0, s, (const bf16_t*)x, gamma, beta, y, rows, C, eps);
   else
     hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, gamma, beta, y, rows, C, eps);
   GILL_CHECK_HIP(hipGetLastError());
@@ -113,6 +171,7 @@ int layernorm_f32out_launch(const void* x, int x_f32, const float* gamma, const 
 // The mean is shifted by the first pixel's value of the group to tame E[x^2]-E[x]^2
 // cancellation: stats hold sums of (x - ref[b][g]) with ref = bf16 value at pixel 0.
 #define GN_ROWS 32
+#define GN_APPLY_ROWS 32
 
 typedef __attribute__((ext_vector_type(4))) unsigned int gn_u32x4;
 
@@ -184,38 +243,55 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
                                                               const float* __restrict__ beta, float eps, int silu,
                                                               const float* __restrict__ stats, bf16_t* __restrict__ y,
                                                               int64_t total_vec) {
+  // block = (b, slab of GN_APPLY_ROWS pixels).  Phase 1: fold statistics and affine into per-channel (scale, shift) in
+  // LDS once per block; phase 2: y = [silu](x * scale + shift), 16-B loads and stores.
+  extern __shared__ __attribute__((aligned(16))) float gn_ss[];   // [C] scale | [C] shift
+  (void)total_vec;
   const int C = C1 + C2;
   const int cg = C / groups;
   const int vec_per_row = C / 8;
+  const int b = blockIdx.y;
   const float inv_n = 1.f / ((float)cg * (float)HW);
-  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total_vec; v += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = v / vec_per_row;             // b*HW + p
-    const int c = (int)(v - row * vec_per_row) * 8;
-    const int b = (int)(row / HW);
+  float* scale = gn_ss;
+  float* shift = gn_ss + C;
+  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+    const int g = ch / cg;
+    const int cr = g * cg;
+    const float ref = (cr < C1) ? bf2f(x1[(size_t)b * HW * C1 + cr]) : bf2f(x2[(size_t)b * HW * C2 + (cr - C1)]);
+    const float sm = stats[((size_t)b * groups + g) * 2] * inv_n;         // mean of (x - ref)
+    const float sq = stats[((size_t)b * groups + g) * 2 + 1] * inv_n;     // mean of (x - ref)^2
+    const float var = fmaxf(sq - sm * sm, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    const float sc = rstd * gamma[ch];
+    scale[ch] = sc;
+    shift[ch] = beta[ch] - (sm + ref) * sc;
+  }
+  __syncthreads();
+  const int p0 = blockIdx.x * GN_APPLY_ROWS;
+  int p1 = p0 + GN_APPLY_ROWS;
+  if (p1 > HW) p1 = HW;
+  const int nwork = (p1 - p0) * vec_per_row;
+  for (int i = threadIdx.x; i < nwork; i += blockDim.x) {
+    const int pr = i / vec_per_row;
+    const int c = (i - pr * vec_per_row) * 8;
+    const int64_t row = (int64_t)b * HW + p0 + pr;
     const bf16_t* src;
     if (c < C1) src = x1 + row * C1 + c; else src = x2 + row * C2 + (c - C1);
-    const uint4 u = *reinterpret_cast<const uint4*>(src);
-    const uint32_t uu[4] = {u.x, u.y, u.z, u.w};
+    const gn_u32x4 u = *reinterpret_cast<const gn_u32x4*>(src);
+    const float4 s0 = *reinterpret_cast<const float4*>(scale + c), s1 = *reinterpret_cast<const float4*>(scale + c + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(shift + c), h1 = *reinterpret_cast<const float4*>(shift + c + 4);
     float o[8];
+    o[0] = fmaf(bf2f((bf16_t)(u[0] & 0xffff)), s0.x, h0.x); o[1] = fmaf(bf2f((bf16_t)(u[0] >> 16)), s0.y, h0.y);
+    o[2] = fmaf(bf2f((bf16_t)(u[1] & 0xffff)), s0.z, h0.z); o[3] = fmaf(bf2f((bf16_t)(u[1] >> 16)), s0.w, h0.w);
+    o[4] = fmaf(bf2f((bf16_t)(u[2] & 0xffff)), s1.x, h1.x); o[5] = fmaf(bf2f((bf16_t)(u[2] >> 16)), s1.y, h1.y);
+    o[6] = fmaf(bf2f((bf16_t)(u[3] & 0xffff)), s1.z, h1.z); o[7] = fmaf(bf2f((bf16_t)(u[3] >> 16)), s1.w, h1.w);
+    if (silu) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = c + 2 * i;
-      const int g = ch / cg;
-      const int cr = g * cg;
-      const float ref = (cr < C1) ? bf2f(x1[(size_t)b * HW * C1 + cr]) : bf2f(x2[(size_t)b * HW * C2 + (cr - C1)]);
-      const float sm = stats[((size_t)b * groups + g) * 2] * inv_n;         // mean of (x - ref)
-      const float sq = stats[((size_t)b * groups + g) * 2 + 1] * inv_n;     // mean of (x - ref)^2
-      const float var = fmaxf(sq - sm * sm, 0.f);
-      const float rstd = rsqrtf(var + eps);
-      const float mean = sm + ref;
-      float a = (bf2f((bf16_t)(uu[i] & 0xffff)) - mean) * rstd * gamma[ch] + beta[ch];
-      float bq = (bf2f((bf16_t)(uu[i] >> 16)) - mean) * rstd * gamma[ch + 1] + beta[ch + 1];
-      if (silu) { a = silu_f(a); bq = silu_f(bq); }
-      o[2 * i] = a; o[2 * i + 1] = bq;
+      for (int e = 0; e < 8; ++e) o[e] = silu_f(o[e]);
     }
-    uint4 w;
-    w.x = pack_bf2(o[0], o[1]); w.y = pack_bf2(o[2], o[3]); w.z = pack_bf2(o[4], o[5]); w.w = pack_bf2(o[6], o[7]);
-    *reinterpret_cast<uint4*>(y + row * C + c) = w;
+    gn_u32x4 w;
+    w[0] = pack_bf2(o[0], o[1]); w[1] = pack_bf2(o[2], o[3]); w[2] = pack_bf2(o[4], o[5]); w[3] = pack_bf2(o[6], o[7]);
+    *reinterpret_cast<gn_u32x4*>(y + row * C + c) = w;
   }
 }
 
@@ -230,10 +306,9 @@ int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, 
   hipLaunchKernelGGL(groupnorm_stats_kernel, g1, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, stats);
   GILL_CHECK_HIP(hipGetLastError());
   const int64_t total_vec = (int64_t)B * HW * (C / 8);
-  int blocks = (int)((total_vec + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(blocks), dim3(256), 0, s, x1, C1, x2, C2, HW, groups, gamma, beta, eps,
-                     silu, stats, y, total_vec);
+  dim3 g2(cdiv(HW, GN_APPLY_ROWS), B);
+  hipLaunchKernelGGL(groupnorm_apply_kernel, g2, dim3(256), sizeof(float) * 2 * C, s, x1, C1, x2, C2, HW, groups, gamma, beta,
+                     eps, silu, stats, y, total_vec);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }
