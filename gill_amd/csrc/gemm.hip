@@ -59,7 +59,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // Generic epilogue for 4 consecutive columns n..n+3 of row m (n % 4 == 0, n + 3 < N): used by the split-K reducer.
-__device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0, float v1, float v2, float v3) {
+__device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0, float v1, float v2, float v3,
+                                       float* fin = nullptr) {
   float v[4] = {v0 * p.alpha, v1 * p.alpha, v2 * p.alpha, v3 * p.alpha};
   if (p.bias) {
     const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
@@ -83,6 +84,7 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], p.act);
   }
+  if (fin) { fin[0] = v[0]; fin[1] = v[1]; fin[2] = v[2]; fin[3] = v[3]; }
   if (p.out_mode == OUT_BF16) {
     uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
     *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
@@ -390,11 +392,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
       rrow[i] = (size_t)m * p.ldr;
       vrow[i] = p.rowvec ? (m / p.rows_per_batch) * p.rowvec_bstride : 0;
     }
+    // fused GroupNorm statistics of the OUTPUT tensor (consumed by the next GroupNorm: saves its whole stats pass).
+    // The 64 rows of a wave belong to one sample (rows_per_batch % 64 == 0); per-(sample, group) sum / sum of squares
+    // go through LDS bins [2 row halves][64 groups][2] (the tile ring is dead by now) and one global atomic per bin.
+    float* red = reinterpret_cast<float*>(smem);
+    if (p.gn_stats) {
+      __syncthreads();
+      red[tid] = 0.f;
+      __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = ncol + j * 16;
       if (n >= p.N) continue;
       const float4 bz = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
+      float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (!mok[i]) continue;
@@ -424,24 +436,88 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
           uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
           *reinterpret_cast<uint2*>((bf16_t*)p.C + crow[i] + n) = o;
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
       }
+      if (p.gn_stats) {
+        // the 4 columns of this lane fall into one group, or straddle two when cg % 4 != 0
+        const int g0 = n / p.gn_cg, g3 = (n + 3) / p.gn_cg;
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool lo = (g0 == g3) || ((n + e) / p.gn_cg == g0);
+          s0 += lo ? gs[e] : 0.f; q0 += lo ? gq[e] : 0.f;
+          s1 += lo ? 0.f : gs[e]; q1 += lo ? 0.f : gq[e];
+        }
+        atomicAdd(&red[(wm * 64 + g0) * 2], s0);
+        atomicAdd(&red[(wm * 64 + g0) * 2 + 1], q0);
+        if (g3 != g0) {
+          atomicAdd(&red[(wm * 64 + g3) * 2], s1);
+          atomicAdd(&red[(wm * 64 + g3) * 2 + 1], q1);
+        }
+      }
+    }
+    if (p.gn_stats) {
+      __syncthreads();
+      const int half = tid >> 7, g = (tid >> 1) & 63, which = tid & 1;
+      const int mfirst = m0 + half * 64;
+      const float val = red[tid];
+      if (mfirst < p.M && g < p.gn_groups && val != 0.f)
+        atomicAdd(&p.gn_stats[((size_t)(mfirst / p.rows_per_batch) * p.gn_groups + g) * 2 + which], val);
     }
   }
 }
 
 // split-K reduction + epilogue
+// Block = 64 rows x 64 columns (thread: one float4 column, 4 rows), so the fused GroupNorm statistics reduce through
+// 64 LDS bins to one global atomic per (group, moment) per block, like the in-kernel epilogue.
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs p) {
-  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
-  const int nq = p.N / 4;
-  if (q >= (int64_t)p.M * nq) return;
-  const int m = (int)(q / nq);
-  const int n = (int)(q - (int64_t)m * nq) * 4;
-  float4 s = make_float4(0, 0, 0, 0);
-  for (int z = 0; z < p.splitk; ++z) {
-    const float4 v = *reinterpret_cast<const float4*>(p.ws + ((size_t)z * p.M + m) * p.N + n);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  __shared__ float red[2 * 64];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int n = blockIdx.x * 64 + tx * 4;
+  const int mbase = blockIdx.y * 64;
+  if (p.gn_stats) {
+    if (threadIdx.x < 128) red[threadIdx.x] = 0.f;
+    __syncthreads();
   }
-  store4(p, m, n, s.x, s.y, s.z, s.w);
+  float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < p.N) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = mbase + ty + 16 * r;
+      if (m >= p.M) continue;
+      float4 s = make_float4(0, 0, 0, 0);
+      for (int z = 0; z < p.splitk; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(p.ws + ((size_t)z * p.M + m) * p.N + n);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      float fin[4];
+      store4(p, m, n, s.x, s.y, s.z, s.w, fin);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gs[e] += fin[e]; gq[e] += fin[e] * fin[e]; }
+    }
+  }
+  if (p.gn_stats) {
+    if (n < p.N) {
+      const int g0 = n / p.gn_cg, g3 = (n + 3) / p.gn_cg;
+      float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool lo = (g0 == g3) || ((n + e) / p.gn_cg == g0);
+        s0 += lo ? gs[e] : 0.f; q0 += lo ? gq[e] : 0.f;
+        s1 += lo ? 0.f : gs[e]; q1 += lo ? 0.f : gq[e];
+      }
+      atomicAdd(&red[g0 * 2], s0); atomicAdd(&red[g0 * 2 + 1], q0);
+      if (g3 != g0) { atomicAdd(&red[g3 * 2], s1); atomicAdd(&red[g3 * 2 + 1], q1); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int g = threadIdx.x >> 1, which = threadIdx.x & 1;
+      const float val = red[threadIdx.x];
+      if (g < p.gn_groups && val != 0.f && mbase < p.M)
+        atomicAdd(&p.gn_stats[((size_t)(mbase / p.rows_per_batch) * p.gn_groups + g) * 2 + which], val);
+    }
+  }
 }
 
 int gemm_pick_splitk(int M, int N, int K, int act) {
@@ -519,8 +595,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     else GILL_TRY((gemm_launch_stages<BN, 0, 0>(d, grid, stages, s)));
   }
   if (sk > 1) {
-    const int64_t n4 = (int64_t)a.M * (a.N / 4);
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, s, d.a);
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(cdiv(a.N, 64), cdiv(a.M, 64)), dim3(256), 0, s, d.a);
     GILL_CHECK_HIP(hipGetLastError());
   }
   return 0;
@@ -542,6 +617,11 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   } else {
     GILL_REQUIRE(a.K1 % BK == 0 && a.K1 <= a.K, "K split must be a multiple of 64");
     GILL_REQUIRE(a.K1 == a.K || a.A2 != nullptr, "second A source missing");
+  }
+  if (a.gn_stats) {
+    GILL_REQUIRE(a.out_mode != OUT_QKV && a.act != ACT_GEGLU, "fused GroupNorm statistics need the row-major epilogue");
+    GILL_REQUIRE(a.rows_per_batch % 64 == 0 && a.gn_groups > 0 && a.gn_groups <= 64 && a.gn_cg * a.gn_groups == a.N,
+                 "fused GroupNorm statistics: rows per sample must be a multiple of 64 and groups must tile N");
   }
   if (a.splitk > 1) {
     GILL_REQUIRE(a.ws != nullptr, "split-K workspace missing");

@@ -300,10 +300,14 @@ int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, 
   GILL_REQUIRE(groups <= 64 && C % groups == 0 && (C / groups) % 2 == 0, "groupnorm: channels/group must be even");
   GILL_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "groupnorm: channel counts must be multiples of 8");
   GILL_REQUIRE(C2 == 0 || x2 != nullptr, "groupnorm: second source missing");
-  if (!stats_prezeroed) GILL_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(float) * 2 * groups * B, s));
-  dim3 g1(cdiv(HW, GN_ROWS), B);
-  hipLaunchKernelGGL(groupnorm_stats_kernel, g1, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, stats);
-  GILL_CHECK_HIP(hipGetLastError());
+  // stats_prezeroed: 0 = zero `stats` here, 1 = caller zeroed it, 2 = `stats` already holds {sum, sum of squares}
+  // (accumulated by the producing GEMM's epilogue): skip the statistics pass entirely
+  if (stats_prezeroed != 2) {
+    if (!stats_prezeroed) GILL_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(float) * 2 * groups * B, s));
+    dim3 g1(cdiv(HW, GN_ROWS), B);
+    hipLaunchKernelGGL(groupnorm_stats_kernel, g1, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, stats);
+    GILL_CHECK_HIP(hipGetLastError());
+  }
   const int64_t total_vec = (int64_t)B * HW * (C / 8);
   dim3 g2(cdiv(HW, GN_APPLY_ROWS), B);
   hipLaunchKernelGGL(groupnorm_apply_kernel, g2, dim3(256), sizeof(float) * 2 * C, s, x1, C1, x2, C2, HW, groups, gamma, beta,

@@ -32,6 +32,9 @@ struct GemmArgs {
   int heads = 0, dp = 0, dpv = 0, ntok = 0, ntok_pad_q = 0, ntok_pad_kv = 0, seg_base = 0;
   // split-K (0/1 = off).  ws must hold splitk*M*N floats.
   int splitk = 1; float* ws = nullptr;
+  // fused GroupNorm statistics of the output: gn_stats[(m / rows_per_batch)][gn_groups][2] += {sum, sum of squares}
+  // over each group of gn_cg output channels (row-major epilogue only; gn_stats zeroed by the caller)
+  float* gn_stats = nullptr; int gn_groups = 0; int gn_cg = 0;
   // tuning: LDS ring depth (2|3, 0 = default 2) and tile width (128|160, 0 = by divisibility)
   int stages = 0; int bn = 0;
 };

@@ -50,7 +50,8 @@ struct XfW {  // Transformer2DModel with one BasicTransformerBlock
   LinW ff2;                   // [C][4C]
 };
 
-struct Tensor { bf16_t* p = nullptr; int H = 0, W = 0, C = 0; };
+// stats: optional slot [Bx][groups][2] that the PRODUCING GEMM epilogue fills with this tensor's GroupNorm sums
+struct Tensor { bf16_t* p = nullptr; int H = 0, W = 0, C = 0; float* stats = nullptr; };
 
 struct Arena {
   unsigned char* base = nullptr;
@@ -371,10 +372,24 @@ struct UNetRun {
   int temb_bstride;         // 0: every sample uses the same row
   bool dry;
 
-  Tensor talloc(int H, int W, int C) {
+  float* stats_slot() {   // next pre-zeroed slot of the per-forward pool (the dry run counts them)
+    float* p = dry ? nullptr : m->gn_stats + (size_t)m->gn_next * m->gn_slot_floats;
+    ++m->gn_next;
+    return p;
+  }
+  Tensor talloc(int H, int W, int C, bool want_stats = false) {
     Tensor t; t.H = H; t.W = W; t.C = C;
     t.p = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * H * W * C);
+    if (want_stats && (H * W) % 64 == 0 && C % m->cfg.norm_num_groups == 0) {
+      t.stats = stats_slot();
+      if (dry) t.stats = (float*)(uintptr_t)16;   // non-null marker so the dry run takes the same branches
+    }
     return t;
+  }
+  void fuse_stats(GemmArgs& g, const Tensor& y) {
+    if (!y.stats) return;
+    g.gn_stats = y.stats; g.gn_groups = m->cfg.norm_num_groups; g.gn_cg = y.C / m->cfg.norm_num_groups;
+    g.rows_per_batch = y.H * y.W;
   }
   int pick_sk(GemmArgs& g) {
     g.splitk = gemm_pick_splitk(g.M, g.N, g.K, g.act);
@@ -388,11 +403,13 @@ struct UNetRun {
     return gemm_launch(g, s);
   }
   int gnorm(const Tensor& x1, const Tensor* x2, const NormW& n, float eps, int silu, const Tensor& y) {
-    if (dry) { ++m->gn_next; return 0; }
-    GILL_REQUIRE(m->gn_next < m->gn_slots, "internal: GroupNorm stats pool exhausted");
-    float* stats = m->gn_stats + (size_t)(m->gn_next++) * m->gn_slot_floats;   // zeroed once per forward
+    // single-source input whose producer already accumulated the sums: no statistics pass
+    const bool ready = (x2 == nullptr) && (x1.stats != nullptr);
+    float* stats = ready ? x1.stats : stats_slot();
+    if (dry) return 0;
+    GILL_REQUIRE(m->gn_next <= m->gn_slots, "internal: GroupNorm stats pool exhausted");
     return groupnorm_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, x1.H * x1.W, m->cfg.norm_num_groups, n.g,
-                            n.b, eps, silu, y.p, stats, s, 1);
+                            n.b, eps, silu, y.p, stats, s, ready ? 2 : 1);
   }
   // 3x3 conv (pad 1) over x1 (++ x2): stride 1|2, optional fused nearest-2x upsample
   int conv(const Tensor& x1, const Tensor* x2, const ConvW& w, int stride, int ups, const float* rowvec, int rv_bstride,
@@ -405,23 +422,26 @@ struct UNetRun {
     g.rowvec = rowvec; g.rows_per_batch = y.H * y.W; g.rowvec_bstride = rv_bstride;
     g.resid = resid; g.ldr = w.cout;
     g.C = y.p; g.ldc = w.cout;
+    fuse_stats(g, y);
     return gemm(g);
   }
   int linear(const bf16_t* A, int lda, const bf16_t* A2, int lda2, int K1, int M, const bf16_t* W, const float* b, int N,
-             int K, const bf16_t* resid, int act, bf16_t* out, int ldc) {
+             int K, const bf16_t* resid, int act, bf16_t* out, int ldc, const Tensor* ystats = nullptr) {
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.K1 = K1; g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.W = W; g.bias = b;
     g.resid = resid; g.ldr = N; g.act = act; g.C = out; g.ldc = ldc;
+    if (ystats) fuse_stats(g, *ystats);
     return gemm(g);
   }
 
-  int resnet(const Tensor& x1, const Tensor* x2, const ResnetW& w, Tensor* out) {
+  // out_stats: the output feeds a single-source GroupNorm next (accumulate its sums in conv2's epilogue)
+  int resnet(const Tensor& x1, const Tensor* x2, const ResnetW& w, Tensor* out, bool out_stats) {
     const int H = x1.H, Wd = x1.W;
-    *out = talloc(H, Wd, w.cout);
+    *out = talloc(H, Wd, w.cout, out_stats);
     const size_t mk = m->arena.mark();
     Tensor n1 = talloc(H, Wd, w.cin);
     GILL_TRY(gnorm(x1, x2, w.n1, 1e-5f, 1, n1));
-    Tensor h = talloc(H, Wd, w.cout);
+    Tensor h = talloc(H, Wd, w.cout, true);   // -> norm2
     GILL_TRY(conv(n1, nullptr, w.c1, 1, 0, temb_rows ? temb_rows + w.temb_off : nullptr, temb_bstride, nullptr, h));
     Tensor n2 = talloc(H, Wd, w.cout);
     GILL_TRY(gnorm(h, nullptr, w.n2, 1e-5f, 1, n2));
@@ -448,10 +468,10 @@ struct UNetRun {
     return attention_launch(a, s);
   }
 
-  int xf(const Tensor& x, const XfW& w, Tensor* out) {
+  int xf(const Tensor& x, const XfW& w, Tensor* out, bool out_stats) {
     const int H = x.H, Wd = x.W, C = w.C, HW = H * Wd, M = Bx * HW;
     const int nh = m->cfg.num_heads, hdp = nh * w.dp;
-    *out = talloc(H, Wd, C);
+    *out = talloc(H, Wd, C, out_stats);
     const size_t mk = m->arena.mark();
     Tensor n = talloc(H, Wd, C);
     GILL_TRY(gnorm(x, nullptr, w.gn, 1e-6f, 0, n));
@@ -496,7 +516,7 @@ struct UNetRun {
     }
     GILL_TRY(linear(ffh, 4 * C, nullptr, 0, 4 * C, M, w.ff2.w, w.ff2.b, C, 4 * C, t.p, ACT_NONE, t.p, C));
     // --- proj_out + outer residual
-    GILL_TRY(linear(t.p, C, nullptr, 0, C, M, w.proj_out.w, w.proj_out.b, C, C, x.p, ACT_NONE, out->p, C));
+    GILL_TRY(linear(t.p, C, nullptr, 0, C, M, w.proj_out.w, w.proj_out.b, C, C, x.p, ACT_NONE, out->p, C, out));
     m->arena.release(mk);
     return 0;
   }
@@ -510,43 +530,45 @@ struct UNetRun {
     m->gn_next = 0;
     if (!dry) GILL_CHECK_HIP(hipMemsetAsync(m->gn_stats, 0, sizeof(float) * (size_t)m->gn_slots * m->gn_slot_floats, s));
     std::vector<Tensor> skips;
-    Tensor x = talloc(L, L, ch[0]);
+    Tensor x = talloc(L, L, ch[0], true);
     {
       // conv_in: im2col (K = 9*Cin padded to 64) + MFMA GEMM
       const size_t mk = m->arena.mark();
       bf16_t* col = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * L * L * 64);
       if (!dry) GILL_TRY(im2col_nchw_launch(sample, Bx, c.in_channels, L, L, 64, col, s));
-      GILL_TRY(linear(col, 64, nullptr, 0, 64, Bx * L * L, m->conv_in_w, m->conv_in_b, ch[0], 64, nullptr, ACT_NONE, x.p, ch[0]));
+      GILL_TRY(linear(col, 64, nullptr, 0, 64, Bx * L * L, m->conv_in_w, m->conv_in_b, ch[0], 64, nullptr, ACT_NONE, x.p, ch[0], &x));
       m->arena.release(mk);
     }
     skips.push_back(x);
     for (int i = 0; i < 4; ++i) {
       for (int j = 0; j < 2; ++j) {
         Tensor y;
-        GILL_TRY(resnet(x, nullptr, m->down_res[i][j], &y));
+        GILL_TRY(resnet(x, nullptr, m->down_res[i][j], &y, true));
         x = y;
-        if (i < 3) { Tensor z; GILL_TRY(xf(x, m->down_xf[i][j], &z)); x = z; }
+        // next consumer: resnet norm1 (j == 0) / the downsample conv or the mid block's norm1 (j == 1)
+        if (i < 3) { Tensor z; GILL_TRY(xf(x, m->down_xf[i][j], &z, j == 0)); x = z; }
         skips.push_back(x);
       }
       if (i < 3) {
-        Tensor y = talloc(x.H / 2, x.W / 2, ch[i]);
+        Tensor y = talloc(x.H / 2, x.W / 2, ch[i], true);
         GILL_TRY(conv(x, nullptr, m->down_ds[i], 2, 0, nullptr, 0, nullptr, y));
         x = y;
         skips.push_back(x);
       }
     }
     {
-      Tensor y; GILL_TRY(resnet(x, nullptr, m->mid_res[0], &y)); x = y;
-      Tensor z; GILL_TRY(xf(x, m->mid_xf, &z)); x = z;
-      Tensor u; GILL_TRY(resnet(x, nullptr, m->mid_res[1], &u)); x = u;
+      Tensor y; GILL_TRY(resnet(x, nullptr, m->mid_res[0], &y, true)); x = y;
+      Tensor z; GILL_TRY(xf(x, m->mid_xf, &z, true)); x = z;
+      Tensor u; GILL_TRY(resnet(x, nullptr, m->mid_res[1], &u, false)); x = u;   // -> two-source norm1 of up block 0
     }
     for (int i = 0; i < 4; ++i) {
       for (int j = 0; j < 3; ++j) {
         Tensor skip = skips.back(); skips.pop_back();
+        const bool last = (i == 3 && j == 2);   // feeds conv_norm_out; every other up-path output meets a skip concat
         Tensor y;
-        GILL_TRY(resnet(x, &skip, m->up_res[i][j], &y));
+        GILL_TRY(resnet(x, &skip, m->up_res[i][j], &y, i > 0));
         x = y;
-        if (i > 0) { Tensor z; GILL_TRY(xf(x, m->up_xf[i][j], &z)); x = z; }
+        if (i > 0) { Tensor z; GILL_TRY(xf(x, m->up_xf[i][j], &z, last)); x = z; }
       }
       if (i < 3) {
         Tensor y = talloc(x.H * 2, x.W * 2, x.C);
