@@ -20,6 +20,9 @@
 // conv epilogues add as a per-channel row vector).
 #include "engine_util.h"
 #include <math.h>
+#include <stdlib.h>
+#include <map>
+#include <set>
 #include <hip/hip_fp16.h>
 
 namespace {
@@ -108,6 +111,12 @@ struct gill_unet {
   float* cur_sample = nullptr;
   float* ets = nullptr;         // [4][B][4*L*L]
   bf16_t* ctx_full = nullptr;   // [2B][77][768]
+  float* temb_cur = nullptr;    // [temb_total]: time-embedding row of the step being replayed
+  // hipGraph of one UNet forward per UNet batch size (captured after the first eager forward of that size)
+  std::map<int, hipGraphExec_t> graphs;
+  std::set<int> warmed;
+  bool use_graph = true;
+  ~gill_unet() { for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second); }
 };
 
 // dst[r][h*dp + dd] = src[r][h*d + dd] (dd < d), zero elsewhere.  dst pre-zeroed.
@@ -627,6 +636,8 @@ static int unet_plan_and_alloc(gill_unet* m) {
   GILL_TRY(m->pool.alloc(&m->cur_sample, (size_t)Bx * n_lat));
   GILL_TRY(m->pool.alloc(&m->ets, (size_t)4 * Bx * n_lat));
   GILL_TRY(m->pool.alloc(&m->ctx_full, (size_t)Bx * c.ctx_len * c.cross_attention_dim));
+  GILL_TRY(m->pool.alloc(&m->temb_cur, (size_t)m->temb_total));
+  { const char* e = getenv("GILL_NO_GRAPH"); m->use_graph = !(e && e[0] == '1'); }
   return 0;
 }
 
@@ -764,8 +775,35 @@ extern "C" int gill_sd_denoise(gill_unet* m, const void* cond_bf16, const void* 
     GILL_CHECK_HIP(hipMemcpyAsync(m->lat2, m->lat, sizeof(float) * n_lat * B, hipMemcpyDeviceToDevice, s));
     if (cfg)
       GILL_CHECK_HIP(hipMemcpyAsync(m->lat2 + n_lat * B, m->lat, sizeof(float) * n_lat * B, hipMemcpyDeviceToDevice, s));
-    UNetRun r{m, s, Bx, m->temb_table + (size_t)i * m->temb_total, 0, false};
-    GILL_TRY(r.forward(m->lat2, m->eps));
+    // One UNet forward is ~520 kernel launches at ~10+ us of host time each: at small batch the GPU outruns the host.
+    // So the forward is captured ONCE per batch size into a hipGraph and replayed; the only per-step input, the
+    // time-embedding row, is staged into a fixed buffer in front of each replay.
+    GILL_CHECK_HIP(hipMemcpyAsync(m->temb_cur, m->temb_table + (size_t)i * m->temb_total, sizeof(float) * m->temb_total,
+                                  hipMemcpyDeviceToDevice, s));
+    const int gkey = Bx;
+    auto git = m->graphs.find(gkey);
+    if (git == m->graphs.end() && m->use_graph && m->warmed.count(gkey)) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      GILL_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+      UNetRun rc{m, s, Bx, m->temb_cur, 0, false};
+      const int rc_status = rc.forward(m->lat2, m->eps);
+      const hipError_t ec = hipStreamEndCapture(s, &graph);
+      if (rc_status != 0) { if (graph) (void)hipGraphDestroy(graph); return rc_status; }
+      GILL_CHECK_HIP(ec);
+      GILL_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      git = m->graphs.emplace(gkey, exec).first;
+    }
+    if (git != m->graphs.end()) {
+      GILL_CHECK_HIP(hipGraphLaunch(git->second, s));
+    } else {
+      // first forward of this batch size runs eagerly: it also performs every one-time kernel attribute set-up,
+      // which must not happen inside a stream capture
+      UNetRun r{m, s, Bx, m->temb_cur, 0, false};
+      GILL_TRY(r.forward(m->lat2, m->eps));
+      m->warmed.insert(gkey);
+    }
 
     int t = ts[i];
     int prev_t = t - ratio;
