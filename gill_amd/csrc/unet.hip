@@ -116,7 +116,11 @@ struct gill_unet {
   std::map<int, hipGraphExec_t> graphs;
   std::set<int> warmed;
   bool use_graph = true;
-  ~gill_unet() { for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second); }
+  hipStream_t cap_stream = nullptr;
+  ~gill_unet() {
+    for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
+  }
 };
 
 // dst[r][h*dp + dd] = src[r][h*d + dd] (dd < d), zero elsewhere.  dst pre-zeroed.
@@ -785,10 +789,13 @@ extern "C" int gill_sd_denoise(gill_unet* m, const void* cond_bf16, const void* 
     if (git == m->graphs.end() && m->use_graph && m->warmed.count(gkey)) {
       hipGraph_t graph = nullptr;
       hipGraphExec_t exec = nullptr;
-      GILL_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-      UNetRun rc{m, s, Bx, m->temb_cur, 0, false};
+      // the caller's stream may be the legacy default stream, which cannot be captured: record on a private stream
+      // (capture only records the launches), replay on the caller's stream
+      if (!m->cap_stream) GILL_CHECK_HIP(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+      GILL_CHECK_HIP(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
+      UNetRun rc{m, m->cap_stream, Bx, m->temb_cur, 0, false};
       const int rc_status = rc.forward(m->lat2, m->eps);
-      const hipError_t ec = hipStreamEndCapture(s, &graph);
+      const hipError_t ec = hipStreamEndCapture(m->cap_stream, &graph);
       if (rc_status != 0) { if (graph) (void)hipGraphDestroy(graph); return rc_status; }
       GILL_CHECK_HIP(ec);
       GILL_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
