@@ -153,13 +153,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
 
   // A rows (4 per lane): element offset of the row start (plain) / of the centre input pixel (conv) in each source,
   // plus conv flag bits {1: dy=-1 in range, 2: dy=+1, 4: dx=-1, 8: dx=+1, 16: oy odd, 32: ox odd}
-  int a_off1[4], a_off2[4], a_fl[4];
+  int a_off1[4], a_off2[4], a_fl[4], a_pc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int row = (i * 4 + w) * 8 + srow;
     int m = m0 + row;
     if (m > p.M - 1) m = p.M - 1;
-    a_fl[i] = 0;
+    a_fl[i] = 0; a_pc[i] = 0;
     if constexpr (CONV == 0) {
       a_off1[i] = m * p.lda + schunk * 8;
       a_off2[i] = m * p.lda2 + schunk * 8;
@@ -182,6 +182,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
         fl |= (cx - 1 >= 0) ? 4 : 0; fl |= (cx + 1 < p.IW) ? 8 : 0;
       }
       a_fl[i] = fl;
+      a_pc[i] = m;          // output pixel == input pixel of the fused 1x1 shortcut segment (stride 1 only)
       a_off1[i] = pc * p.K1 + schunk * 8;
       a_off2[i] = pc * (p.Cin - p.K1) + schunk * 8;
     }
@@ -214,6 +215,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
                                          (__attribute__((address_space(3))) void*)l, 16, 0, 0);
       }
     } else {
+      if (CONV == 1 && k0 >= 9 * p.Cin) {
+        // fused 1x1 "conv_shortcut" segment: K continues over the channels of the raw block input X1 (++ X2) at the
+        // centre pixel; the weight rows carry [conv taps | shortcut] back to back
+        const int ke = k0 - 9 * p.Cin;
+        const bool fx = (ke < p.KX1);
+        const bf16_t* xs = fx ? p.X1 : p.X2;
+        const int cx = fx ? p.KX1 : (p.KX - p.KX1);
+        const int kc = (fx ? ke : ke - p.KX1) + schunk * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bf16_t* g = xs + (size_t)a_pc[i] * cx + kc;
+          bf16_t* l = As + (i * 4 + w) * 8 * BK;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                           (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        }
+      } else {
       // all wave-uniform: tap, source tensor, channel offset, tap displacement
       const int tap = k0 / p.Cin;
       const int c0 = k0 - tap * p.Cin;
@@ -239,6 +256,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
         bf16_t* l = As + (i * 4 + w) * 8 * BK;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+      }
       }
     }
 #pragma unroll
@@ -608,7 +626,12 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   GILL_REQUIRE(a.N % 4 == 0, "N must be a multiple of 4");
   GILL_REQUIRE(a.A != nullptr && a.W != nullptr, "null operand");
   if (a.conv) {
-    GILL_REQUIRE(a.Cin % BK == 0 && a.K == 9 * a.Cin, "conv: Cin must be a multiple of 64 and K == 9*Cin");
+    GILL_REQUIRE(a.Cin % BK == 0 && a.K == 9 * a.Cin + a.KX, "conv: Cin must be a multiple of 64 and K == 9*Cin + KX");
+    if (a.KX) {
+      GILL_REQUIRE(a.stride == 1 && !a.ups && a.X1 != nullptr, "conv: the fused 1x1 segment needs stride 1, no upsample");
+      GILL_REQUIRE(a.KX % BK == 0 && a.KX1 % BK == 0 && a.KX1 <= a.KX && (a.KX1 == a.KX || a.X2 != nullptr),
+                   "conv: fused 1x1 segment channel counts must be multiples of 64");
+    }
     GILL_REQUIRE(a.K1 % BK == 0 && a.K1 <= a.Cin, "conv: source split must be a multiple of 64");
     GILL_REQUIRE(a.K1 == a.Cin || a.A2 != nullptr, "conv: second source missing");
     GILL_REQUIRE(!(a.ups && a.stride != 1), "conv: upsample needs stride 1");

@@ -18,7 +18,10 @@ struct GemmArgs {
   int K1 = 0;                 // plain: columns taken from A (K1 == K when single source); conv: channels of A
   int conv = 0;               // 0 plain GEMM, 1 conv3x3 pad 1 over NHWC
   int IH = 0, IW = 0, OH = 0, OW = 0, Cin = 0, stride = 1, ups = 0;
-  const bf16_t* W = nullptr;  // [N][K], K contiguous (conv: k = tap*Cin + c)
+  // conv only: extra plain K segment appended after the 9 taps (a fused 1x1 conv of the tensor X1 ++ X2 at the same
+  // pixel, i.e. ResnetBlock2D's conv_shortcut): KX channels in total, the first KX1 from X1
+  const bf16_t* X1 = nullptr; const bf16_t* X2 = nullptr; int KX = 0, KX1 = 0;
+  const bf16_t* W = nullptr;  // [N][K], K contiguous (conv: k = tap*Cin + c, then the KX shortcut channels)
   float alpha = 1.f;
   const float* bias = nullptr;
   const float* rowvec = nullptr; int rows_per_batch = 1; int rowvec_bstride = 0;  // + rowvec[(m/rows_per_batch)*bstride + n]

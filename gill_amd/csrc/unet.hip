@@ -36,6 +36,8 @@ struct ResnetW {
   ConvW c1, c2;
   bool has_sc = false;
   LinW sc;
+  // conv2 with the 1x1 conv_shortcut fused as extra K channels: weights [cout][9*cout + cin], bias b2 + b_sc
+  bf16_t* c2f_w = nullptr; float* c2f_b = nullptr;
   int cin = 0, cout = 0, temb_off = 0;
 };
 
@@ -123,6 +125,11 @@ struct gill_unet {
   }
 };
 
+__global__ void vec_add_f32_kernel(const float* a, const float* b, int n, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
+}
+
 // dst[r][h*dp + dd] = src[r][h*d + dd] (dd < d), zero elsewhere.  dst pre-zeroed.
 __global__ __launch_bounds__(256) void pad_head_cols_kernel(const void* src, int dtype, int rows, int H, int d, int dp,
                                                             bf16_t* dst) {
@@ -195,7 +202,22 @@ struct Loader {
     GILL_TRY(norm(p + ".norm2", cout, &r->n2));
     GILL_TRY(conv3(p + ".conv2", cout, cout, &r->c2));
     r->has_sc = (cin != cout);
-    if (r->has_sc) GILL_TRY(lin(p + ".conv_shortcut", cout, cin, &r->sc));
+    if (r->has_sc) {
+      GILL_TRY(lin(p + ".conv_shortcut", cout, cin, &r->sc));
+      // fused weight rows: [conv2 taps (9*cout) | shortcut (cin)]
+      const int kf = 9 * cout + cin;
+      std::vector<int32_t> ident(cout);
+      for (int i = 0; i < cout; ++i) ident[i] = i;
+      int32_t* idx;
+      GILL_TRY(pool.alloc(&idx, (size_t)cout, false));
+      GILL_CHECK_HIP(hipMemcpy(idx, ident.data(), sizeof(int32_t) * cout, hipMemcpyHostToDevice));
+      GILL_TRY(pool.alloc(&r->c2f_w, (size_t)cout * kf, false));
+      GILL_TRY(scatter_rows_bf16_launch(r->c2.w, cout, 9 * cout, idx, r->c2f_w, kf, s));
+      GILL_TRY(scatter_rows_bf16_launch(r->sc.w, cout, cin, idx, r->c2f_w + 9 * cout, kf, s));
+      GILL_TRY(pool.alloc(&r->c2f_b, (size_t)cout, false));
+      hipLaunchKernelGGL(vec_add_f32_kernel, dim3(cdiv(cout, 256)), dim3(256), 0, s, r->c2.b, r->sc.b, cout, r->c2f_b);
+      GILL_CHECK_HIP(hipGetLastError());
+    }
     // time_emb_proj rows go into the shared [sum Cout][temb_dim] matrix
     r->temb_off = *temb_off;
     const gill_tensor* t;
@@ -458,14 +480,22 @@ struct UNetRun {
     GILL_TRY(conv(n1, nullptr, w.c1, 1, 0, temb_rows ? temb_rows + w.temb_off : nullptr, temb_bstride, nullptr, h));
     Tensor n2 = talloc(H, Wd, w.cout);
     GILL_TRY(gnorm(h, nullptr, w.n2, 1e-5f, 1, n2));
-    const bf16_t* res = x1.p;
     if (w.has_sc) {
-      Tensor sc = talloc(H, Wd, w.cout);
-      GILL_TRY(linear(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, x1.C, Bx * H * Wd, w.sc.w, w.sc.b, w.cout, w.cin,
-                      nullptr, ACT_NONE, sc.p, w.cout));
-      res = sc.p;
+      // out = conv2(n2) + conv_shortcut(x1 ++ x2): ONE implicit GEMM whose K runs over the 9 taps of n2 and then over
+      // the raw input channels (no separate 1x1 GEMM, no shortcut tensor written and re-read as a residual)
+      GemmArgs g;
+      g.conv = 1; g.IH = H; g.IW = Wd; g.OH = H; g.OW = Wd; g.Cin = w.cout; g.stride = 1; g.ups = 0;
+      g.M = Bx * H * Wd; g.N = w.cout; g.K = 9 * w.cout + w.cin;
+      g.A = n2.p; g.K1 = w.cout;
+      g.X1 = x1.p; g.X2 = x2 ? x2->p : nullptr; g.KX = w.cin; g.KX1 = x1.C;
+      g.W = w.c2f_w; g.bias = w.c2f_b;
+      g.rows_per_batch = H * Wd;
+      g.C = out->p; g.ldc = w.cout;
+      fuse_stats(g, *out);
+      GILL_TRY(gemm(g));
+    } else {
+      GILL_TRY(conv(n2, nullptr, w.c2, 1, 0, nullptr, 0, x1.p, *out));
     }
-    GILL_TRY(conv(n2, nullptr, w.c2, 1, 0, nullptr, 0, res, *out));
     m->arena.release(mk);
     return 0;
   }
