@@ -101,7 +101,7 @@ def cpu_baseline(n_infer_steps):
   minutes; it is 0.65 % of an image's FLOPs and is left out of the sample, which flatters the CPU slightly)."""
   from gill_amd import synth
   from oracle import mapper_ref, unet_ref
-  cores = os.cpu_count() or 1
+  cores = synth.host_cores()
   torch.set_num_threads(cores)
   cfg = synth.UNetConfig.sd15()
   sd = synth.unet_state_dict(cfg, seed=0)

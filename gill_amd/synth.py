@@ -257,6 +257,20 @@ def uncond_context(ctx_len: int = 77, dim: int = 768, seed: int = 0) -> torch.Te
   return normal("uncond_context", (1, ctx_len, dim), seed)
 
 
+def host_cores() -> int:
+  """CPU cores this process may actually use: min(affinity mask, cgroup cpu.max quota).  (The MI355X boxes expose 256
+  logical CPUs but run under a 16-CPU quota; oversubscribing torch's CPU thread pool there is ~20x slower.)"""
+  import os
+  n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+  try:
+    quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+    if quota != "max":
+      n = min(n, max(1, int(int(quota) / int(period))))
+  except Exception:
+    pass
+  return max(1, n)
+
+
 # ---------------------------------------------------------------------------------------------- tokenizer stand-in
 class HashTokenizer:
   """Offline stand-in for the OPT GPT2 tokenizer (no vocab files exist in this environment).  Exposes the

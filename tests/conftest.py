@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
   config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+  # the CPU oracle runs on torch's CPU thread pool: size it to the cores this process may use (cgroup quota)
+  import torch
+  from gill_amd.synth import host_cores
+  torch.set_num_threads(host_cores())
 
 
 @pytest.fixture(scope="session")

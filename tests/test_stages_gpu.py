@@ -178,7 +178,6 @@ def test_unet_forward_sd15_vs_oracle(cuda):
   x = synth.initial_latents(2, 4, 64, seed=1337)
   ctx = torch.cat([uncond, synth.normal("sd15_ctx", (1, 77, 768), 2)], 0).bfloat16().float()
   t = torch.tensor([961.0, 961.0])
-  torch.set_num_threads(max(1, os.cpu_count() or 1))
   ref = unet_ref.unet_forward(sd, x, t, ctx)
   got = pipe.unet(x, t, ctx)
   mse, rel, cos = _stats("unet SD-1.5 forward", got, ref)
