@@ -18,6 +18,10 @@
 // k-slots of the B operand of the PV MFMAs, provided the Vt fragment is gathered with the same kv permutation
 //   kv(h, hi, j) = 16*h + 8*(j>>2) + 4*hi + (j&3)          (two 8-byte LDS reads per fragment).
 //
+// Softmax cost (the bound at d = 40: one exp per 80 MACs): Q is pre-scaled by scale*log2(e) and the S accumulator is
+// initialised to -m_run, so p = exp2(mfma result); the running max only moves when a row grows past m_run + 8 (rare,
+// wave-uniform slow path), and for DP % 32 != 0 the row sum rides through the PV MFMAs on a ones-row of Vt.
+//
 // DP (padded head dim, multiple of 16): 48 (d=40), 64, 80, 128, 160.  Padding columns of Q/K are exact zeros
 // (zero weight rows); padding rows of Vt (up to dpv = roundup(DP,32)) only feed output rows that are never stored.
 #include "ops.h"
@@ -33,6 +37,7 @@ struct AttCfg {
   static constexpr int DPV = NDT * 32;
   static constexpr int KSTR = DP + 8;             // K row stride in elements (+16 B)
   static constexpr int VSTR = ATT_KVT + 4;        // Vt row stride in elements (+8 B)
+  static constexpr bool HAS_ONES = (DP % 32) != 0; // a spare Vt row (index DP) of ones carries the softmax row sum
   static constexpr int K_CHUNKS = ATT_KVT * DP / 8;       // 16-B chunks of a K tile
   static constexpr int V_CHUNKS = DPV * ATT_KVT / 8;      // 16-B chunks of a Vt tile
   static constexpr int K_PER_THR = (K_CHUNKS + ATT_THREADS - 1) / ATT_THREADS;
@@ -82,8 +87,8 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
 
-  const float sl2 = p.scale * 1.4426950408889634f;  // scores are tracked in the log2 domain
-  float m_run = -1e30f, l_run = 0.f;
+  // scores live in the log2 domain: Q was multiplied by scale * log2(e) by its producer (AttnArgs::scale is informative)
+  float m_run = 0.f, l_run = 0.f;
 
   // causal: query i attends kv <= i + (nkv - nq).  The tile loop bound is uniform per workgroup.
   const int coff = p.nkv - p.nq;
@@ -155,12 +160,15 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
     const bf16_t* Vs = Ks + Cfg::K_ELEMS;
 
     if (wave_active && kv0 < wave_kv_end) {
-      // ---- S^T for the two 32-key halves
+      // ---- S^T for the two 32-key halves.  Q arrives pre-multiplied by scale*log2(e), and the accumulator starts at
+      // -m_run, so the MFMA result IS the exponent s - m_run: no per-element scale / subtract VALU work.
+      const bool first = (tile == 0);
+      const float acc0 = first ? 0.f : -m_run;
       f32x16 s[2];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[hh][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[hh][r] = acc0;
         const bf16_t* krow = Ks + (hh * 32 + lq) * KSTR + hi * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -186,25 +194,42 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[hh][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      // masked entries are -inf (exp2 -> exactly 0); the running max lives in the scaled log2 domain and stays finite
-      const float m_new = fmaxf(m_run, mx > -1e29f ? mx * sl2 : -1e30f);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      float rs = 0.f;
+      // Lazy running max: m_run moves only on the first tile or when a row's scores exceed it by > 8 (p <= 2^8: exact
+      // in the bf16 exponent range, fp32 accumulators have the headroom).  The rescale of O (and of the row sum, which
+      // rides in O as the ones-row of Vt) is then a rare wave-uniform slow path instead of per-tile work.
+      // Masked entries are -inf (exp2 -> exactly 0).
+      const bool grow = first || (mx > 8.0f);
+      if (__any(grow)) {
+        float delta;
+        if (first) { m_run = (mx > -INFINITY) ? mx : 0.f; delta = m_run; }   // (a valid row always sees key 0)
+        else { delta = fmaxf(mx, 0.f); m_run += delta; }                    // fully masked row: mx = -inf -> 0
+        if (!first) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          l_run *= alpha;
+#pragma unroll
+          for (int t = 0; t < NDT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[hh][r] -= delta;
+      }
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = __builtin_amdgcn_exp2f(fmaf(s[hh][r], sl2, -m_new));
-          s[hh][r] = e;
-          rs += e;
-        }
-      rs += __shfl_xor(rs, 32, 64);
-      l_run = l_run * alpha + rs;
-      m_run = m_new;
+        for (int r = 0; r < 16; ++r) s[hh][r] = __builtin_amdgcn_exp2f(s[hh][r]);
+      if constexpr (!Cfg::HAS_ONES) {
+        // no spare Vt row to carry the row sum (DP % 32 == 0): explicit sum
+        float rs = 0.f;
 #pragma unroll
-      for (int t = 0; t < NDT; ++t)
+        for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+          for (int r = 0; r < 16; ++r) rs += s[hh][r];
+        rs += __shfl_xor(rs, 32, 64);
+        l_run += rs;
+      }
 
       bf16x8 pa[4];
 #pragma unroll
@@ -230,7 +255,14 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
     __syncthreads();
   }
 
-  if (!wave_active || !qvalid) return;
+  if (!wave_active) return;
+  if constexpr (Cfg::HAS_ONES) {
+    // Vt row DP is all ones (written by the QKV epilogue), so O^T row DP accumulated sum_kv P: it sits in register 8
+    // of tile DP/32 in the hi = 0 half wave (d = 32 t + 8 g + 4 hi + j with DP % 32 == 16 -> g = 2, hi = 0, j = 0)
+    static_assert(DP % 32 == 16, "ones-row position");
+    l_run = __shfl(oacc[DP / 32][8], lq, 64);
+  }
+  if (!qvalid) return;
   const float inv = 1.f / l_run;
   bf16_t* orow = p.O + (size_t)(b * p.nq + qrow) * p.ldo + h * DP;
 #pragma unroll

@@ -109,7 +109,7 @@ extern "C" int gill_op_attention(const void* q, const void* k, const void* v, vo
   GILL_TRY(K.alloc_zero(sizeof(bf16_t) * (size_t)B * H * nkv_pad * dp, s));
   GILL_TRY(Vt.alloc_zero(sizeof(bf16_t) * (size_t)B * H * dpv * nkv_pad, s));
   GILL_TRY(O.alloc_zero(sizeof(bf16_t) * (size_t)B * nq * H * dp, s));
-  GILL_TRY(pack_heads_launch((const bf16_t*)q, B, nq, H, d, nq_pad, dp, dpv, 0, (bf16_t*)Q.p, s));
+  GILL_TRY(pack_heads_launch((const bf16_t*)q, B, nq, H, d, nq_pad, dp, dpv, 0, (bf16_t*)Q.p, s, scale * 1.4426950408889634f));
   GILL_TRY(pack_heads_launch((const bf16_t*)k, B, nkv, H, d, nkv_pad, dp, dpv, 0, (bf16_t*)K.p, s));
   GILL_TRY(pack_heads_launch((const bf16_t*)v, B, nkv, H, d, nkv_pad, dp, dpv, 1, (bf16_t*)Vt.p, s));
   AttnArgs a;

@@ -404,21 +404,25 @@ int permute_f32_launch(const float* src, const int32_t* idx, int n, float* dst, 
 // token-major (B, n, H*d) -> head-major padded [B][H][n_pad][dp] (mode 0) or transposed [B][H][dpv][n_pad] (mode 1).
 // Destination must be pre-zeroed (padding).
 __global__ __launch_bounds__(256) void pack_heads_kernel(const bf16_t* __restrict__ src, int n, int H, int d, int n_pad,
-                                                         int dp, int dpv, int mode, bf16_t* __restrict__ dst, int64_t total) {
+                                                         int dp, int dpv, int mode, bf16_t* __restrict__ dst, int64_t total,
+                                                         float mul) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int dd = (int)(i % d);
     const int h = (int)((i / d) % H);
     const int t = (int)((i / ((int64_t)d * H)) % n);
     const int b = (int)(i / ((int64_t)d * H * n));
-    const bf16_t v = src[i];
+    const bf16_t v = (mul == 1.f) ? src[i] : f2bf(bf2f(src[i]) * mul);
     if (mode == 0) dst[((size_t)(b * H + h) * n_pad + t) * dp + dd] = v;
-    else dst[((size_t)(b * H + h) * dpv + dd) * n_pad + t] = v;
+    else {
+      dst[((size_t)(b * H + h) * dpv + dd) * n_pad + t] = v;
+      if (dd == 0 && dpv > dp) dst[((size_t)(b * H + h) * dpv + dp) * n_pad + t] = (bf16_t)0x3F80;   // ones row (row sum)
+    }
   }
 }
 int pack_heads_launch(const bf16_t* src, int B, int n, int H, int d, int n_pad, int dp, int dpv, int mode, bf16_t* dst,
-                      hipStream_t s) {
+                      hipStream_t s, float mul) {
   const int64_t total = (int64_t)B * n * H * d;
-  hipLaunchKernelGGL(pack_heads_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, n, H, d, n_pad, dp, dpv, mode, dst, total);
+  hipLaunchKernelGGL(pack_heads_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, n, H, d, n_pad, dp, dpv, mode, dst, total, mul);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }

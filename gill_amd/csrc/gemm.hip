@@ -97,7 +97,7 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0
     const int h = within / p.dp, dd = within % p.dp;
     const int b = m / p.ntok, t = m % p.ntok;
     if (seg == 0) {
-      uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+      uint2 o; o.x = pack_bf2(v[0] * p.qscale, v[1] * p.qscale); o.y = pack_bf2(v[2] * p.qscale, v[3] * p.qscale);
       *reinterpret_cast<uint2*>(p.Cq + ((size_t)(b * p.heads + h) * p.ntok_pad_q + t) * p.dp + dd) = o;
     } else if (seg == 1) {
       uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
@@ -106,6 +106,7 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0
       bf16_t* base = p.Cvt + ((size_t)(b * p.heads + h) * p.dpv + dd) * p.ntok_pad_kv + t;
 #pragma unroll
       for (int i = 0; i < 4; ++i) base[(size_t)i * p.ntok_pad_kv] = f2bf(v[i]);
+      if (dd + 4 == p.dp && p.dpv > p.dp) base[(size_t)4 * p.ntok_pad_kv] = (bf16_t)0x3F80;
     }
   }
 }
@@ -382,9 +383,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (!mok[i]) continue;
-        const float v0 = acc[i][j][0] * p.alpha + bz.x, v1 = acc[i][j][1] * p.alpha + bz.y;
-        const float v2 = acc[i][j][2] * p.alpha + bz.z, v3 = acc[i][j][3] * p.alpha + bz.w;
+        float v0 = acc[i][j][0] * p.alpha + bz.x, v1 = acc[i][j][1] * p.alpha + bz.y;
+        float v2 = acc[i][j][2] * p.alpha + bz.z, v3 = acc[i][j][3] * p.alpha + bz.w;
         if (seg == 0) {
+          v0 *= p.qscale; v1 *= p.qscale; v2 *= p.qscale; v3 *= p.qscale;   // softmax scale * log2(e) folded into Q
           uint2 o; o.x = pack_bf2(v0, v1); o.y = pack_bf2(v2, v3);
           *reinterpret_cast<uint2*>(p.Cq + (size_t)rq[i] + (size_t)h * p.ntok_pad_q * p.dp + dd) = o;
         } else if (seg == 1) {
@@ -396,6 +398,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
           base[(size_t)p.ntok_pad_kv] = f2bf(v1);
           base[(size_t)2 * p.ntok_pad_kv] = f2bf(v2);
           base[(size_t)3 * p.ntok_pad_kv] = f2bf(v3);
+          // spare row dp of Vt := 1.0: the attention kernel reads the softmax row sum off the PV MFMAs
+          if (dd + 4 == p.dp && p.dpv > p.dp) base[(size_t)4 * p.ntok_pad_kv] = (bf16_t)0x3F80;
         }
       }
     }

@@ -155,6 +155,7 @@ struct MapperRun {
     g.out_mode = OUT_QKV; g.Cq = m->q; g.Ck = m->k; g.Cvt = m->vt;
     g.heads = m->cfg.num_heads; g.dp = m->dp; g.dpv = m->dpv; g.ntok = ntok;
     g.ntok_pad_q = npad_q; g.ntok_pad_kv = npad_kv; g.seg_base = seg_base;
+    g.qscale = 1.4426950408889634f / sqrtf((float)m->dp);
     return gemm_launch(g, s);
   }
   int attend(int B, int nq, int nkv) {

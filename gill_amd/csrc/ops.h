@@ -33,6 +33,7 @@ struct GemmArgs {
   //   segment = seg_base + n / (heads*dp): 0 -> Q[b][h][t][dp], 1 -> K[b][h][t][dp], 2 -> Vt[b][h][dd][t]
   bf16_t* Cq = nullptr; bf16_t* Ck = nullptr; bf16_t* Cvt = nullptr;
   int heads = 0, dp = 0, dpv = 0, ntok = 0, ntok_pad_q = 0, ntok_pad_kv = 0, seg_base = 0;
+  float qscale = 1.f;   // multiplies the Q segment: softmax scale * log2(e) (attention.hip works in the log2 domain)
   // split-K (0/1 = off).  ws must hold splitk*M*N floats.
   int splitk = 1; float* ws = nullptr;
   // fused GroupNorm statistics of the output: gn_stats[(m / rows_per_batch)][gn_groups][2] += {sum, sum of squares}
@@ -51,7 +52,7 @@ struct AttnArgs {
   const bf16_t* Q = nullptr; const bf16_t* K = nullptr; const bf16_t* Vt = nullptr; bf16_t* O = nullptr;
   int B = 0, H = 0, nq = 0, nkv = 0, nq_pad = 0, nkv_pad = 0, dp = 0, dpv = 0;
   int ldo = 0;          // row stride of O in elements (>= H*dp)
-  float scale = 1.f;
+  float scale = 1.f;    // informative only: Q must arrive pre-multiplied by scale * log2(e) (GemmArgs::qscale)
   int causal = 0;
   int kv_bstride_zero = 0;  // 1: K/Vt have a single batch entry shared by every b (learned queries etc.)
 };
@@ -117,7 +118,7 @@ int scatter_rows_bf16_launch(const bf16_t* src, int rows, int cols, const int32_
 
 int permute_f32_launch(const float* src, const int32_t* idx, int n, float* dst, hipStream_t s);
 int pack_heads_launch(const bf16_t* src, int B, int n, int H, int d, int n_pad, int dp, int dpv, int mode, bf16_t* dst,
-                      hipStream_t s);
+                      hipStream_t s, float mul = 1.f);
 int unpad_heads_launch(const bf16_t* src, int64_t rows, int H, int d, int dp, bf16_t* dst, hipStream_t s);
 
 // padded head dim used by the attention kernel for a true head dim d (0 = unsupported)

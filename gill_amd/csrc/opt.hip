@@ -168,6 +168,7 @@ struct OptRun {
         g.out_mode = OUT_QKV; g.Cq = m->q; g.Ck = m->k; g.Cvt = m->vt;
         g.heads = c.num_heads; g.dp = m->dp; g.dpv = m->dpv; g.ntok = T; g.ntok_pad_q = Tpad; g.ntok_pad_kv = Tpad;
         g.seg_base = 0;
+        g.qscale = 1.4426950408889634f / sqrtf((float)m->dp);   // HF scales q by head_dim^-0.5
         g.splitk = gemm_pick_splitk(R, 3 * D, D, 0);
         if ((size_t)g.splitk * R * 3 * D > m->splitk_ws_floats) g.splitk = 1;
         g.ws = m->splitk_ws;

@@ -533,6 +533,7 @@ struct UNetRun {
       g.M = M; g.N = 3 * hdp; g.K = C; g.K1 = C; g.A = ln; g.lda = C; g.W = w.wqkv1;
       g.out_mode = OUT_QKV; g.Cq = q; g.Ck = k; g.Cvt = vt; g.heads = nh; g.dp = w.dp; g.dpv = w.dpv;
       g.ntok = HW; g.ntok_pad_q = hw_pad; g.ntok_pad_kv = hw_pad; g.seg_base = 0;
+      g.qscale = 1.4426950408889634f / sqrtf((float)w.d);
       GILL_TRY(gemm(g));
     }
     GILL_TRY(attend(q, k, vt, o, HW, HW, hw_pad, hw_pad, w));
@@ -544,6 +545,7 @@ struct UNetRun {
       g.M = M; g.N = hdp; g.K = C; g.K1 = C; g.A = ln; g.lda = C; g.W = w.wq2;
       g.out_mode = OUT_QKV; g.Cq = q; g.Ck = k; g.Cvt = vt; g.heads = nh; g.dp = w.dp; g.dpv = w.dpv;
       g.ntok = HW; g.ntok_pad_q = hw_pad; g.ntok_pad_kv = hw_pad; g.seg_base = 0;
+      g.qscale = 1.4426950408889634f / sqrtf((float)w.d);
       GILL_TRY(gemm(g));
     }
     GILL_TRY(attend(q, m->kcache[w.layer_id], m->vcache[w.layer_id], o, HW, m->cfg.ctx_len, hw_pad, m->ctx_pad, w));
