@@ -81,8 +81,10 @@ def build_model(dev, opt_cfg, unet_cfg, max_prompts):
   opt_sd = gpu_state_dict(lambda c, meta: shapes_of("opt_state_dict", c), opt_cfg, dev, 0)
   unet_sd = gpu_state_dict(lambda c, meta: shapes_of("unet_state_dict", c), unet_cfg, dev, 1)
   uncond = synth.uncond_context(unet_cfg.ctx_len, unet_cfg.cross_attention_dim, 0)
-  pipe = GillSDPipeline(unet_sd, unet_cfg, uncond, dev, max_batch=2 * min(8, max_prompts))
-  del unet_sd
+  vae_cfg = synth.VAEConfig.sd15()
+  vae_sd = gpu_state_dict(lambda c, meta: shapes_of("vae_decoder_state_dict", c), vae_cfg, dev, 3)
+  pipe = GillSDPipeline(unet_sd, unet_cfg, uncond, dev, max_batch=2 * min(8, max_prompts), vae_state=vae_sd, vae_cfg=vae_cfg)
+  del unet_sd, vae_sd
   name = "facebook/opt-6.7b" if opt_cfg.hidden_size == 4096 else "facebook/opt-125m"
   args = SimpleNamespace(freeze_lm=True, freeze_vm=True, opt_version=name, visual_encoder="openai/clip-vit-large-patch14",
                          n_visual_tokens=4, ret_emb_dim=256, gen_emb_dim=768, text_emb_layers=[-1], text_fc_mode="gill_mapper",
@@ -163,18 +165,31 @@ def main():
     return out
   g.sd_pipe.__class__.__call__ = timed_call
 
-  def step():
-    return g.generate_images(ids, num_inference_steps=a.infer_steps, guidance_scale=7.5, latents=lat0)
+  vae_ev = []
+  orig_dec = g.sd_pipe.__class__.decode_latents
+
+  def timed_dec(self, *args, **kw):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    o = orig_dec(self, *args, **kw)
+    e1.record()
+    vae_ev.append((e0, e1))
+    return o
+  g.sd_pipe.__class__.decode_latents = timed_dec
+
+  def step():   # prompts -> OPT -> mapper -> 51 UNet calls -> latents (all-gathered) -> VAE decode -> uint8 512x512 images
+    return g.generate_images(ids, num_inference_steps=a.infer_steps, guidance_scale=7.5, latents=lat0, decode=True)
 
   for _ in range(a.warmup):
     step()
   ev["t"].clear()
+  vae_ev.clear()
   if world > 1:
     dist.barrier()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   for _ in range(a.steps):
-    out = step()
+    out, images = step()
   if world > 1:
     dist.barrier()
   torch.cuda.synchronize()
@@ -184,11 +199,13 @@ def main():
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
   assert out.shape == (P * world, 4, unet_cfg.sample_size, unet_cfg.sample_size) and bool(torch.isfinite(out).all())
+  assert images.shape == (P, 512, 512, 3) and images.dtype == torch.uint8
 
   if rank == 0:
     images = P * world * a.steps
     value = images / dt
     unet_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev["t"]) / max(1, len(ev["t"]))   # per sd_pipe call (P prompts)
+    vae_ms = sum(e0.elapsed_time(e1) for e0, e1 in vae_ev) / max(1, len(vae_ev))
     flop_per_call = UNET_TFLOP_PER_SAMPLE_FORWARD * 2 * (a.infer_steps + 1) * P
     achieved = flop_per_call / (unet_ms * 1e-3)
     rec = {
@@ -198,7 +215,7 @@ def main():
       "config": {"workload": f"{'opt-125m' if a.small else 'opt-6.7b'} + GILLMapper + SD-1.5 UNet (random-init weights of the "
                              f"exact shapes), {P} prompts/GPU x {world} GPU, prompt {a.prompt_len}+8 [IMG] tokens, "
                              f"{a.infer_steps} PLMS steps ({a.infer_steps + 1} UNet calls, CFG 7.5, batch {2 * P}), final latents "
-                             f"all-gathered; VAE decode not included", "parallelism": f"dp{world}"},
+                             f"all-gathered, then VAE decode of the local shard to uint8 512x512 ({vae_ms:.1f} ms per {P} images)", "parallelism": f"dp{world}"},
       "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                    "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
                    "kernel": "SD-1.5 UNet denoise loop (gill_sd_denoise: MFMA GEMM/implicit-conv + flash attention kernels)",

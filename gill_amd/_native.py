@@ -42,6 +42,12 @@ class gill_unet_config(C.Structure):
               ("max_batch", C.c_int32)]
 
 
+class gill_vae_config(C.Structure):
+  _fields_ = [("latent_channels", C.c_int32), ("out_channels", C.c_int32), ("block_out_channels", C.c_int32 * 4),
+              ("layers_per_block", C.c_int32), ("norm_num_groups", C.c_int32), ("latent_size", C.c_int32),
+              ("scaling_factor", C.c_float), ("max_batch", C.c_int32)]
+
+
 # every symbol include/gill_amd.h declares: (restype, argtypes)
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 SYMBOLS: Dict[str, Tuple[object, List[object]]] = {
@@ -60,6 +66,9 @@ SYMBOLS: Dict[str, Tuple[object, List[object]]] = {
   "gill_unet_destroy": (None, [_vp]),
   "gill_unet_forward": (_i, [_vp, _vp, C.POINTER(C.c_float), _vp, _i, _vp, _vp]),
   "gill_sd_denoise": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
+  "gill_vae_create": (_i, [C.POINTER(_vp), C.POINTER(gill_vae_config), C.POINTER(gill_tensor), _i]),
+  "gill_vae_destroy": (None, [_vp]),
+  "gill_vae_decode": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
   "gill_pndm_schedule": (_i, [_i, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
   "gill_op_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _i, _vp]),
   "gill_op_geglu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -13,7 +13,7 @@ New here (NOT in the reference): GILL.generate_images
 per-prompt semantics are the 'gen' branch of generate_for_images_and_texts([p], num_words=2, gen_scale_factor=1e5).
 
 Out of scope of this build (raise NotImplementedError): image prompts / CLIP vision tower, captioning and
-retrieval modes, the retrieval + decision + CLIP-rerank branches, VAE decode.
+retrieval modes, the retrieval + decision + CLIP-rerank branches.
 """
 from __future__ import annotations
 
@@ -491,8 +491,9 @@ class GILL(nn.Module):
             for i in range(0, self.num_gen_images, gen_max_bs):
               gen_images.extend(
                 self.sd_pipe(prompt_embeds=gen_emb[i:i + gen_max_bs], generator=generator, guidance_scale=guidance_scale,
-                             num_inference_steps=num_inference_steps).images)
-            # VAE decode is not built yet: `gen_images` holds final latents (4,64,64) instead of PIL images
+                             num_inference_steps=num_inference_steps,
+                             output_type="pil" if getattr(self.sd_pipe, "_vae", None) else "latent").images)
+            # PIL images when the pipeline holds VAE weights (reference behaviour), else the final latents (4,64,64)
             image_outputs['gen'] = [(gen_images[0], 0)]
           else:
             image_outputs['gen'] = [gen_emb]
@@ -507,14 +508,16 @@ class GILL(nn.Module):
   @torch.no_grad()
   def generate_images(self, prompts, num_inference_steps: int = 50, guidance_scale: float = 7.5,
                       latents: Optional[Tensor] = None, seed: int = 1337, return_latents: bool = True,
-                      return_embeddings: bool = False, distributed: bool = True):
+                      return_embeddings: bool = False, distributed: bool = True, decode: bool = False):
     """Batched text -> image latents.  `prompts` is a list of strings (tokenized here) or an int64 tensor
     (B,T) of prompt token ids WITHOUT the [IMG] tokens (right-padded with pad_token_id).  Per prompt this equals the
     'gen' branch of generate_for_images_and_texts([p], num_words=2, gen_scale_factor=1e5): the 8 [IMG] ids are
     appended, one OPT pass yields their hidden states (models.py:384), the GILLMapper maps them to the (77,768)
     SD conditioning (models.py:387/710) and the SD-1.5 UNet runs the CFG/PLMS loop (custom_sd.py:607-651).
     With torch.distributed initialised (one process per GPU, RCCL) the prompts are sharded contiguously over
-    ranks and the final latents are all-gathered (the only collective of the path)."""
+    ranks and the final latents are all-gathered (the only collective of the path).  decode=True additionally runs
+    the VAE decoder (custom_sd.py:385-392) on THIS rank's shard and returns (latents_all, images_local) with
+    images_local (B_local,512,512,3) uint8 on the device; decoded pixels are never exchanged between ranks."""
     from . import parallel
     dev = self.model.logit_scale.device
     ids, lens = self._prompt_ids(prompts)
@@ -549,9 +552,16 @@ class GILL(nn.Module):
           outs.append(self.sd_pipe(prompt_embeds=embs[i:i + 8], latents=lat0[i:i + 8], guidance_scale=guidance_scale,
                                    num_inference_steps=num_inference_steps, output_type="latent").images)
         local = torch.cat(outs, 0)
+    images = None
+    if decode:
+      if not self.load_sd:
+        raise ValueError('decode=True needs load_sd=True')
+      images = self.sd_pipe.decode_latents(local, as_uint8=True) if local is not None else None
     if not self.load_sd:
       return parallel.gather_rows(embs, B_total, distributed) if embs is not None else None
     out = parallel.gather_rows(local, B_total, distributed)
+    if decode:
+      return out, images
     if return_embeddings:
       return out, parallel.gather_rows(embs.float(), B_total, distributed)
     return out

@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Union
 import torch
 
 from . import _native as N
-from .synth import UNetConfig
+from .synth import UNetConfig, VAEConfig
 
 
 @dataclass
@@ -33,7 +33,8 @@ class PipelineOutput:
 
 class GillSDPipeline:
   def __init__(self, unet_state: Dict[str, torch.Tensor], cfg: UNetConfig, uncond_embeds: torch.Tensor,
-               device: Union[str, torch.device] = "cuda", max_batch: int = 16):
+               device: Union[str, torch.device] = "cuda", max_batch: int = 16,
+               vae_state: Optional[Dict[str, torch.Tensor]] = None, vae_cfg: Optional[VAEConfig] = None):
     self.cfg = cfg
     self.device = torch.device(device if str(device) != "cuda" else "cuda:0")
     if self.device.type != "cuda":
@@ -52,6 +53,45 @@ class GillSDPipeline:
       N.check(N.lib().gill_unet_create(C.byref(h), C.byref(ccfg), arr, len(unet_state)))
     del keep
     self._h = h
+    self._vae = None
+    self.vae_cfg = None
+    if vae_state is not None:
+      self.load_vae(vae_state, vae_cfg or VAEConfig(latent_size=cfg.sample_size))
+
+  def load_vae(self, vae_state: Dict[str, torch.Tensor], vae_cfg: VAEConfig) -> None:
+    """AutoencoderKL decoder half (state-dict keys post_quant_conv.* / decoder.*) -> gill_vae handle."""
+    v = N.gill_vae_config(latent_channels=vae_cfg.latent_channels, out_channels=vae_cfg.out_channels,
+                          layers_per_block=vae_cfg.layers_per_block, norm_num_groups=vae_cfg.norm_num_groups,
+                          latent_size=vae_cfg.latent_size, scaling_factor=vae_cfg.scaling_factor,
+                          max_batch=max(1, self.max_batch // 2))
+    for i in range(4):
+      v.block_out_channels[i] = vae_cfg.block_out_channels[i]
+    dec = {k: t for k, t in vae_state.items() if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
+    arr, keep = N.make_tensor_table(dec, self.device)
+    h = C.c_void_p()
+    with torch.cuda.device(self.device):
+      N.check(N.lib().gill_vae_create(C.byref(h), C.byref(v), arr, len(dec)))
+    del keep
+    self._vae, self.vae_cfg = h, vae_cfg
+
+  def decode_latents(self, latents: torch.Tensor, as_uint8: bool = True, both: bool = False):
+    """custom_sd.py:385-392 (+ numpy_to_pil's uint8 step): latents (B,4,L,L) -> (B,8L,8L,3) uint8, or with
+    as_uint8=False the raw decoder output vae.decode(latents / 0.18215).sample (B,3,8L,8L) fp32; both=True returns
+    (fp32, uint8) of the same decode."""
+    if self._vae is None:
+      raise N.GillNativeError("this pipeline was built without VAE weights (pass vae_state= / use from_pretrained)")
+    lat = latents.to(self.device, torch.float32).contiguous()
+    B, side = lat.shape[0], 8 * self.vae_cfg.latent_size
+    ch = self.vae_cfg.out_channels
+    f32 = torch.empty((B, ch, side, side), device=self.device, dtype=torch.float32) if (both or not as_uint8) else None
+    u8 = torch.empty((B, side, side, ch), device=self.device, dtype=torch.uint8) if (both or as_uint8) else None
+    cap = max(1, self.max_batch // 2)
+    with torch.cuda.device(self.device):
+      for i in range(0, B, cap):
+        b = min(cap, B - i)
+        N.check(N.lib().gill_vae_decode(self._vae, N.ptr(lat[i:i + b]), b, None if f32 is None else N.ptr(f32[i:i + b]),
+                                        None if u8 is None else N.ptr(u8[i:i + b]), N.current_stream()))
+    return (f32, u8) if both else (u8 if as_uint8 else f32)
 
   # ---- construction from a local diffusers directory (no diffusers import: safetensors + json only)
   @classmethod
@@ -75,7 +115,16 @@ class GillSDPipeline:
       with torch.no_grad():
         ids = tok([""], padding="max_length", max_length=tok.model_max_length, return_tensors="pt").input_ids
         uncond_embeds = enc(ids)[0]
-    return cls(sd, cfg, uncond_embeds, device, max_batch)
+    vae_sd, vae_cfg = None, None
+    vdir = os.path.join(model_dir, "vae")
+    if os.path.exists(os.path.join(vdir, "diffusion_pytorch_model.safetensors")):
+      with open(os.path.join(vdir, "config.json")) as f:
+        vc = json.load(f)
+      vae_cfg = VAEConfig(latent_channels=vc["latent_channels"], out_channels=vc["out_channels"],
+                          block_out_channels=tuple(vc["block_out_channels"]), layers_per_block=vc["layers_per_block"],
+                          norm_num_groups=vc["norm_num_groups"], latent_size=cfg.sample_size)   # scaling 0.18215: custom_sd.py:387
+      vae_sd = load_file(os.path.join(vdir, "diffusion_pytorch_model.safetensors"))
+    return cls(sd, cfg, uncond_embeds, device, max_batch, vae_state=vae_sd, vae_cfg=vae_cfg)
 
   def to(self, device):   # the reference chains .to("cuda")
     assert torch.device(device).type == "cuda"
@@ -86,6 +135,9 @@ class GillSDPipeline:
       if getattr(self, "_h", None):
         N.lib().gill_unet_destroy(self._h)
         self._h = None
+      if getattr(self, "_vae", None):
+        N.lib().gill_vae_destroy(self._vae)
+        self._vae = None
     except Exception:
       pass
 
@@ -134,9 +186,10 @@ class GillSDPipeline:
     L = self.cfg.sample_size
     if (height is not None and height != L * 8) or (width is not None and width != L * 8):
       raise ValueError(f"this handle was built for {L * 8}x{L * 8} images")
-    if output_type not in ("latent",):
-      raise NotImplementedError("VAE decode / PIL output is the next component to build (SURVEY.md section 8f rank 1); "
-                                "call with output_type='latent'")
+    if output_type not in ("latent", "pil", "np", "pt"):
+      raise ValueError(f"unknown output_type {output_type!r}")
+    if output_type != "latent" and self._vae is None:
+      raise N.GillNativeError("output_type != 'latent' needs the VAE decoder weights (vae_state= / from_pretrained)")
     cond = prompt_embeds.to(self.device, torch.bfloat16)
     if num_images_per_prompt != 1:
       cond = cond.repeat_interleave(num_images_per_prompt, dim=0)
@@ -149,6 +202,14 @@ class GillSDPipeline:
     with torch.cuda.device(self.device):
       N.check(N.lib().gill_sd_denoise(self._h, N.ptr(cond), N.ptr(uncond), N.ptr(lat0), B, int(num_inference_steps),
                                       float(guidance_scale), N.ptr(out), N.current_stream()))
+    if output_type == "pil":      # custom_sd.py:654-661 (the safety checker is not part of this path)
+      from PIL import Image
+      u8 = self.decode_latents(out, as_uint8=True).cpu().numpy()
+      out = [Image.fromarray(im) for im in u8]
+    elif output_type == "np":
+      out = self.decode_latents(out, as_uint8=True).cpu().numpy().astype("float32") / 255.0
+    elif output_type == "pt":
+      out = self.decode_latents(out, as_uint8=False)
     if not return_dict:
       return (out, None)
     return PipelineOutput(images=out)

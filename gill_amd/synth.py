@@ -229,6 +229,65 @@ def unet_state_dict(cfg: UNetConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
   return sd
 
 
+# ---------------------------------------------------------------------------------------------- SD VAE (decoder half)
+@dataclass
+class VAEConfig:
+  latent_channels: int = 4
+  out_channels: int = 3
+  block_out_channels: Tuple[int, int, int, int] = (128, 256, 512, 512)
+  layers_per_block: int = 2
+  norm_num_groups: int = 32
+  latent_size: int = 64
+  scaling_factor: float = 0.18215
+
+  @staticmethod
+  def sd15():
+    return VAEConfig()
+
+  @staticmethod
+  def tiny(latent_size=16):
+    return VAEConfig(block_out_channels=(64, 64, 128, 128), latent_size=latent_size)
+
+
+def vae_decoder_state_dict(cfg: VAEConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+  """diffusers AutoencoderKL keys needed by decode(): post_quant_conv.* and decoder.*"""
+  sd: Dict[str, torch.Tensor] = {}
+  ch = cfg.block_out_channels
+
+  def conv(p, cout, cin, k=3):
+    sd[p + ".weight"] = _matrix(p + ".weight", (cout, cin, k, k), seed)
+    sd[p + ".bias"] = _bias(p + ".bias", cout, seed)
+
+  def resnet(p, cin, cout):
+    _norm(sd, p + ".norm1", cin, seed)
+    conv(p + ".conv1", cout, cin)
+    _norm(sd, p + ".norm2", cout, seed)
+    conv(p + ".conv2", cout, cout)
+    if cin != cout:
+      conv(p + ".conv_shortcut", cout, cin, 1)
+
+  conv("post_quant_conv", cfg.latent_channels, cfg.latent_channels, 1)
+  top = ch[3]
+  conv("decoder.conv_in", top, cfg.latent_channels)
+  resnet("decoder.mid_block.resnets.0", top, top)
+  a = "decoder.mid_block.attentions.0"
+  _norm(sd, a + ".group_norm", top, seed)
+  for n in ("to_q", "to_k", "to_v", "to_out.0"):
+    _linear(sd, f"{a}.{n}", top, top, seed)
+  resnet("decoder.mid_block.resnets.1", top, top)
+  prev = top
+  for i in range(4):
+    outc = ch[3 - i]
+    for j in range(3):
+      resnet(f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else outc, outc)
+    if i < 3:
+      conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", outc, outc)
+    prev = outc
+  _norm(sd, "decoder.conv_norm_out", ch[0], seed)
+  conv("decoder.conv_out", cfg.out_channels, ch[0])
+  return sd
+
+
 # ---------------------------------------------------------------------------------------------- inputs
 IMG_TOKEN_IDS = list(range(50266, 50274))  # checkpoints/gill_opt/model_args.json:19-36
 

@@ -139,6 +139,30 @@ int gill_unet_forward(gill_unet* h, const float* sample, const float* timesteps_
 int gill_sd_denoise(gill_unet* h, const void* cond_bf16, const void* uncond_bf16, const float* latents0, int B,
                     int num_steps, float guidance, float* latents_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Stage 3b — VAE decode of the final latents.  Replaces StableDiffusionPipeline.decode_latents
+ * (gill/custom_sd.py:385-392: latents / 0.18215 -> vae.decode -> (x/2+0.5).clamp(0,1)) and the uint8 conversion
+ * of numpy_to_pil (custom_sd.py:660-661).  State-dict names are diffusers AutoencoderKL's
+ * ("post_quant_conv.weight", "decoder.up_blocks.2.resnets.0.conv1.weight", ...).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gill_vae gill_vae;
+typedef struct {
+  int32_t latent_channels;       /* 4 */
+  int32_t out_channels;          /* 3 */
+  int32_t block_out_channels[4]; /* 128,256,512,512 */
+  int32_t layers_per_block;      /* 2 */
+  int32_t norm_num_groups;       /* 32 */
+  int32_t latent_size;           /* 64 -> 512x512 pixels */
+  float scaling_factor;          /* 0.18215 (hard-coded at custom_sd.py:387) */
+  int32_t max_batch;
+} gill_vae_config;
+
+int gill_vae_create(gill_vae** out, const gill_vae_config* cfg, const gill_tensor* weights, int n_weights);
+void gill_vae_destroy(gill_vae* h);
+/* latents (B,4,L,L) fp32 -> image_f32 (B,3,8L,8L) fp32 in [-1,1] (vae.decode(...).sample; may be NULL) and/or
+ * image_u8 (B,8L,8L,3) uint8 = round(255 * clamp(x/2+0.5, 0, 1)) (may be NULL). */
+int gill_vae_decode(gill_vae* h, const float* latents, int B, float* image_f32, uint8_t* image_u8, void* stream);
+
 /* PNDM schedule known-answers for tests (host arrays): timesteps_out must hold num_steps+1 ints;
  * returns the number written.  alphas_cumprod_out (optional) must hold 1000 doubles. */
 int gill_pndm_schedule(int num_steps, int32_t* timesteps_out, double* alphas_cumprod_out);

@@ -199,3 +199,63 @@ def test_generate_images_end_to_end_tiny(cuda):
   ref = pipeline_ref.sd_embedding(osd, msd, 12, 12, full, torch.full((4,), full.shape[1] - 1))
   mse, _, _ = _stats("generate_images SD embedding (B=4)", embs, ref)
   assert embs.shape == (4, 77, 768) and mse < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ stage 3b (VAE decode)
+def test_vae_decode_tiny_vs_oracle(cuda):
+  """custom_sd.py:385-392 + numpy_to_pil: latents -> vae.decode(latents / 0.18215).sample -> uint8 HWC."""
+  from oracle import vae_ref
+  cfg, sd, uncond, pipe = _tiny_pipe(cuda)
+  vcfg = synth.VAEConfig.tiny(16)
+  vsd = _bfw(synth.vae_decoder_state_dict(vcfg, seed=5))
+  pipe.load_vae(vsd, vcfg)
+  B = 3
+  lat = synth.initial_latents(B, 4, 16, seed=77) * 0.18215 * 3.0   # decoder input of a few units, as real latents are
+  ref = vae_ref.vae_decode(vsd, lat, vcfg.block_out_channels, vcfg.norm_num_groups, vcfg.scaling_factor)
+  got = pipe.decode_latents(lat, as_uint8=False)
+  assert got.shape == ref.shape == (B, 3, 128, 128)
+  mse, rel, cos = _stats("vae decode tiny", got, ref)
+  assert rel < 4e-2 and cos > 0.999
+  f32, u8 = pipe.decode_latents(lat, both=True)
+  u8 = u8.cpu()
+  assert u8.shape == (B, 128, 128, 3) and u8.dtype == torch.uint8
+  # the uint8 conversion is exact on the fp32 output of the same decode (two decodes differ in the last fp32 bits:
+  # the fused GroupNorm statistics are accumulated with float atomics)...
+  assert torch.equal(u8, vae_ref.to_uint8(f32.cpu()))
+  # ...and within a few grey levels of the fp32 oracle's image
+  d = (u8.int() - vae_ref.to_uint8(ref).int()).abs()
+  print(f"[vae uint8] max level diff {d.max().item()}, mean {d.float().mean().item():.3f}")
+  assert d.float().mean().item() < 1.5
+  # output_type plumbing of the pipeline object
+  cond = synth.normal("dn_cond", (1, 77, cfg.cross_attention_dim), 4).bfloat16().float()
+  ims = pipe(prompt_embeds=cond, latents=lat[:1], guidance_scale=7.5, num_inference_steps=3, output_type="pil").images
+  assert len(ims) == 1 and ims[0].size == (128, 128)
+  arr = pipe(prompt_embeds=cond, latents=lat[:1], guidance_scale=7.5, num_inference_steps=3, output_type="np").images
+  assert arr.shape == (1, 128, 128, 3) and 0.0 <= arr.min() and arr.max() <= 1.0
+  # run-to-run: the fused GroupNorm statistics use float atomics, so two runs differ by bf16 rounding flips (the same
+  # size as the bf16-vs-fp32 distance); a random-weight tiny UNet amplifies them over the recurrent steps
+  dd = np.abs((arr[0] * 255).round().astype(np.int32) - np.asarray(ims[0]).astype(np.int32))
+  print(f"[denoise+decode run-to-run] max level diff {dd.max()}, mean {dd.mean():.4f}")
+  assert dd.mean() < 8.0
+  u8b = pipe.decode_latents(lat, as_uint8=True).cpu()
+  d2 = (u8b.int() - u8.int()).abs()
+  print(f"[decode run-to-run] max level diff {d2.max().item()}, mean {d2.float().mean().item():.4f}")
+  assert d2.float().mean().item() < 0.5
+
+
+@pytest.mark.skipif(os.environ.get("GILL_SKIP_SLOW") == "1", reason="slow CPU oracle")
+def test_vae_decode_sd15_vs_oracle(cuda):
+  """Full SD-1.5 decoder geometry (64x64 latents -> 512x512), batch 1, against the fp32 oracle."""
+  from oracle import vae_ref
+  from gill_amd.sd import GillSDPipeline
+  ucfg = synth.UNetConfig.tiny(64)
+  pipe = GillSDPipeline(_bfw(synth.unet_state_dict(ucfg, seed=3)), ucfg,
+                        synth.uncond_context(ucfg.ctx_len, ucfg.cross_attention_dim, seed=3), cuda, max_batch=2)
+  vcfg = synth.VAEConfig.sd15()
+  vsd = _bfw(synth.vae_decoder_state_dict(vcfg, seed=6))
+  pipe.load_vae(vsd, vcfg)
+  lat = synth.initial_latents(1, 4, 64, seed=78) * 0.18215 * 3.0
+  ref = vae_ref.vae_decode(vsd, lat, vcfg.block_out_channels, vcfg.norm_num_groups, vcfg.scaling_factor)
+  got = pipe.decode_latents(lat, as_uint8=False)
+  mse, rel, cos = _stats("vae decode sd1.5", got, ref)
+  assert rel < 4e-2 and cos > 0.999
