@@ -8,6 +8,7 @@ under gill_amd/ does.  It restates, in plain fp32 torch-CPU ops, the algorithm t
   stage 3  oracle.unet_ref     diffusers UNet2DConditionModel (SD-1.5 config) — NOT in the reference tree
            oracle.scheduler_ref  diffusers PNDMScheduler (skip_prk_steps) — NOT in the reference tree
            oracle.pipeline_ref   the driver loop gill/custom_sd.py:607-651 and the glue gill/models.py:164-441
+           oracle.vae_ref        diffusers AutoencoderKL.decode + uint8 conversion (custom_sd.py:385-392) — NOT in the tree
 
 Pinning status
   * stages 1-2 are PINNED: tests/golden/*.npz hold outputs of the reference's own code
@@ -16,6 +17,6 @@ Pinning status
     restatement against them.
   * stage 3 is PARITY UNPINNED: diffusers==0.17.1 is a pinned, un-vendored dependency (requirements.txt:9)
     that is not installed here and cannot be fetched; the reference holds no test or golden vector for it.
-    unet_ref / scheduler_ref restate the published SD-1.5 UNet2DConditionModel / PNDMScheduler algorithm and
+    unet_ref / scheduler_ref / vae_ref restate the published SD-1.5 UNet2DConditionModel / PNDMScheduler / AutoencoderKL decoder algorithm and
     are anchored on the reference's call sites (gill/custom_sd.py:567-651, gill/models.py:724-731).
 """
