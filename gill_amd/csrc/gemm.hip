@@ -27,14 +27,17 @@
 #define BK 64
 #define GEMM_THREADS 256
 
-__device__ __attribute__((aligned(256))) uint32_t g_zero_page_storage[128];
+// zeros read by padding taps; a row's pointer advances 128 B per K step within a (tap, source) segment, so the page
+// covers the longest segment (ZERO_PAGE_STEPS K steps) plus one 128-B row
+#define ZERO_PAGE_STEPS 127
+__device__ __attribute__((aligned(256))) uint32_t g_zero_page_storage[(ZERO_PAGE_STEPS + 1) * 32];
 
 const bf16_t* gill_zero_page() {
   static const bf16_t* p = nullptr;
   if (!p) {
     void* d = nullptr;
     if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_zero_page_storage)) == hipSuccess) {
-      (void)hipMemset(d, 0, sizeof(uint32_t) * 128);
+      (void)hipMemset(d, 0, sizeof(g_zero_page_storage));
       p = (const bf16_t*)d;
     }
   }
@@ -196,25 +199,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
     int row = (i * 4 + w) * 8 + srow;
     int n = n0 + row;
     if (n > p.N - 1) n = p.N - 1;
-    w_ptr[i] = p.W + (size_t)n * p.K + schunk * 8;
+    w_ptr[i] = p.W + (size_t)n * p.K + schunk * 8 + kt_beg * BK;
   }
   const bf16_t* zero_lane = d.zero + schunk * 8;
 
-  auto issue = [&](int kt, int buf) {
-    const int k0 = kt * BK;
-    bf16_t* As = smem + buf * BUF_ELEMS;
-    bf16_t* Bs = As + A_ELEMS;
+  // ---- K-step addressing is incremental: K is walked in (tap, source) segments inside which every row pointer just
+  // advances by 64 elements; seg_setup() (wave-uniform control flow, once per segment) recomputes the 4 A row pointers
+  const bf16_t* a_ptr[4];
+  int seg_left = 0;
+  auto seg_setup = [&](int k0) {
     if constexpr (CONV == 0) {
       const bool first = (k0 < p.K1);
       const bf16_t* src = first ? p.A : p.A2;
       const int kk = first ? k0 : k0 - p.K1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bf16_t* g = src + (first ? a_off1[i] : a_off2[i]) + kk;
-        bf16_t* l = As + (i * 4 + w) * 8 * BK;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-      }
+      for (int i = 0; i < 4; ++i) a_ptr[i] = src + (first ? a_off1[i] : a_off2[i]) + kk;
+      seg_left = ((first ? p.K1 : p.K) - k0) / BK;
     } else {
       if (CONV == 1 && k0 >= 9 * p.Cin) {
         // fused 1x1 "conv_shortcut" segment: K continues over the channels of the raw block input X1 (++ X2) at the
@@ -225,48 +225,57 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
         const int cx = fx ? p.KX1 : (p.KX - p.KX1);
         const int kc = (fx ? ke : ke - p.KX1) + schunk * 8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bf16_t* g = xs + (size_t)a_pc[i] * cx + kc;
-          bf16_t* l = As + (i * 4 + w) * 8 * BK;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                           (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i) a_ptr[i] = xs + (size_t)a_pc[i] * cx + kc;
+        seg_left = ((fx ? p.KX1 : p.KX) - ke) / BK;
       } else {
-      // all wave-uniform: tap, source tensor, channel offset, tap displacement
-      const int tap = k0 / p.Cin;
-      const int c0 = k0 - tap * p.Cin;
-      const int ty = tap / 3;
-      const int dy = ty - 1, dx = tap - ty * 3 - 1;
-      const int need = (dy < 0 ? 1 : (dy > 0 ? 2 : 0)) | (dx < 0 ? 4 : (dx > 0 ? 8 : 0));
-      const bool first = (c0 < p.K1);
-      const bf16_t* src = first ? p.A : p.A2;
-      const int cs = first ? p.K1 : (p.Cin - p.K1);
-      const int cc = first ? c0 : c0 - p.K1;
-      const int delta = (dy * p.IW + dx) * cs + cc;   // used when CONV == 1
+        // all wave-uniform: tap, source tensor, channel offset, tap displacement
+        const int tap = k0 / p.Cin;
+        const int c0 = k0 - tap * p.Cin;
+        const int ty = tap / 3;
+        const int dy = ty - 1, dx = tap - ty * 3 - 1;
+        const int need = (dy < 0 ? 1 : (dy > 0 ? 2 : 0)) | (dx < 0 ? 4 : (dx > 0 ? 8 : 0));
+        const bool first = (c0 < p.K1);
+        const bf16_t* src = first ? p.A : p.A2;
+        const int cs = first ? p.K1 : (p.Cin - p.K1);
+        const int cc = first ? c0 : c0 - p.K1;
+        const int delta = (dy * p.IW + dx) * cs + cc;   // used when CONV == 1
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int off = (first ? a_off1[i] : a_off2[i]);
-        if constexpr (CONV == 2) {
-          const int ddy = (dy + ((a_fl[i] >> 4) & 1)) >> 1, ddx = (dx + ((a_fl[i] >> 5) & 1)) >> 1;
-          off += (ddy * p.IW + ddx) * cs + cc;
-        } else {
-          off += delta;
+        for (int i = 0; i < 4; ++i) {
+          int off = (first ? a_off1[i] : a_off2[i]);
+          if constexpr (CONV == 2) {
+            const int ddy = (dy + ((a_fl[i] >> 4) & 1)) >> 1, ddx = (dx + ((a_fl[i] >> 5) & 1)) >> 1;
+            off += (ddy * p.IW + ddx) * cs + cc;
+          } else {
+            off += delta;
+          }
+          const bool ok = (a_fl[i] & need) == need;
+          a_ptr[i] = ok ? src + off : zero_lane;
         }
-        const bool ok = (a_fl[i] & need) == need;
-        const bf16_t* g = ok ? src + off : zero_lane;
-        bf16_t* l = As + (i * 4 + w) * 8 * BK;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        seg_left = ((first ? p.K1 : p.Cin) - c0) / BK;
       }
-      }
+    }
+  };
+  int k_issue = kt_beg * BK;     // K coordinate of the next step to stage
+  auto issue = [&](int buf) {
+    if (seg_left == 0) seg_setup(k_issue);
+    --seg_left;
+    bf16_t* As = smem + buf * BUF_ELEMS;
+    bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16_t* l = As + (i * 4 + w) * 8 * BK;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[i],
+                                       (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+      a_ptr[i] += BK;
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      const bf16_t* g = w_ptr[i] + k0;
       bf16_t* l = Bs + (i * 4 + w) * 8 * BK;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
                                        (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+      w_ptr[i] += BK;
     }
+    k_issue += BK;
   };
 
   f32x4 acc[4][NT];
@@ -283,18 +292,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
   static_assert(STAGES == 2 || STAGES == 3, "ring depth");
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nsteps) issue(kt_beg + s, s);
+    if (s < nsteps) issue(s);
   int buf = 0, buf_issue = STAGES - 1;
   for (int it = 0; it < nsteps; ++it) {
     // wait for stage `it` only: with a 3-deep ring stage it+1 (the youngest LOADS instructions) stays in flight
     if (STAGES == 3 && it + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (it + STAGES - 1 < nsteps) issue(kt_beg + it + STAGES - 1, buf_issue);
     const bf16_t* As = smem + buf * BUF_ELEMS;
     const bf16_t* Bs = As + A_ELEMS;
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
-    buf_issue = (buf_issue + 1 == STAGES) ? 0 : buf_issue + 1;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[4];
@@ -310,6 +317,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
         const int row = wn * (BN / 2) + j * 16 + frow;
         const int slot = (kk * 4 + fkc) ^ (row & 7);
         bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * BK + slot * 8);
+      }
+      if (kk == 0) {
+        // stage the next tile while the first fragments are in flight from LDS (its ~30 instructions cover that latency)
+        if (it + STAGES - 1 < nsteps) issue(buf_issue);
+        buf_issue = (buf_issue + 1 == STAGES) ? 0 : buf_issue + 1;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -491,30 +503,58 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
 }
 
 // split-K reduction + epilogue
-// Block = 64 rows x 64 columns (thread: one float4 column, 4 rows), so the fused GroupNorm statistics reduce through
-// 64 LDS bins to one global atomic per (group, moment) per block, like the in-kernel epilogue.
+// Block = 16*R rows x 64 columns (thread: one float4 column, R rows), so the fused GroupNorm statistics reduce through
+// 64 LDS bins to one global atomic per (group, moment) per block, like the in-kernel epilogue.  R = 4 for large outputs,
+// R = 1 when the output is small (many splits of a short M): more workgroups to pull the partials out of HBM/L2.
+template <int R>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs p) {
   __shared__ float red[2 * 64];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int n = blockIdx.x * 64 + tx * 4;
-  const int mbase = blockIdx.y * 64;
+  const int mbase = blockIdx.y * (16 * R);
   if (p.gn_stats) {
     if (threadIdx.x < 128) red[threadIdx.x] = 0.f;
     __syncthreads();
   }
   float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
   if (n < p.N) {
+    // all partial loads of the thread's 4 rows are issued before any epilogue store (a store in between would fence the
+    // next row's loads): 4 rows x 4 splits = 16 independent 16-B loads in flight per pass
+    float4 s[R];
+    const float* src[R];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < R; ++r) {
+      int m = mbase + ty + 16 * r;
+      if (m > p.M - 1) m = p.M - 1;
+      s[r] = make_float4(0, 0, 0, 0);
+      src[r] = p.ws + (size_t)m * p.N + n;
+    }
+    const size_t zstride = (size_t)p.M * p.N;
+    int z = 0;
+    for (; z + 4 <= p.splitk; z += 4) {
+      float4 v[R][4];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[r][u] = *reinterpret_cast<const float4*>(src[r] + (size_t)(z + u) * zstride);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s[r].x += v[r][u].x; s[r].y += v[r][u].y; s[r].z += v[r][u].z; s[r].w += v[r][u].w; }
+    }
+    for (; z < p.splitk; ++z) {
+      float4 v[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) v[r] = *reinterpret_cast<const float4*>(src[r] + (size_t)z * zstride);
+#pragma unroll
+      for (int r = 0; r < R; ++r) { s[r].x += v[r].x; s[r].y += v[r].y; s[r].z += v[r].z; s[r].w += v[r].w; }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
       const int m = mbase + ty + 16 * r;
       if (m >= p.M) continue;
-      float4 s = make_float4(0, 0, 0, 0);
-      for (int z = 0; z < p.splitk; ++z) {
-        const float4 v = *reinterpret_cast<const float4*>(p.ws + ((size_t)z * p.M + m) * p.N + n);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      }
       float fin[4];
-      store4(p, m, n, s.x, s.y, s.z, s.w, fin);
+      store4(p, m, n, s[r].x, s[r].y, s[r].z, s[r].w, fin);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { gs[e] += fin[e]; gq[e] += fin[e] * fin[e]; }
     }
@@ -617,7 +657,10 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     else GILL_TRY((gemm_launch_stages<BN, 0, 0>(d, grid, stages, s)));
   }
   if (sk > 1) {
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(cdiv(a.N, 64), cdiv(a.M, 64)), dim3(256), 0, s, d.a);
+    if ((int64_t)cdiv(a.N, 64) * cdiv(a.M, 64) >= 1024)
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel<4>, dim3(cdiv(a.N, 64), cdiv(a.M, 64)), dim3(256), 0, s, d.a);
+    else
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel<1>, dim3(cdiv(a.N, 64), cdiv(a.M, 16)), dim3(256), 0, s, d.a);
     GILL_CHECK_HIP(hipGetLastError());
   }
   return 0;
@@ -637,6 +680,7 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
                    "conv: fused 1x1 segment channel counts must be multiples of 64");
     }
     GILL_REQUIRE(a.K1 % BK == 0 && a.K1 <= a.Cin, "conv: source split must be a multiple of 64");
+    GILL_REQUIRE(a.Cin / BK <= ZERO_PAGE_STEPS, "conv: Cin too large for the zero page");
     GILL_REQUIRE(a.K1 == a.Cin || a.A2 != nullptr, "conv: second source missing");
     GILL_REQUIRE(!(a.ups && a.stride != 1), "conv: upsample needs stride 1");
     GILL_REQUIRE(a.out_mode != OUT_QKV && a.act != ACT_GEGLU, "conv: row-major epilogue only");

@@ -31,6 +31,22 @@ def main():
            "| kernel | calls | total ms | % | avg us | min us | max us |", "|---|---|---|---|---|---|---|"]
   for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     lines.append(f"| `{k}` | {a[0]} | {a[1] / 1e6:.2f} | {100.0 * a[1] / total:.1f} | {a[1] / a[0] / 1e3:.1f} | {a[2] / 1e3:.1f} | {a[3] / 1e3:.1f} |")
+  # inter-kernel gaps (start[i+1] - end[i] in start order); gaps > 200 us are host pauses, not dispatch cost
+  rs = sorted(rows, key=lambda r: r[1])
+  gaps = [(rs[i + 1][1] - rs[i][2], short(rs[i][0])) for i in range(len(rs) - 1)]
+  small = [g for g, _ in gaps if 0 <= g < 200e3]
+  overl = sum(1 for g, _ in gaps if g < 0)
+  if small:
+    ss = sorted(small)
+    lines += ["", f"inter-kernel gaps < 200 us: n={len(small)}, sum {sum(small) / 1e6:.2f} ms, median {ss[len(ss) // 2] / 1e3:.2f} us, "
+                  f"p90 {ss[int(len(ss) * 0.9)] / 1e3:.2f} us, mean {sum(small) / len(small) / 1e3:.2f} us; overlapping pairs {overl}"]
+    by = {}
+    for g, n in gaps:
+      if 0 <= g < 200e3:
+        b_ = by.setdefault(n, [0, 0]); b_[0] += 1; b_[1] += g
+    lines += ["", "| gap AFTER kernel | n | mean gap us | total ms |", "|---|---|---|---|"]
+    for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])[:12]:
+      lines.append(f"| `{k}` | {v[0]} | {v[1] / v[0] / 1e3:.2f} | {v[1] / 1e6:.2f} |")
   out = "\n".join(lines) + "\n"
   if len(sys.argv) > 2:
     open(sys.argv[2], "w").write(out)

@@ -1,0 +1,323 @@
+// Micro-benchmark of the GEMM main loop structure (128x160x64 tile, 256 threads, 2-stage LDS-DMA ring).
+// Components can be switched off to find what bounds the loop.  M=32768 N=320 K=2880 (the L0 conv as a plain GEMM).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <stdlib.h>
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#define BM 128
+#define BN 160
+#define BK 64
+#define KW 320   // A is [M][KW]: the K walk wraps over it (cache behaviour of a 3x3 conv over an L2/MALL-resident input)
+__device__ __forceinline__ int xcd_tile() {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// MODE 0: 16x16x32, waves 2x2 (64x80 each).  MODE 1: 32x32x16, waves 2(M) x 2(K halves), 64x160 each.
+template <int MODE, int LOADS, int LDSR, int BARR, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_gemm(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, float* __restrict__ C,
+                                                   int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, BUF = A_ELEMS + B_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = N / BN;
+  const int tile = xcd_tile();
+  const int tn = tile % tiles_n, tm = tile / tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int srow = lane >> 3;
+  const int nsteps = K / BK;
+  const bf16_t* a_ptr[4];
+  const bf16_t* w_ptr[5];
+  for (int i = 0; i < 4; ++i) {
+    int row = (i * 4 + w) * 8 + srow;
+    int sw = MODE == 0 ? (row & 7) : ((row >> 1) & 7);
+    a_ptr[i] = A + (size_t)(m0 + row) * KW + ((lane & 7) ^ sw) * 8;
+  }
+  for (int i = 0; i < 5; ++i) {
+    int row = (i * 4 + w) * 8 + srow;
+    int sw = MODE == 0 ? (row & 7) : ((row >> 1) & 7);
+    w_ptr[i] = W + (size_t)(n0 + row) * K + ((lane & 7) ^ sw) * 8;
+  }
+  int kcol = 0;
+  auto issue = [&](int buf) {
+    if (!LOADS) return;
+    bf16_t* As = smem + buf * BUF;
+    bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[i],
+                                       (__attribute__((address_space(3))) void*)(As + (i * 4 + w) * 8 * BK), 16, 0, 0);
+      a_ptr[i] += BK;
+    }
+    if (++kcol == KW / BK) { kcol = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_ptr[i] -= KW; }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
+                                       (__attribute__((address_space(3))) void*)(Bs + (i * 4 + w) * 8 * BK), 16, 0, 0);
+      w_ptr[i] += BK;
+    }
+  };
+  const int wm = w >> 1, wn = w & 1;
+  float result = 0.f;
+  if constexpr (MODE == 0) {
+    f32x4 acc[4][5];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+    const int frow = lane & 15, fkc = lane >> 4;
+    bf16x8 af[4], bfr[5];
+    for (int i = 0; i < 4; ++i) af[i] = (bf16x8)(short)(0x3c00 + lane);
+    for (int j = 0; j < 5; ++j) bfr[j] = (bf16x8)(short)(0x3c10 + lane);
+    issue(0);
+    int buf = 0;
+    for (int it = 0; it < nsteps; ++it) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (BARR) __builtin_amdgcn_s_barrier();
+      const bf16_t* As = smem + buf * BUF;
+      const bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        if (LDSR) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = wm * 64 + i * 16 + frow;
+            af[i] = *reinterpret_cast<const bf16x8*>(As + row * BK + (((kk * 4 + fkc) ^ (row & 7)) * 8));
+          }
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const int row = wn * 80 + j * 16 + frow;
+            bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * BK + (((kk * 4 + fkc) ^ (row & 7)) * 8));
+          }
+        }
+        if (kk == 0 && it + 1 < nsteps) issue(buf ^ 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      buf ^= 1;
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) result += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  } else {
+    f32x16 acc[2][5];
+    for (int t = 0; t < 2; ++t) for (int j = 0; j < 5; ++j) for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+    const int wk = wn;
+    const int l31 = lane & 31, lh = lane >> 5;
+    bf16x8 a2[2], b5[5];
+    for (int i = 0; i < 2; ++i) a2[i] = (bf16x8)(short)(0x3c00 + lane);
+    for (int j = 0; j < 5; ++j) b5[j] = (bf16x8)(short)(0x3c10 + lane);
+    issue(0);
+    int buf = 0;
+    for (int it = 0; it < nsteps; ++it) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (BARR) __builtin_amdgcn_s_barrier();
+      const bf16_t* As = smem + buf * BUF;
+      const bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const int st = wk * 2 + ss;
+        if (LDSR) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int row = wm * 64 + t * 32 + l31;
+            a2[t] = *reinterpret_cast<const bf16x8*>(As + row * BK + (((st * 2 + lh) ^ ((row >> 1) & 7)) * 8));
+          }
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const int row = j * 32 + l31;
+            b5[j] = *reinterpret_cast<const bf16x8*>(Bs + row * BK + (((st * 2 + lh) ^ ((row >> 1) & 7)) * 8));
+          }
+        }
+        if (ss == 0 && it + 1 < nsteps) issue(buf ^ 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b5[j], a2[t], acc[t][j], 0, 0, 0);
+      }
+      buf ^= 1;
+    }
+    for (int t = 0; t < 2; ++t) for (int j = 0; j < 5; ++j) for (int r = 0; r < 16; ++r) result += acc[t][j][r];
+  }
+  C[(size_t)blockIdx.x * 256 + tid] = result;
+}
+
+
+// 8 waves: 2(M) x 2(N... none) -> wave (wm = w&1 .. ) layout: wm = (w >> 1) & 1 picks 64 rows, wk = w & 1 ... see below.
+// Config K8: block 128x160, 512 threads; waves = 2 (M halves) x 4 (k16 steps of the BK=64 stage): each wave 64x160 via 32x32x16,
+// one k16 step per stage -> 10 MFMAs + 7 ds_read_b128 per stage per wave.  STAGES-deep ring, counted vmcnt.
+template <int STAGES>
+__global__ __launch_bounds__(512, 1) void k_gemm8(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, float* __restrict__ C,
+                                                  int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, BUF = A_ELEMS + B_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = N / BN;
+  const int tile = xcd_tile();
+  const int tn = tile % tiles_n, tm = tile / tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int srow = lane >> 3;
+  const int nsteps = K / BK;
+  // A: 16 row-groups of 8 -> 2 per wave; W: 20 row-groups -> waves 0..3 take 3, waves 4..7 take 2
+  const bf16_t* a_ptr[2];
+  const bf16_t* w_ptr[3];
+  for (int i = 0; i < 2; ++i) {
+    int row = (i * 8 + w) * 8 + srow;
+    a_ptr[i] = A + (size_t)(m0 + row) * KW + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+  }
+  const int nw = w < 4 ? 3 : 2;
+  for (int i = 0; i < 3; ++i) {
+    int g = i * 8 + w; if (g > 19) g = 19;
+    int row = g * 8 + srow;
+    w_ptr[i] = W + (size_t)(n0 + row) * K + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+  }
+  int kcol = 0;
+  auto issue = [&](int buf) {
+    bf16_t* As = smem + buf * BUF;
+    bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[i],
+                                       (__attribute__((address_space(3))) void*)(As + (i * 8 + w) * 8 * BK), 16, 0, 0);
+      a_ptr[i] += BK;
+    }
+    if (++kcol == KW / BK) { kcol = 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a_ptr[i] -= KW; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i < nw) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
+                                         (__attribute__((address_space(3))) void*)(Bs + (i * 8 + w) * 8 * BK), 16, 0, 0);
+        w_ptr[i] += BK;
+      }
+    }
+  };
+  const int wm = w >> 2, st = w & 3;
+  f32x16 acc[2][5];
+  for (int t = 0; t < 2; ++t) for (int j = 0; j < 5; ++j) for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+  const int l31 = lane & 31, lh = lane >> 5;
+  for (int s = 0; s < STAGES - 1; ++s) if (s < nsteps) issue(s);
+  int buf = 0, buf_issue = STAGES - 1;
+  for (int it = 0; it < nsteps; ++it) {
+    // leave the youngest STAGES-2 stages in flight
+    const int rem = nsteps - 1 - it;   // stages issued after stage `it`
+    const int fly = rem < STAGES - 2 ? rem : STAGES - 2;
+    if (w < 4) {
+      if (fly >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (fly == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (fly >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (fly == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const bf16_t* As = smem + buf * BUF;
+    const bf16_t* Bs = As + A_ELEMS;
+    bf16x8 a2[2], b5[5];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = wm * 64 + t * 32 + l31;
+      a2[t] = *reinterpret_cast<const bf16x8*>(As + row * BK + (((st * 2 + lh) ^ ((row >> 1) & 7)) * 8));
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int row = j * 32 + l31;
+      b5[j] = *reinterpret_cast<const bf16x8*>(Bs + row * BK + (((st * 2 + lh) ^ ((row >> 1) & 7)) * 8));
+    }
+    if (it + STAGES - 1 < nsteps) issue(buf_issue);
+    buf_issue = (buf_issue + 1 == STAGES) ? 0 : buf_issue + 1;
+    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b5[j], a2[t], acc[t][j], 0, 0, 0);
+  }
+  float result = 0.f;
+  for (int t = 0; t < 2; ++t) for (int j = 0; j < 5; ++j) for (int r = 0; r < 16; ++r) result += acc[t][j][r];
+  C[(size_t)blockIdx.x * 512 + tid] = result;
+}
+
+template <int STAGES>
+void run8(const bf16_t* A, const bf16_t* W, float* C, int M, int N, int K, const char* what) {
+  constexpr int smem = STAGES * (BM * BK + BN * BK) * 2;
+  hipFuncSetAttribute((const void*)k_gemm8<STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  int grid = (M / BM) * (N / BN);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) k_gemm8<STAGES><<<grid, 512, smem>>>(A, W, C, M, N, K);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  const int R = 20;
+  for (int i = 0; i < R; ++i) k_gemm8<STAGES><<<grid, 512, smem>>>(A, W, C, M, N, K);
+  hipEventRecord(e1); hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double us = ms * 1e3 / R;
+  printf("%-44s stages=%d: %7.1f us  %6.0f TFLOP/s  (%.2f us per K step)  [%s]\n", what, STAGES, us, 2.0 * M * N * K / us / 1e6, us / (K / BK),
+         hipGetErrorString(hipGetLastError()));
+}
+
+template <int MODE, int LOADS, int LDSR, int BARR, int OCC>
+void run(const bf16_t* A, const bf16_t* W, float* C, int M, int N, int K, const char* what) {
+  constexpr int smem = 2 * (BM * BK + BN * BK) * 2;
+  hipFuncSetAttribute((const void*)k_gemm<MODE, LOADS, LDSR, BARR, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+  int lds = OCC == 1 ? 100 * 1024 : smem;
+  int grid = (M / BM) * (N / BN);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) k_gemm<MODE, LOADS, LDSR, BARR, OCC><<<grid, 256, lds>>>(A, W, C, M, N, K);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  const int R = 20;
+  for (int i = 0; i < R; ++i) k_gemm<MODE, LOADS, LDSR, BARR, OCC><<<grid, 256, lds>>>(A, W, C, M, N, K);
+  hipEventRecord(e1); hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double us = ms * 1e3 / R;
+  printf("%-44s mode=%d loads=%d lds=%d barrier=%d occ=%d: %7.1f us  %6.0f TFLOP/s  (%.2f us per K step)\n", what, MODE, LOADS, LDSR, BARR, OCC, us,
+         2.0 * M * N * K / us / 1e6, us / (K / BK));
+}
+
+int main(int argc, char** argv) {
+  setvbuf(stdout, NULL, _IONBF, 0);
+  int M = 32768, N = 320, K = argc > 1 ? atoi(argv[1]) : 2880;
+  bf16_t *A, *W; float* C;
+  hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&W, (size_t)N * K * 2); hipMalloc(&C, (size_t)1024 * 512 * 4);
+  // random bf16 in [-1, 1)
+  {
+    size_t na = (size_t)M * K, nw = (size_t)N * K;
+    bf16_t* h = (bf16_t*)malloc((na > nw ? na : nw) * 2);
+    unsigned s = 12345;
+    for (size_t i = 0; i < na; ++i) { s = s * 1664525u + 1013904223u; h[i] = (bf16_t)(0x3c00 + ((s >> 16) & 0x3ff)) ^ (bf16_t)((s >> 31) << 15); }
+    hipMemcpy(A, h, na * 2, hipMemcpyHostToDevice);
+    for (size_t i = 0; i < nw; ++i) { s = s * 1664525u + 1013904223u; h[i] = (bf16_t)(0x3c00 + ((s >> 16) & 0x3ff)) ^ (bf16_t)((s >> 31) << 15); }
+    hipMemcpy(W, h, nw * 2, hipMemcpyHostToDevice);
+    free(h);
+  }
+  printf("M=%d N=%d K=%d, %d tiles\n", M, N, K, (M / BM) * (N / BN));
+  run<0, 1, 1, 1, 2>(A, W, C, M, N, K, "16x16x32 full");
+  run<0, 0, 1, 1, 2>(A, W, C, M, N, K, "16x16x32 no global loads");
+  run<0, 0, 1, 0, 2>(A, W, C, M, N, K, "16x16x32 no loads, no barrier");
+  run<0, 0, 0, 0, 2>(A, W, C, M, N, K, "16x16x32 pure MFMA");
+  run<0, 1, 0, 1, 2>(A, W, C, M, N, K, "16x16x32 loads+barrier, no LDS reads");
+  run<0, 1, 1, 1, 1>(A, W, C, M, N, K, "16x16x32 full, 1 block/CU");
+  run<0, 0, 0, 0, 1>(A, W, C, M, N, K, "16x16x32 pure MFMA, 1 block/CU");
+  run<1, 1, 1, 1, 2>(A, W, C, M, N, K, "32x32x16 K-split full");
+  run<1, 0, 1, 1, 2>(A, W, C, M, N, K, "32x32x16 no global loads");
+  run<1, 0, 1, 0, 2>(A, W, C, M, N, K, "32x32x16 no loads, no barrier");
+  run<1, 0, 0, 0, 2>(A, W, C, M, N, K, "32x32x16 pure MFMA");
+  run<1, 1, 0, 1, 2>(A, W, C, M, N, K, "32x32x16 loads+barrier, no LDS reads");
+  run<1, 1, 1, 1, 1>(A, W, C, M, N, K, "32x32x16 full, 1 block/CU");
+  run<1, 0, 0, 0, 1>(A, W, C, M, N, K, "32x32x16 pure MFMA, 1 block/CU");
+  run8<2>(A, W, C, M, N, K, "K8: 8 waves 128x160, 1 block/CU");
+  run8<3>(A, W, C, M, N, K, "K8: 8 waves 128x160, 1 block/CU");
+  run8<4>(A, W, C, M, N, K, "K8: 8 waves 128x160, 1 block/CU");
+  return 0;
+}
