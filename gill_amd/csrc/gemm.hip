@@ -50,6 +50,8 @@ struct GemmDev {
   int ksteps;        // K / 64
   int ksteps_per_split;
   int tiles_n;
+  int npw;           // N tiles one workgroup walks back to back (plain GEMM, no split-K): the LDS ring keeps flowing
+  int groups_n;      // cdiv(tiles_n, npw)
 };
 
 __device__ __noinline__ float gelu_erf_call(float v) { return gelu_erf(v); }  // keeps erff out of the unrolled epilogue
@@ -120,7 +122,7 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0
 //         the DMA of K steps i+1 AND i+2 is in flight while step i is multiplied (counted s_waitcnt vmcnt(N), raw
 //         s_barrier) — for grids of ~one workgroup per CU where co-residency cannot do the hiding.
 template <int BN, int CONV, int EPI, int STAGES>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) {
   constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
@@ -141,10 +143,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
     const int xcd = bid & 7, idx = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tn = tile % d.tiles_n;
-  const int tm = tile / d.tiles_n;
+  const int gn = tile % d.groups_n;
+  const int tm = tile / d.groups_n;
   const int m0 = tm * BM;
-  const int n0 = tn * BN;
+  const int tn_first = gn * d.npw;
+  const int ntl = (d.tiles_n - tn_first < d.npw) ? d.tiles_n - tn_first : d.npw;   // N tiles of this workgroup
+  int n0 = tn_first * BN;
   const int z = blockIdx.y;
   const int kt_beg = z * d.ksteps_per_split;
   int kt_end = kt_beg + d.ksteps_per_split;
@@ -194,13 +198,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
   // W rows: BN/32 instructions per wave (BN rows / 8 rows per instr / 4 waves)
   constexpr int WI = BN / 32;
   const bf16_t* w_ptr[WI];
+  int n_issue = n0;        // first column of the N tile being staged
+  auto w_setup = [&]() {
 #pragma unroll
-  for (int i = 0; i < WI; ++i) {
-    int row = (i * 4 + w) * 8 + srow;
-    int n = n0 + row;
-    if (n > p.N - 1) n = p.N - 1;
-    w_ptr[i] = p.W + (size_t)n * p.K + schunk * 8 + kt_beg * BK;
-  }
+    for (int i = 0; i < WI; ++i) {
+      int row = (i * 4 + w) * 8 + srow;
+      int n = n_issue + row;
+      if (n > p.N - 1) n = p.N - 1;
+      w_ptr[i] = p.W + (size_t)n * p.K + schunk * 8 + kt_beg * BK;
+    }
+  };
+  w_setup();
   const bf16_t* zero_lane = d.zero + schunk * 8;
 
   // ---- K-step addressing is incremental: K is walked in (tap, source) segments inside which every row pointer just
@@ -256,7 +264,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
     }
   };
   int k_issue = kt_beg * BK;     // K coordinate of the next step to stage
+  int steps_in_tile = 0;
   auto issue = [&](int buf) {
+    if (steps_in_tile == nsteps) {   // next N tile of this workgroup: same A rows from the top, next BN weight rows
+      steps_in_tile = 0;
+      k_issue = kt_beg * BK;
+      seg_left = 0;
+      n_issue += BN;
+      w_setup();
+    }
+    ++steps_in_tile;
     if (seg_left == 0) seg_setup(k_issue);
     --seg_left;
     bf16_t* As = smem + buf * BUF_ELEMS;
@@ -279,10 +296,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
   };
 
   f32x4 acc[4][NT];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int wm = w >> 1, wn = w & 1;
   const int frow = lane & 15;       // fragment row within a 16-row sub-tile
@@ -290,13 +303,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
 
   constexpr int LOADS = 4 + WI;     // LDS-DMA instructions one wave issues per K step
   static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+  const int total_steps = ntl * nsteps;
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nsteps) issue(s);
+    if (s < total_steps) issue(s);
   int buf = 0, buf_issue = STAGES - 1;
-  for (int it = 0; it < nsteps; ++it) {
-    // wait for stage `it` only: with a 3-deep ring stage it+1 (the youngest LOADS instructions) stays in flight
-    if (STAGES == 3 && it + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+  int flat = 0;          // K steps consumed over all N tiles of this workgroup
+  for (int t = 0; t < ntl; ++t, n0 += BN) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < nsteps; ++it, ++flat) {
+    // wait for stage `flat` only: with a 3-deep ring the next stage (the youngest LOADS instructions) stays in flight
+    if (STAGES == 3 && flat + 1 < total_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const bf16_t* As = smem + buf * BUF_ELEMS;
@@ -320,7 +340,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
       }
       if (kk == 0) {
         // stage the next tile while the first fragments are in flight from LDS (its ~30 instructions cover that latency)
-        if (it + STAGES - 1 < nsteps) issue(buf_issue);
+        if (flat + STAGES - 1 < total_steps) issue(buf_issue);
         buf_issue = (buf_issue + 1 == STAGES) ? 0 : buf_issue + 1;
       }
 #pragma unroll
@@ -500,6 +520,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmDev d) {
         atomicAdd(&p.gn_stats[((size_t)(mfirst / p.rows_per_batch) * p.gn_groups + g) * 2 + which], val);
     }
   }
+  }   // N tiles of this workgroup
 }
 
 // split-K reduction + epilogue
@@ -637,11 +658,23 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   d.ksteps_per_split = cdiv(d.ksteps, sk);
   d.tiles_n = cdiv(a.N, BN);
   const int tiles_m = cdiv(a.M, BM);
-  dim3 grid(tiles_m * d.tiles_n, sk, 1);
   static const int forced = env_int("GILL_GEMM_STAGES");
   int stages = a.stages;
   if (forced == 2 || forced == 3) stages = forced;
   if (stages != 3) stages = 2;
+  // Short-K GEMMs with many N tiles (GEGLU, QKV: K = 320..1280, 6..80 N tiles) spend most of a tile's life in the first-load
+  // latency and the epilogue.  Let one workgroup walk `npw` N tiles back to back instead: the ring is staged across tile
+  // boundaries, so the loads of tile t+1 fly during the epilogue of tile t.  Keep ~2 workgroups per CU.
+  d.npw = 1;
+  static const int npw_off = env_int("GILL_GEMM_NPW_OFF");
+  if (!a.conv && sk == 1 && stages == 2 && !a.gn_stats && d.tiles_n >= 2 && !npw_off) {
+    int groups = cdiv(512, tiles_m);
+    if (groups < 1) groups = 1;
+    if (groups > d.tiles_n) groups = d.tiles_n;
+    d.npw = cdiv(d.tiles_n, groups);
+  }
+  d.groups_n = cdiv(d.tiles_n, d.npw);
+  dim3 grid(tiles_m * d.groups_n, sk, 1);
   if (a.conv) {
     if (a.ups) {
       if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 2, 2>(d, grid, stages, s)));
