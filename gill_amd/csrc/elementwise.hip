@@ -442,3 +442,31 @@ int unpad_heads_launch(const bf16_t* src, int64_t rows, int H, int d, int dp, bf
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+// LayerNorm folded into the following Linear (see GemmArgs::ln_stats): one wave per weight row n:
+//   W[n,k] <- bf16(W[n,k] * g[k]);  colsum[n] = sum_k W'[n,k] (of the ROUNDED products, what the MFMA multiplies);
+//   bias[n] += sum_k beta[k] * W[n,k]
+__global__ __launch_bounds__(256) void ln_fold_rows_kernel(bf16_t* __restrict__ W, int N, int K, const float* __restrict__ g,
+                                                           const float* __restrict__ beta, float* __restrict__ colsum,
+                                                           float* __restrict__ bias) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  bf16_t* row = W + (size_t)n * K;
+  float s = 0.f, c = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = bf2f(row[k]);
+    const bf16_t wp = f2bf(w * g[k]);
+    row[k] = wp;
+    s += bf2f(wp);
+    c += beta[k] * w;
+  }
+  s = wave_sum(s); c = wave_sum(c);
+  if (lane == 0) { colsum[n] = s; bias[n] += c; }
+}
+
+int ln_fold_rows_launch(bf16_t* W, int N, int K, const float* g, const float* beta, float* colsum, float* bias, hipStream_t s) {
+  hipLaunchKernelGGL(ln_fold_rows_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, W, N, K, g, beta, colsum, bias);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -121,6 +121,16 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0
 // STAGES: depth of the LDS ring.  2: two workgroups per CU hide each other's DMA waits.  3: one workgroup per CU,
 //         the DMA of K steps i+1 AND i+2 is in flight while step i is multiplied (counted s_waitcnt vmcnt(N), raw
 //         s_barrier) — for grids of ~one workgroup per CU where co-residency cannot do the hiding.
+// folded LayerNorm: rstd and mean*rstd of A's row m from the producer's {sum, sum of squares}
+__device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& rr, float& rm) {
+  const float2 st = *reinterpret_cast<const float2*>(p.ln_stats + (size_t)m * 2);
+  const float invk = 1.f / (float)p.K;
+  const float mean = st.x * invk;
+  const float var = fmaxf(st.y * invk - mean * mean, 0.f);
+  rr = rsqrtf(var + p.ln_eps);
+  rm = mean * rr;
+}
+
 template <int BN, int CONV, int EPI, int STAGES>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) {
   constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
@@ -370,6 +380,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) 
     }
   } else if constexpr (EPI == 1) {
     // weight rows are interleaved in 16-row blocks: even block = value rows, odd block = gate rows
+    float rr[4], rm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rr[i] = 1.f; rm[i] = 0.f;
+      const int m = mrow + i * 16;
+      if (p.ln_stats && m < p.M) ln_row_factors(p, m, rr[i], rm[i]);
+    }
 #pragma unroll
     for (int j = 0; j + 1 < NT; j += 2) {
       const int nv = ncol + j * 16;         // physical column of the value block
@@ -378,14 +395,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) 
       const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + nv) : make_float4(0, 0, 0, 0);
       const float4 bg = p.bias ? *reinterpret_cast<const float4*>(p.bias + ng) : make_float4(0, 0, 0, 0);
       const int no = (nv >> 5) * 16 + (nv & 15);  // logical output column
+      const float4 sv = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + nv) : make_float4(0, 0, 0, 0);
+      const float4 sg = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + ng) : make_float4(0, 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = mrow + i * 16;
         if (m >= p.M) continue;
-        const float o0 = (acc[i][j][0] + bv.x) * gelu_erf(acc[i][j + 1][0] + bg.x);
-        const float o1 = (acc[i][j][1] + bv.y) * gelu_erf(acc[i][j + 1][1] + bg.y);
-        const float o2 = (acc[i][j][2] + bv.z) * gelu_erf(acc[i][j + 1][2] + bg.z);
-        const float o3 = (acc[i][j][3] + bv.w) * gelu_erf(acc[i][j + 1][3] + bg.w);
+        const float o0 = (acc[i][j][0] * rr[i] - rm[i] * sv.x + bv.x) * gelu_erf(acc[i][j + 1][0] * rr[i] - rm[i] * sg.x + bg.x);
+        const float o1 = (acc[i][j][1] * rr[i] - rm[i] * sv.y + bv.y) * gelu_erf(acc[i][j + 1][1] * rr[i] - rm[i] * sg.y + bg.y);
+        const float o2 = (acc[i][j][2] * rr[i] - rm[i] * sv.z + bv.z) * gelu_erf(acc[i][j + 1][2] * rr[i] - rm[i] * sg.z + bg.z);
+        const float o3 = (acc[i][j][3] * rr[i] - rm[i] * sv.w + bv.w) * gelu_erf(acc[i][j + 1][3] * rr[i] - rm[i] * sg.w + bg.w);
         uint2 o; o.x = pack_bf2(o0, o1); o.y = pack_bf2(o2, o3);
         *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + no) = o;
       }
@@ -393,10 +412,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) 
   } else if constexpr (EPI == 3) {
     // head-major scatter; all divisions hoisted: per-row (b, t) once, per-column (segment, head, dd) once
     int rq[4], rk[4], rv[4]; bool mok[4];
+    float rr[4], rm[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = mrow + i * 16;
       mok[i] = m < p.M;
+      rr[i] = p.alpha; rm[i] = 0.f;
+      if (p.ln_stats && mok[i]) ln_row_factors(p, m, rr[i], rm[i]);
       const int b = m / p.ntok, t = m - b * p.ntok;
       rq[i] = (b * p.heads * p.ntok_pad_q + t) * p.dp;
       rk[i] = (b * p.heads * p.ntok_pad_kv + t) * p.dp;
@@ -412,11 +434,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) 
       const int h = within / p.dp, dd = within - h * p.dp;
       const int seg = p.seg_base + segl;
       const float4 bz = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
+      const float4 cs = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + n) : make_float4(0, 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (!mok[i]) continue;
-        float v0 = acc[i][j][0] * p.alpha + bz.x, v1 = acc[i][j][1] * p.alpha + bz.y;
-        float v2 = acc[i][j][2] * p.alpha + bz.z, v3 = acc[i][j][3] * p.alpha + bz.w;
+        float v0 = acc[i][j][0] * rr[i] - rm[i] * cs.x + bz.x, v1 = acc[i][j][1] * rr[i] - rm[i] * cs.y + bz.y;
+        float v2 = acc[i][j][2] * rr[i] - rm[i] * cs.z + bz.z, v3 = acc[i][j][3] * rr[i] - rm[i] * cs.w + bz.w;
         if (seg == 0) {
           v0 *= p.qscale; v1 *= p.qscale; v2 *= p.qscale; v3 *= p.qscale;   // softmax scale * log2(e) folded into Q
           uint2 o; o.x = pack_bf2(v0, v1); o.y = pack_bf2(v2, v3);
@@ -455,6 +478,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) 
       red[tid] = 0.f;
       __syncthreads();
     }
+    float rws[4] = {0.f, 0.f, 0.f, 0.f}, rwq[4] = {0.f, 0.f, 0.f, 0.f};   // row sums for a following (folded) LayerNorm
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = ncol + j * 16;
@@ -489,6 +513,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) 
         } else {
           uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
           *reinterpret_cast<uint2*>((bf16_t*)p.C + crow[i] + n) = o;
+          if (p.row_stats) {   // statistics of what the consumer will read: the rounded values
+            const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
+            const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
+            rws[i] += (r0 + r1) + (r2 + r3);
+            rwq[i] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+          }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
@@ -508,6 +538,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) 
         if (g3 != g0) {
           atomicAdd(&red[(wm * 64 + g3) * 2], s1);
           atomicAdd(&red[(wm * 64 + g3) * 2 + 1], q1);
+        }
+      }
+    }
+    if (p.row_stats) {
+      // a row's BN/2 columns of this wave sit in the 4 lanes {frow, frow+16, frow+32, frow+48}
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rws[i] += __shfl_xor(rws[i], 16, 64); rwq[i] += __shfl_xor(rwq[i], 16, 64);
+        rws[i] += __shfl_xor(rws[i], 32, 64); rwq[i] += __shfl_xor(rwq[i], 32, 64);
+        if (fkc == 0 && mok[i]) {
+          atomicAdd(p.row_stats + (size_t)(mrow + i * 16) * 2, rws[i]);
+          atomicAdd(p.row_stats + (size_t)(mrow + i * 16) * 2 + 1, rwq[i]);
         }
       }
     }
@@ -538,6 +580,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs 
     __syncthreads();
   }
   float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+  float rsum[R], rsq[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { rsum[r] = 0.f; rsq[r] = 0.f; }
   if (n < p.N) {
     // all partial loads of the thread's 4 rows are issued before any epilogue store (a store in between would fence the
     // next row's loads): 4 rows x 4 splits = 16 independent 16-B loads in flight per pass
@@ -570,14 +615,35 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs 
 #pragma unroll
       for (int r = 0; r < R; ++r) { s[r].x += v[r].x; s[r].y += v[r].y; s[r].z += v[r].z; s[r].w += v[r].w; }
     }
+    const float4 cs = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + n) : make_float4(0, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int m = mbase + ty + 16 * r;
       if (m >= p.M) continue;
+      if (p.ln_stats) {
+        float rr, rm;
+        ln_row_factors(p, m, rr, rm);
+        s[r].x = s[r].x * rr - rm * cs.x; s[r].y = s[r].y * rr - rm * cs.y;
+        s[r].z = s[r].z * rr - rm * cs.z; s[r].w = s[r].w * rr - rm * cs.w;
+      }
       float fin[4];
       store4(p, m, n, s[r].x, s[r].y, s[r].z, s[r].w, fin);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { gs[e] += fin[e]; gq[e] += fin[e] * fin[e]; }
+      rsum[r] = 0.f; rsq[r] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float q = bf2f(f2bf(fin[e])); rsum[r] += q; rsq[r] += q * q; }
+    }
+  }
+  if (p.row_stats) {
+    // the 16 threads tx = 0..15 of a row hold its 64 columns of this block: reduce, one atomic pair per row per block
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float a = rsum[r], q = rsq[r];
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) { a += __shfl_xor(a, off, 64); q += __shfl_xor(q, off, 64); }
+      const int m = mbase + ty + 16 * r;
+      if (tx == 0 && m < p.M) { atomicAdd(p.row_stats + (size_t)m * 2, a); atomicAdd(p.row_stats + (size_t)m * 2 + 1, q); }
     }
   }
   if (p.gn_stats) {
@@ -726,6 +792,13 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
     GILL_REQUIRE(a.out_mode != OUT_QKV && a.act != ACT_GEGLU, "fused GroupNorm statistics need the row-major epilogue");
     GILL_REQUIRE(a.rows_per_batch % 64 == 0 && a.gn_groups > 0 && a.gn_groups <= 64 && a.gn_cg * a.gn_groups == a.N,
                  "fused GroupNorm statistics: rows per sample must be a multiple of 64 and groups must tile N");
+  }
+  if (a.row_stats)
+    GILL_REQUIRE(a.out_mode == OUT_BF16 && a.act != ACT_GEGLU, "row statistics need the bf16 row-major epilogue");
+  if (a.ln_stats) {
+    GILL_REQUIRE(a.ln_colsum != nullptr && !a.conv && a.K1 == a.K, "folded LayerNorm: column sums missing / single-source plain GEMM only");
+    GILL_REQUIRE(a.act == ACT_GEGLU || a.out_mode == OUT_QKV, "folded LayerNorm is implemented in the GEGLU and QKV epilogues");
+    GILL_REQUIRE(a.alpha == 1.f, "folded LayerNorm: alpha must be 1");
   }
   if (a.splitk > 1) {
     GILL_REQUIRE(a.ws != nullptr, "split-K workspace missing");

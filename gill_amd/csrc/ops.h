@@ -39,6 +39,13 @@ struct GemmArgs {
   // fused GroupNorm statistics of the output: gn_stats[(m / rows_per_batch)][gn_groups][2] += {sum, sum of squares}
   // over each group of gn_cg output channels (row-major epilogue only; gn_stats zeroed by the caller)
   float* gn_stats = nullptr; int gn_groups = 0; int gn_cg = 0;
+  // LayerNorm folded into the NEXT GEMM: LN(x) W^T + b = rstd (x (g*W)^T - mean * colsum(g*W)) + (beta W^T + b).
+  //  producer: row_stats[m][2] += {sum, sum of squares} of each bf16-rounded output row (row-major bf16 epilogue; zeroed
+  //            by the caller);
+  //  consumer: ln_stats = the producer's row_stats of A, ln_colsum[n] = sum_k W'[n,k] (W' = g*W is what `W` holds, and
+  //            `bias` holds beta W^T + b); mean/rstd over K with eps ln_eps.  GEGLU and QKV epilogues (+ split-K reducer).
+  float* row_stats = nullptr;
+  const float* ln_stats = nullptr; const float* ln_colsum = nullptr; float ln_eps = 1e-5f;
   // tuning: LDS ring depth (2|3, 0 = default 2) and tile width (128|160, 0 = by divisibility)
   int stages = 0; int bn = 0;
 };
@@ -117,6 +124,8 @@ int scatter_rows_bf16_launch(const bf16_t* src, int rows, int cols, const int32_
                              hipStream_t s);
 
 int permute_f32_launch(const float* src, const int32_t* idx, int n, float* dst, hipStream_t s);
+// fold LayerNorm(g, beta) into the Linear that follows it: W <- bf16(W*g) in place, colsum[n] = sum_k W', bias[n] += beta.W[n]
+int ln_fold_rows_launch(bf16_t* W, int N, int K, const float* g, const float* beta, float* colsum, float* bias, hipStream_t s);
 int pack_heads_launch(const bf16_t* src, int B, int n, int H, int d, int n_pad, int dp, int dpv, int mode, bf16_t* dst,
                       hipStream_t s, float mul = 1.f);
 int unpad_heads_launch(const bf16_t* src, int64_t rows, int H, int d, int dp, bf16_t* dst, hipStream_t s);

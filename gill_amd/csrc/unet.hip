@@ -52,6 +52,8 @@ struct XfW {  // Transformer2DModel with one BasicTransformerBlock
   bf16_t* wkv2 = nullptr;     // [2*H*dp][ctx_dim]
   LinW out2;
   bf16_t* wff1 = nullptr; float* bff1 = nullptr;   // GEGLU-permuted [8C][C]
+  // norm1/2/3 are folded into wqkv1 / wq2 / wff1 at load (GemmArgs::ln_stats): column sums of g*W and beta.W^T (+ bias)
+  float *s_qkv1 = nullptr, *c_qkv1 = nullptr, *s_q2 = nullptr, *c_q2 = nullptr, *s_ff1 = nullptr;
   LinW ff2;                   // [C][4C]
 };
 
@@ -96,6 +98,8 @@ struct gill_unet {
   unsigned char* arena_mem = nullptr;
   float* gn_stats = nullptr;      // pool of pre-zeroed [Bx][groups][2] slots, one per GroupNorm call of a forward
   int gn_slots = 0, gn_slot_floats = 0, gn_next = 0;
+  float* ln_stats = nullptr;      // pre-zeroed per-forward pool of [rows][2] row sums feeding the folded LayerNorms
+  size_t ln_floats = 0, ln_next = 0;
   float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
   std::vector<bf16_t*> kcache, vcache;   // per transformer layer: [Bx][H][ctx_pad][dp] / [Bx][H][dpv][ctx_pad]
   int ctx_pad = 0;
@@ -275,6 +279,13 @@ struct Loader {
       GILL_TRY(permute_f32_launch(tmpb, idx, 2 * inner, x->bff1, s));
     }
     GILL_TRY(lin(b + ".ff.net.2", C, 4 * C, &x->ff2));
+    // fold the three LayerNorms into the projections that consume them
+    GILL_TRY(pool.alloc(&x->s_qkv1, (size_t)3 * hdp)); GILL_TRY(pool.alloc(&x->c_qkv1, (size_t)3 * hdp));
+    GILL_TRY(pool.alloc(&x->s_q2, (size_t)hdp)); GILL_TRY(pool.alloc(&x->c_q2, (size_t)hdp));
+    GILL_TRY(pool.alloc(&x->s_ff1, (size_t)8 * C));
+    GILL_TRY(ln_fold_rows_launch(x->wqkv1, 3 * hdp, C, x->ln1.g, x->ln1.b, x->s_qkv1, x->c_qkv1, s));
+    GILL_TRY(ln_fold_rows_launch(x->wq2, hdp, C, x->ln2.g, x->ln2.b, x->s_q2, x->c_q2, s));
+    GILL_TRY(ln_fold_rows_launch(x->wff1, 8 * C, C, x->ln3.g, x->ln3.b, x->s_ff1, x->bff1, s));
     return 0;
   }
 };
@@ -412,6 +423,11 @@ struct UNetRun {
     ++m->gn_next;
     return p;
   }
+  float* ln_slot(int rows) {   // [rows][2] floats of the per-forward LayerNorm row-sum pool (the dry run sizes it)
+    float* p = dry ? (float*)(uintptr_t)16 : m->ln_stats + m->ln_next;
+    m->ln_next += (size_t)rows * 2;
+    return p;
+  }
   Tensor talloc(int H, int W, int C, bool want_stats = false) {
     Tensor t; t.H = H; t.W = W; t.C = C;
     t.p = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * H * W * C);
@@ -461,10 +477,11 @@ struct UNetRun {
     return gemm(g);
   }
   int linear(const bf16_t* A, int lda, const bf16_t* A2, int lda2, int K1, int M, const bf16_t* W, const float* b, int N,
-             int K, const bf16_t* resid, int act, bf16_t* out, int ldc, const Tensor* ystats = nullptr) {
+             int K, const bf16_t* resid, int act, bf16_t* out, int ldc, const Tensor* ystats = nullptr,
+             float* row_stats = nullptr) {
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.K1 = K1; g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.W = W; g.bias = b;
-    g.resid = resid; g.ldr = N; g.act = act; g.C = out; g.ldc = ldc;
+    g.resid = resid; g.ldr = N; g.act = act; g.C = out; g.ldc = ldc; g.row_stats = row_stats;
     if (ystats) fuse_stats(g, *ystats);
     return gemm(g);
   }
@@ -519,43 +536,45 @@ struct UNetRun {
     Tensor n = talloc(H, Wd, C);
     GILL_TRY(gnorm(x, nullptr, w.gn, 1e-6f, 0, n));
     Tensor t = talloc(H, Wd, C);   // transformer residual stream
-    GILL_TRY(linear(n.p, C, nullptr, 0, C, M, w.proj_in.w, w.proj_in.b, C, C, nullptr, ACT_NONE, t.p, C));
-    bf16_t* ln = n.p;              // reuse: normalised activations
+    // norm1/2/3 never materialise: the GEMM that writes the residual stream also accumulates each row's sum and sum of
+    // squares, and the projection that follows applies mean / rstd in its epilogue on weights pre-multiplied by the LN gain
+    float* st1 = ln_slot(M); float* st2 = ln_slot(M); float* st3 = ln_slot(M);
+    GILL_TRY(linear(n.p, C, nullptr, 0, C, M, w.proj_in.w, w.proj_in.b, C, C, nullptr, ACT_NONE, t.p, C, nullptr, st1));
     const int hw_pad = round_up(HW, 32);   // kv tiles are 32 wide; pad rows hold finite stale data and are masked
     bf16_t* q = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * nh * hw_pad * w.dp);
     bf16_t* k = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * nh * hw_pad * w.dp);
     bf16_t* vt = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * nh * w.dpv * hw_pad);
     bf16_t* o = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)M * hdp);
     // --- self attention
-    if (!dry) GILL_TRY(layernorm_launch(t.p, 0, w.ln1.g, w.ln1.b, ln, M, C, 1e-5f, s));
     {
       GemmArgs g;
-      g.M = M; g.N = 3 * hdp; g.K = C; g.K1 = C; g.A = ln; g.lda = C; g.W = w.wqkv1;
+      g.M = M; g.N = 3 * hdp; g.K = C; g.K1 = C; g.A = t.p; g.lda = C; g.W = w.wqkv1;
+      g.ln_stats = st1; g.ln_colsum = w.s_qkv1; g.bias = w.c_qkv1;
       g.out_mode = OUT_QKV; g.Cq = q; g.Ck = k; g.Cvt = vt; g.heads = nh; g.dp = w.dp; g.dpv = w.dpv;
       g.ntok = HW; g.ntok_pad_q = hw_pad; g.ntok_pad_kv = hw_pad; g.seg_base = 0;
       g.qscale = 1.4426950408889634f / sqrtf((float)w.d);
       GILL_TRY(gemm(g));
     }
     GILL_TRY(attend(q, k, vt, o, HW, HW, hw_pad, hw_pad, w));
-    GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M, w.out1.w, w.out1.b, C, hdp, t.p, ACT_NONE, t.p, C));
+    GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M, w.out1.w, w.out1.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, st2));
     // --- cross attention (K/V cached per prompt)
-    if (!dry) GILL_TRY(layernorm_launch(t.p, 0, w.ln2.g, w.ln2.b, ln, M, C, 1e-5f, s));
     {
       GemmArgs g;
-      g.M = M; g.N = hdp; g.K = C; g.K1 = C; g.A = ln; g.lda = C; g.W = w.wq2;
+      g.M = M; g.N = hdp; g.K = C; g.K1 = C; g.A = t.p; g.lda = C; g.W = w.wq2;
+      g.ln_stats = st2; g.ln_colsum = w.s_q2; g.bias = w.c_q2;
       g.out_mode = OUT_QKV; g.Cq = q; g.Ck = k; g.Cvt = vt; g.heads = nh; g.dp = w.dp; g.dpv = w.dpv;
       g.ntok = HW; g.ntok_pad_q = hw_pad; g.ntok_pad_kv = hw_pad; g.seg_base = 0;
       g.qscale = 1.4426950408889634f / sqrtf((float)w.d);
       GILL_TRY(gemm(g));
     }
     GILL_TRY(attend(q, m->kcache[w.layer_id], m->vcache[w.layer_id], o, HW, m->cfg.ctx_len, hw_pad, m->ctx_pad, w));
-    GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M, w.out2.w, w.out2.b, C, hdp, t.p, ACT_NONE, t.p, C));
+    GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M, w.out2.w, w.out2.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, st3));
     // --- GEGLU feed-forward
-    if (!dry) GILL_TRY(layernorm_launch(t.p, 0, w.ln3.g, w.ln3.b, ln, M, C, 1e-5f, s));
     bf16_t* ffh = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)M * 4 * C);
     {
       GemmArgs g;
-      g.M = M; g.N = 8 * C; g.K = C; g.K1 = C; g.A = ln; g.lda = C; g.W = w.wff1; g.bias = w.bff1;
+      g.M = M; g.N = 8 * C; g.K = C; g.K1 = C; g.A = t.p; g.lda = C; g.W = w.wff1; g.bias = w.bff1;
+      g.ln_stats = st3; g.ln_colsum = w.s_ff1;
       g.act = ACT_GEGLU; g.C = ffh; g.ldc = 4 * C;
       GILL_TRY(gemm(g));
     }
@@ -573,7 +592,11 @@ struct UNetRun {
     const int L = c.sample_size;
     m->arena.off = 0;
     m->gn_next = 0;
-    if (!dry) GILL_CHECK_HIP(hipMemsetAsync(m->gn_stats, 0, sizeof(float) * (size_t)m->gn_slots * m->gn_slot_floats, s));
+    m->ln_next = 0;
+    if (!dry) {
+      GILL_CHECK_HIP(hipMemsetAsync(m->gn_stats, 0, sizeof(float) * (size_t)m->gn_slots * m->gn_slot_floats, s));
+      GILL_CHECK_HIP(hipMemsetAsync(m->ln_stats, 0, sizeof(float) * m->ln_floats, s));
+    }
     std::vector<Tensor> skips;
     Tensor x = talloc(L, L, ch[0], true);
     {
@@ -646,6 +669,8 @@ static int unet_plan_and_alloc(gill_unet* m) {
   m->gn_slots = m->gn_next + 1;             // counted by the dry run
   m->gn_slot_floats = Bx * 64 * 2;
   GILL_TRY(m->pool.alloc(&m->gn_stats, (size_t)m->gn_slots * m->gn_slot_floats));
+  m->ln_floats = m->ln_next + 64;           // counted by the dry run (max batch)
+  GILL_TRY(m->pool.alloc(&m->ln_stats, m->ln_floats));
   m->splitk_ws_floats = (size_t)48 << 20;   // 192 MiB of fp32 partials
   GILL_TRY(m->pool.alloc(&m->splitk_ws, m->splitk_ws_floats, false));
   // cross-attention K/V caches
