@@ -790,6 +790,7 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   }
   if (a.gn_stats) {
     GILL_REQUIRE(a.out_mode != OUT_QKV && a.act != ACT_GEGLU, "fused GroupNorm statistics need the row-major epilogue");
+    GILL_REQUIRE(a.gn_cg >= 2, "fused GroupNorm statistics: bins of at least 2 channels");
     GILL_REQUIRE(a.rows_per_batch % 64 == 0 && a.gn_groups > 0 && a.gn_groups <= 64 && a.gn_cg * a.gn_groups == a.N,
                  "fused GroupNorm statistics: rows per sample must be a multiple of 64 and groups must tile N");
   }

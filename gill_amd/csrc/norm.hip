@@ -242,8 +242,9 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ x2, int C2, int HW, int groups,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, int silu,
-                                                              const float* __restrict__ stats, bf16_t* __restrict__ y,
-                                                              int64_t total_vec) {
+                                                              const float* __restrict__ stats1, int bin1, int sc1,
+                                                              const float* __restrict__ stats2, int bin2,
+                                                              bf16_t* __restrict__ y, int64_t total_vec) {
   // block = (b, slab of GN_APPLY_ROWS pixels).  Phase 1: fold statistics and affine into per-channel (scale, shift) in
   // LDS once per block; phase 2: y = [silu](x * scale + shift), 16-B loads and stores.
   extern __shared__ __attribute__((aligned(16))) float gn_ss[];   // [C] scale | [C] shift
@@ -255,10 +256,37 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
   const float inv_n = 1.f / ((float)cg * (float)HW);
   float* scale = gn_ss;
   float* shift = gn_ss + C;
+  // The sums arrive in BINS of bin1 (bin2) channels: stats1 covers channels [0, sc1) of the (concatenated) input, stats2
+  // the rest.  Producers accumulate bins finer than a group so that the same sums serve this tensor's own GroupNorm and
+  // the wider groups of a later skip concatenation; a group's sum is the sum of the bins it covers.
+  __shared__ float gsum[64][2];
+  if (threadIdx.x < groups) {
+    const int g = threadIdx.x;
+    const int lo = g * cg, hi = lo + cg;
+    float a = 0.f, q = 0.f;
+    {
+      const int nb1 = sc1 / bin1;
+      const int e = hi < sc1 ? hi : sc1;
+      for (int bin = lo / bin1; bin * bin1 < e; ++bin) {
+        const float2 v = *reinterpret_cast<const float2*>(stats1 + ((size_t)b * nb1 + bin) * 2);
+        a += v.x; q += v.y;
+      }
+    }
+    if (stats2 && hi > sc1) {
+      const int nb2 = (C - sc1) / bin2;
+      const int s0 = (lo > sc1 ? lo : sc1) - sc1, e = hi - sc1;
+      for (int bin = s0 / bin2; bin * bin2 < e; ++bin) {
+        const float2 v = *reinterpret_cast<const float2*>(stats2 + ((size_t)b * nb2 + bin) * 2);
+        a += v.x; q += v.y;
+      }
+    }
+    gsum[g][0] = a; gsum[g][1] = q;
+  }
+  __syncthreads();
   for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
     const int g = ch / cg;
-    const float sm = stats[((size_t)b * groups + g) * 2] * inv_n;         // E[x]
-    const float sq = stats[((size_t)b * groups + g) * 2 + 1] * inv_n;     // E[x^2]
+    const float sm = gsum[g][0] * inv_n;         // E[x]
+    const float sq = gsum[g][1] * inv_n;         // E[x^2]
     const float var = fmaxf(sq - sm * sm, 0.f);
     const float rstd = rsqrtf(var + eps);
     const float sc = rstd * gamma[ch];
@@ -308,10 +336,35 @@ int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, 
     hipLaunchKernelGGL(groupnorm_stats_kernel, g1, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, stats);
     GILL_CHECK_HIP(hipGetLastError());
   }
+  // `stats` holds one {sum, sum of squares} per group of the whole (concatenated) input
+  return groupnorm_apply_launch(x1, C1, x2, C2, B, HW, groups, gamma, beta, eps, silu, y, stats, C / groups, C, nullptr, 0, s);
+}
+
+static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+
+// Normalise from sums accumulated elsewhere (GEMM / conv epilogues): stats1 = [B][sc1 / bin1][2] over the first sc1 channels,
+// stats2 = [B][(C - sc1) / bin2][2] over the rest (nullptr when stats1 covers everything).
+int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups, const float* gamma,
+                           const float* beta, float eps, int silu, bf16_t* y, const float* stats1, int bin1, int sc1,
+                           const float* stats2, int bin2, hipStream_t s) {
+  const int C = C1 + C2;
+  GILL_REQUIRE(groups <= 64 && C % groups == 0 && (C / groups) % 2 == 0, "groupnorm: channels/group must be even");
+  GILL_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "groupnorm: channel counts must be multiples of 8");
+  GILL_REQUIRE(C2 == 0 || x2 != nullptr, "groupnorm: second source missing");
+  GILL_REQUIRE(stats1 != nullptr && bin1 > 0 && sc1 > 0 && sc1 <= C && sc1 % bin1 == 0, "groupnorm: bad statistics layout");
+  GILL_REQUIRE(groupnorm_bins_align(C / groups, sc1, bin1, (stats2 || sc1 < C) ? bin2 : 0),
+               "groupnorm: group boundaries must fall on statistics bin boundaries");
+  GILL_REQUIRE(sc1 == C || (stats2 != nullptr && bin2 > 0 && (C - sc1) % bin2 == 0), "groupnorm: second statistics block missing");
   const int64_t total_vec = (int64_t)B * HW * (C / 8);
   dim3 g2(cdiv(HW, GN_APPLY_ROWS), B);
   hipLaunchKernelGGL(groupnorm_apply_kernel, g2, dim3(256), sizeof(float) * 2 * C, s, x1, C1, x2, C2, HW, groups, gamma, beta,
-                     eps, silu, stats, y, total_vec);
+                     eps, silu, stats1, bin1, sc1, stats2, bin2, y, total_vec);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+// every group boundary k*cg lands on a bin boundary of the statistics block that holds it
+bool groupnorm_bins_align(int cg, int sc1, int bin1, int bin2) {
+  const int g = gcd_int(cg, sc1);
+  return g % bin1 == 0 && (bin2 == 0 || g % bin2 == 0);
 }

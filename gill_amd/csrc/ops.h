@@ -77,6 +77,12 @@ int layernorm_f32out_launch(const void* x, int x_f32, const float* gamma, const 
 int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups,
                      const float* gamma, const float* beta, float eps, int silu, bf16_t* y,
                      float* stats, hipStream_t s, int stats_prezeroed = 0);
+// normalise from sums accumulated in bins by producer epilogues (see norm.hip); groupnorm_bins_align() tells whether a
+// (channels per group, split point, bin sizes) combination is usable
+int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups, const float* gamma,
+                           const float* beta, float eps, int silu, bf16_t* y, const float* stats1, int bin1, int sc1,
+                           const float* stats2, int bin2, hipStream_t s);
+bool groupnorm_bins_align(int cg, int sc1, int bin1, int bin2);
 
 // ---- small elementwise / gather kernels ----
 int embed_tokens_launch(const int64_t* ids, const bf16_t* table, int vocab, const bf16_t* pos_table, int pos_offset,

@@ -58,7 +58,8 @@ struct XfW {  // Transformer2DModel with one BasicTransformerBlock
 };
 
 // stats: optional slot [Bx][groups][2] that the PRODUCING GEMM epilogue fills with this tensor's GroupNorm sums
-struct Tensor { bf16_t* p = nullptr; int H = 0, W = 0, C = 0; float* stats = nullptr; };
+// sbin: channels per statistics bin (C/64: finer than a group, so the sums also serve the wider groups of a skip concat)
+struct Tensor { bf16_t* p = nullptr; int H = 0, W = 0, C = 0; float* stats = nullptr; int sbin = 0; };
 
 struct Arena {
   unsigned char* base = nullptr;
@@ -432,6 +433,8 @@ struct UNetRun {
     Tensor t; t.H = H; t.W = W; t.C = C;
     t.p = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * H * W * C);
     if (want_stats && (H * W) % 64 == 0 && C % m->cfg.norm_num_groups == 0) {
+      // (the epilogue's 4 consecutive columns may straddle two bins, not more: bins of at least 2 channels)
+      t.sbin = (C % 64 == 0 && C / 64 >= 2) ? C / 64 : C / m->cfg.norm_num_groups;
       t.stats = stats_slot();
       if (dry) t.stats = (float*)(uintptr_t)16;   // non-null marker so the dry run takes the same branches
     }
@@ -439,7 +442,7 @@ struct UNetRun {
   }
   void fuse_stats(GemmArgs& g, const Tensor& y) {
     if (!y.stats) return;
-    g.gn_stats = y.stats; g.gn_groups = m->cfg.norm_num_groups; g.gn_cg = y.C / m->cfg.norm_num_groups;
+    g.gn_stats = y.stats; g.gn_groups = y.C / y.sbin; g.gn_cg = y.sbin;
     g.rows_per_batch = y.H * y.W;
   }
   int pick_sk(GemmArgs& g) {
@@ -455,12 +458,18 @@ struct UNetRun {
   }
   int gnorm(const Tensor& x1, const Tensor* x2, const NormW& n, float eps, int silu, const Tensor& y) {
     // single-source input whose producer already accumulated the sums: no statistics pass
-    const bool ready = (x2 == nullptr) && (x1.stats != nullptr);
-    float* stats = ready ? x1.stats : stats_slot();
+    const int C = x1.C + (x2 ? x2->C : 0);
+    const bool ready = x1.stats != nullptr && (x2 == nullptr || x2->stats != nullptr) &&
+                       groupnorm_bins_align(C / m->cfg.norm_num_groups, x1.C, x1.sbin, x2 ? x2->sbin : 0);
+    float* stats = ready ? nullptr : stats_slot();
     if (dry) return 0;
     GILL_REQUIRE(m->gn_next <= m->gn_slots, "internal: GroupNorm stats pool exhausted");
+    if (ready)
+      return groupnorm_apply_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, x1.H * x1.W, m->cfg.norm_num_groups,
+                                    n.g, n.b, eps, silu, y.p, x1.stats, x1.sbin, x1.C, x2 ? x2->stats : nullptr,
+                                    x2 ? x2->sbin : 0, s);
     return groupnorm_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, x1.H * x1.W, m->cfg.norm_num_groups, n.g,
-                            n.b, eps, silu, y.p, stats, s, ready ? 2 : 1);
+                            n.b, eps, silu, y.p, stats, s, 1);
   }
   // 3x3 conv (pad 1) over x1 (++ x2): stride 1|2, optional fused nearest-2x upsample
   int conv(const Tensor& x1, const Tensor* x2, const ConvW& w, int stride, int ups, const float* rowvec, int rv_bstride,
@@ -614,7 +623,7 @@ struct UNetRun {
         GILL_TRY(resnet(x, nullptr, m->down_res[i][j], &y, true));
         x = y;
         // next consumer: resnet norm1 (j == 0) / the downsample conv or the mid block's norm1 (j == 1)
-        if (i < 3) { Tensor z; GILL_TRY(xf(x, m->down_xf[i][j], &z, j == 0)); x = z; }
+        if (i < 3) { Tensor z; GILL_TRY(xf(x, m->down_xf[i][j], &z, true)); x = z; }   // next GroupNorm and / or a skip
         skips.push_back(x);
       }
       if (i < 3) {
@@ -627,19 +636,18 @@ struct UNetRun {
     {
       Tensor y; GILL_TRY(resnet(x, nullptr, m->mid_res[0], &y, true)); x = y;
       Tensor z; GILL_TRY(xf(x, m->mid_xf, &z, true)); x = z;
-      Tensor u; GILL_TRY(resnet(x, nullptr, m->mid_res[1], &u, false)); x = u;   // -> two-source norm1 of up block 0
+      Tensor u; GILL_TRY(resnet(x, nullptr, m->mid_res[1], &u, true)); x = u;   // -> two-source norm1 of up block 0
     }
     for (int i = 0; i < 4; ++i) {
       for (int j = 0; j < 3; ++j) {
         Tensor skip = skips.back(); skips.pop_back();
-        const bool last = (i == 3 && j == 2);   // feeds conv_norm_out; every other up-path output meets a skip concat
         Tensor y;
-        GILL_TRY(resnet(x, &skip, m->up_res[i][j], &y, i > 0));
+        GILL_TRY(resnet(x, &skip, m->up_res[i][j], &y, true));
         x = y;
-        if (i > 0) { Tensor z; GILL_TRY(xf(x, m->up_xf[i][j], &z, last)); x = z; }
+        if (i > 0) { Tensor z; GILL_TRY(xf(x, m->up_xf[i][j], &z, true)); x = z; }
       }
       if (i < 3) {
-        Tensor y = talloc(x.H * 2, x.W * 2, x.C);
+        Tensor y = talloc(x.H * 2, x.W * 2, x.C, true);
         GILL_TRY(conv(x, nullptr, m->up_us[i], 1, 1, nullptr, 0, nullptr, y));
         x = y;
       }
