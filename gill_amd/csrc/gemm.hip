@@ -317,6 +317,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) 
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < total_steps) issue(s);
+  // folded LayerNorm (GEGLU / QKV epilogues): the row factors are loaded here, under the first tile's DMA latency
+  float ln_rr[4] = {1.f, 1.f, 1.f, 1.f}, ln_rm[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == 1 || EPI == 3) {
+    if (p.ln_stats) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + frow;
+        if (m < p.M) ln_row_factors(p, m, ln_rr[i], ln_rm[i]);
+      }
+    }
+  }
   int buf = 0, buf_issue = STAGES - 1;
   int flat = 0;          // K steps consumed over all N tiles of this workgroup
   for (int t = 0; t < ntl; ++t, n0 += BN) {
@@ -380,13 +391,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) 
     }
   } else if constexpr (EPI == 1) {
     // weight rows are interleaved in 16-row blocks: even block = value rows, odd block = gate rows
-    float rr[4], rm[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      rr[i] = 1.f; rm[i] = 0.f;
-      const int m = mrow + i * 16;
-      if (p.ln_stats && m < p.M) ln_row_factors(p, m, rr[i], rm[i]);
-    }
+    const float* rr = ln_rr; const float* rm = ln_rm;
 #pragma unroll
     for (int j = 0; j + 1 < NT; j += 2) {
       const int nv = ncol + j * 16;         // physical column of the value block
@@ -417,8 +422,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) 
     for (int i = 0; i < 4; ++i) {
       const int m = mrow + i * 16;
       mok[i] = m < p.M;
-      rr[i] = p.alpha; rm[i] = 0.f;
-      if (p.ln_stats && mok[i]) ln_row_factors(p, m, rr[i], rm[i]);
+      rr[i] = p.ln_stats ? ln_rr[i] : p.alpha; rm[i] = ln_rm[i];
       const int b = m / p.ntok, t = m - b * p.ntok;
       rq[i] = (b * p.heads * p.ntok_pad_q + t) * p.dp;
       rk[i] = (b * p.heads * p.ntok_pad_kv + t) * p.dp;

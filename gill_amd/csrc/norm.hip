@@ -259,11 +259,10 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
   // The sums arrive in BINS of bin1 (bin2) channels: stats1 covers channels [0, sc1) of the (concatenated) input, stats2
   // the rest.  Producers accumulate bins finer than a group so that the same sums serve this tensor's own GroupNorm and
   // the wider groups of a later skip concatenation; a group's sum is the sum of the bins it covers.
-  __shared__ float gsum[64][2];
-  if (threadIdx.x < groups) {
-    const int g = threadIdx.x;
+  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+    const int g = ch / cg;
     const int lo = g * cg, hi = lo + cg;
-    float a = 0.f, q = 0.f;
+    float a = 0.f, q = 0.f;       // every channel thread adds up its group's few bins itself (L2-hot, no extra barrier)
     {
       const int nb1 = sc1 / bin1;
       const int e = hi < sc1 ? hi : sc1;
@@ -280,13 +279,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
         a += v.x; q += v.y;
       }
     }
-    gsum[g][0] = a; gsum[g][1] = q;
-  }
-  __syncthreads();
-  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
-    const int g = ch / cg;
-    const float sm = gsum[g][0] * inv_n;         // E[x]
-    const float sq = gsum[g][1] * inv_n;         // E[x^2]
+    const float sm = a * inv_n;         // E[x]
+    const float sq = q * inv_n;         // E[x^2]
     const float var = fmaxf(sq - sm * sm, 0.f);
     const float rstd = rsqrtf(var + eps);
     const float sc = rstd * gamma[ch];
