@@ -97,6 +97,46 @@ def build_model(dev, opt_cfg, unet_cfg, max_prompts):
   return g
 
 
+def pmc_traffic_gb(prompts_per_step):
+  """HBM bytes of one step from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+  WRITE_SIZE over this very command, corrected as MI355X_MICROARCH.md prescribes), scaled to this run's prompts per step.
+  bench.py cannot run a profiler around itself; None when the file is absent."""
+  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+  if not os.path.exists(path):
+    return None
+  with open(path) as f:
+    t = json.load(f)
+  kb = t["FETCH_SIZE_kb_hot_path"] * t["gfx950_fetch_correction"] + t["WRITE_SIZE_kb_hot_path"]
+  return kb * 1024.0 / 1e9 * (prompts_per_step / 4.0)
+
+
+def kernel_rooflines(dev):
+  """The three dominant device kernels of the UNet loop, each timed alone with HIP events on its level-0 shape of the CFG
+  batch 8 through the operator C ABI (gill_op_*): algorithmic FLOPs / average launch time."""
+  os.environ["GILL_OP_REPEAT"] = "20"      # read once by libgill_amd at the first gill_op_* call
+  from gill_amd import ops
+  out = []
+
+  def timed(fn, flops, name):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    out.append({"kernel": name, "avg_launch_us": us, "achieved": flops / us / 1e6, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops / us / 1e6 / PEAK_BF16_TFLOPS, "bound": "mfma"})
+
+  x = torch.randn(8, 64, 64, 320, device=dev).bfloat16()
+  w = torch.randn(320, 320, 3, 3, device=dev) * 0.02
+  timed(lambda: ops.conv3x3(x, w), 2.0 * 8 * 4096 * 320 * 2880, "gemm_kernel<160,1,0,2>: 3x3 conv 320->320 @ 64x64 x 8 (implicit GEMM)")
+  q = torch.randn(8, 4096, 320, device=dev).bfloat16()
+  timed(lambda: ops.attention(q, q, q, 8), 4.0 * 8 * 8 * 4096 * 4096 * 40, "attention_kernel<48>: self-attention N=4096, 8 heads x d=40, x 8 (incl. head re-layout wrappers)")
+  a = torch.randn(32768, 1280, device=dev).bfloat16()
+  wl = (torch.randn(320, 1280, device=dev) * 0.03).bfloat16()
+  timed(lambda: ops.gemm(a, wl), 2.0 * 32768 * 320 * 1280, "gemm_kernel<160,0,0,2>: GEMM 32768 x 320 x 1280 (FF out projection)")
+  return out
+
+
 def cpu_baseline(n_infer_steps):
   """The CPU oracle timed on this host's cores on a bounded sample of the same workload: ONE full-size SD-1.5 UNet
   forward of the CFG pair (batch 2) + the GILLMapper, extrapolated to images/s (OPT-6.7b fp32 would need 27 GB and
@@ -217,10 +257,12 @@ def main():
                              f"{a.infer_steps} PLMS steps ({a.infer_steps + 1} UNet calls, CFG 7.5, batch {2 * P}), final latents "
                              f"all-gathered, then VAE decode of the local shard to uint8 512x512 ({vae_ms:.1f} ms per {P} images)", "parallelism": f"dp{world}"},
       "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                   "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                   "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic_gb(P), "traffic_unit": "GB per step (PMC, profiles/r01_pmc_traffic.json)",
                    "kernel": "SD-1.5 UNet denoise loop (gill_sd_denoise: MFMA GEMM/implicit-conv + flash attention kernels)",
                    "algorithmic_tflop_per_launch": flop_per_call, "avg_launch_ms": unet_ms},
     }
+    if world == 1 and not a.small:
+      rec["roofline_kernels"] = kernel_rooflines(dev)
     if not a.no_cpu_baseline and world == 1:
       rec["cpu_baseline"] = cpu_baseline(a.infer_steps)
     else:

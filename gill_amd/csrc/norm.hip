@@ -242,8 +242,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ x2, int C2, int HW, int groups,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, int silu,
-                                                              const float* __restrict__ stats1, int bin1, int sc1,
-                                                              const float* __restrict__ stats2, int bin2,
+                                                              const float* __restrict__ stats1, int nb1, int r1,
+                                                              const float* __restrict__ stats2, int nb2, int r2, int o2,
                                                               bf16_t* __restrict__ y, int64_t total_vec) {
   // block = (b, slab of GN_APPLY_ROWS pixels).  Phase 1: fold statistics and affine into per-channel (scale, shift) in
   // LDS once per block; phase 2: y = [silu](x * scale + shift), 16-B loads and stores.
@@ -261,20 +261,22 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
   // the wider groups of a later skip concatenation; a group's sum is the sum of the bins it covers.
   for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
     const int g = ch / cg;
-    const int lo = g * cg, hi = lo + cg;
+    // bin index space (no divisions): group g covers bins [g*r1, (g+1)*r1) of block 1 (clipped to its nb1 bins) and bins
+    // [g*r2 - o2, (g+1)*r2 - o2) of block 2 (clipped at 0); r = bins per group, o2 = block-1 channels in units of bin2
     float a = 0.f, q = 0.f;       // every channel thread adds up its group's few bins itself (L2-hot, no extra barrier)
     {
-      const int nb1 = sc1 / bin1;
-      const int e = hi < sc1 ? hi : sc1;
-      for (int bin = lo / bin1; bin * bin1 < e; ++bin) {
+      int e = (g + 1) * r1;
+      if (e > nb1) e = nb1;
+      for (int bin = g * r1; bin < e; ++bin) {
         const float2 v = *reinterpret_cast<const float2*>(stats1 + ((size_t)b * nb1 + bin) * 2);
         a += v.x; q += v.y;
       }
     }
-    if (stats2 && hi > sc1) {
-      const int nb2 = (C - sc1) / bin2;
-      const int s0 = (lo > sc1 ? lo : sc1) - sc1, e = hi - sc1;
-      for (int bin = s0 / bin2; bin * bin2 < e; ++bin) {
+    if (stats2) {
+      int s0 = g * r2 - o2;
+      const int e = s0 + r2;
+      if (s0 < 0) s0 = 0;
+      for (int bin = s0; bin < e; ++bin) {
         const float2 v = *reinterpret_cast<const float2*>(stats2 + ((size_t)b * nb2 + bin) * 2);
         a += v.x; q += v.y;
       }
@@ -350,9 +352,11 @@ int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, i
                "groupnorm: group boundaries must fall on statistics bin boundaries");
   GILL_REQUIRE(sc1 == C || (stats2 != nullptr && bin2 > 0 && (C - sc1) % bin2 == 0), "groupnorm: second statistics block missing");
   const int64_t total_vec = (int64_t)B * HW * (C / 8);
+  const int cg = C / groups;   // bins_align() guarantees cg, sc1 (and the block-2 offsets) are whole numbers of bins
   dim3 g2(cdiv(HW, GN_APPLY_ROWS), B);
   hipLaunchKernelGGL(groupnorm_apply_kernel, g2, dim3(256), sizeof(float) * 2 * C, s, x1, C1, x2, C2, HW, groups, gamma, beta,
-                     eps, silu, stats1, bin1, sc1, stats2, bin2, y, total_vec);
+                     eps, silu, stats1, sc1 / bin1, cg / bin1, stats2, stats2 ? (C - sc1) / bin2 : 0, stats2 ? cg / bin2 : 0,
+                     stats2 ? sc1 / bin2 : 0, y, total_vec);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }
