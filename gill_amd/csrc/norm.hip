@@ -244,22 +244,23 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
                                                               const float* __restrict__ beta, float eps, int silu,
                                                               const float* __restrict__ stats1, int nb1, int r1,
                                                               const float* __restrict__ stats2, int nb2, int r2, int o2,
-                                                              bf16_t* __restrict__ y, int64_t total_vec) {
-  // block = (b, slab of GN_APPLY_ROWS pixels).  Phase 1: fold statistics and affine into per-channel (scale, shift) in
-  // LDS once per block; phase 2: y = [silu](x * scale + shift), 16-B loads and stores.
-  extern __shared__ __attribute__((aligned(16))) float gn_ss[];   // [C] scale | [C] shift
-  (void)total_vec;
+                                                              bf16_t* __restrict__ y, int rows, int cc) {
+  // block = (slab of `rows` pixels, sample b, chunk of cc <= 256 channels).  Phase 1: fold statistics and affine into
+  // per-channel (scale, shift) in LDS — one channel per thread, so the dependent loads of the prologue are paid once,
+  // not C/256 times; phase 2: y = [silu](x * scale + shift), 16-B loads and stores.
+  __shared__ __attribute__((aligned(16))) float gn_ss[512];   // [cc] scale | [cc] shift
   const int C = C1 + C2;
   const int cg = C / groups;
-  const int vec_per_row = C / 8;
+  const int vec_per_row = cc / 8;
   const int b = blockIdx.y;
+  const int c0 = blockIdx.z * cc;
   const float inv_n = 1.f / ((float)cg * (float)HW);
-  float* scale = gn_ss;
-  float* shift = gn_ss + C;
+  float* scale = gn_ss - c0;          // indexed by absolute channel
+  float* shift = gn_ss + 256 - c0;
   // The sums arrive in BINS of bin1 (bin2) channels: stats1 covers channels [0, sc1) of the (concatenated) input, stats2
   // the rest.  Producers accumulate bins finer than a group so that the same sums serve this tensor's own GroupNorm and
   // the wider groups of a later skip concatenation; a group's sum is the sum of the bins it covers.
-  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+  for (int ch = c0 + threadIdx.x; ch < c0 + cc; ch += blockDim.x) {
     const int g = ch / cg;
     // bin index space (no divisions): group g covers bins [g*r1, (g+1)*r1) of block 1 (clipped to its nb1 bins) and bins
     // [g*r2 - o2, (g+1)*r2 - o2) of block 2 (clipped at 0); r = bins per group, o2 = block-1 channels in units of bin2
@@ -290,13 +291,13 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
     shift[ch] = beta[ch] - sm * sc;
   }
   __syncthreads();
-  const int p0 = blockIdx.x * GN_APPLY_ROWS;
-  int p1 = p0 + GN_APPLY_ROWS;
+  const int p0 = blockIdx.x * rows;
+  int p1 = p0 + rows;
   if (p1 > HW) p1 = HW;
   const int nwork = (p1 - p0) * vec_per_row;
   for (int i = threadIdx.x; i < nwork; i += blockDim.x) {
     const int pr = i / vec_per_row;
-    const int c = (i - pr * vec_per_row) * 8;
+    const int c = c0 + (i - pr * vec_per_row) * 8;
     const int64_t row = (int64_t)b * HW + p0 + pr;
     const bf16_t* src;
     if (c < C1) src = x1 + row * C1 + c; else src = x2 + row * C2 + (c - C1);
@@ -351,12 +352,17 @@ int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, i
   GILL_REQUIRE(groupnorm_bins_align(C / groups, sc1, bin1, (stats2 || sc1 < C) ? bin2 : 0),
                "groupnorm: group boundaries must fall on statistics bin boundaries");
   GILL_REQUIRE(sc1 == C || (stats2 != nullptr && bin2 > 0 && (C - sc1) % bin2 == 0), "groupnorm: second statistics block missing");
-  const int64_t total_vec = (int64_t)B * HW * (C / 8);
   const int cg = C / groups;   // bins_align() guarantees cg, sc1 (and the block-2 offsets) are whole numbers of bins
-  dim3 g2(cdiv(HW, GN_APPLY_ROWS), B);
-  hipLaunchKernelGGL(groupnorm_apply_kernel, g2, dim3(256), sizeof(float) * 2 * C, s, x1, C1, x2, C2, HW, groups, gamma, beta,
+  // channel chunks of <= 256 (whole 8-channel vectors); slabs of 32 rows, fewer while the grid is short of ~4 blocks per CU
+  int nch = cdiv(C, 256);
+  while (C % (8 * nch) != 0) ++nch;
+  const int cc = C / nch;
+  int rows = GN_APPLY_ROWS;
+  while (rows > 4 && (int64_t)cdiv(HW, rows) * B * nch < 1024) rows >>= 1;
+  dim3 g2(cdiv(HW, rows), B, nch);
+  hipLaunchKernelGGL(groupnorm_apply_kernel, g2, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, gamma, beta,
                      eps, silu, stats1, sc1 / bin1, cg / bin1, stats2, stats2 ? (C - sc1) / bin2 : 0, stats2 ? cg / bin2 : 0,
-                     stats2 ? sc1 / bin2 : 0, y, total_vec);
+                     stats2 ? sc1 / bin2 : 0, y, rows, cc);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }
