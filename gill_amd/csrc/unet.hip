@@ -418,6 +418,9 @@ struct UNetRun {
   const float* temb_rows;   // row for sample 0
   int temb_bstride;         // 0: every sample uses the same row
   bool dry;
+  // classifier-free-guidance pair: samples b and b + Bx/2 carry the same latents and timestep and differ only in the prompt,
+  // so everything before the first cross-attention runs once on the first half (gill_sd_denoise sets this)
+  bool cfg_pair = false;
 
   float* stats_slot() {   // next pre-zeroed slot of the per-forward pool (the dry run counts them)
     float* p = dry ? nullptr : m->gn_stats + (size_t)m->gn_next * m->gn_slot_floats;
@@ -537,18 +540,26 @@ struct UNetRun {
     return attention_launch(a, s);
   }
 
-  int xf(const Tensor& x, const XfW& w, Tensor* out, bool out_stats) {
-    const int H = x.H, Wd = x.W, C = w.C, HW = H * Wd, M = Bx * HW;
+  // shared: `x` (and Bx on entry) cover only the first half of a CFG pair; the block runs at that half batch up to the end of
+  // the self-attention, then the residual stream is duplicated and the rest runs on the full pair (Bx restored on return)
+  int xf(const Tensor& x, const XfW& w, Tensor* out, bool out_stats, bool shared = false) {
+    const int Bpre = Bx, Bfull = shared ? 2 * Bx : Bx;
+    Bx = Bfull;                    // every buffer is sized for the full batch
+    const int H = x.H, Wd = x.W, C = w.C, HW = H * Wd, M = Bfull * HW, M1 = Bpre * HW;
     const int nh = m->cfg.num_heads, hdp = nh * w.dp;
     *out = talloc(H, Wd, C, out_stats);
     const size_t mk = m->arena.mark();
     Tensor n = talloc(H, Wd, C);
+    Tensor xd = x;                 // the outer residual at full batch
+    if (shared) xd = talloc(H, Wd, C);
+    Bx = Bpre;
     GILL_TRY(gnorm(x, nullptr, w.gn, 1e-6f, 0, n));
+    Bx = Bfull;
     Tensor t = talloc(H, Wd, C);   // transformer residual stream
     // norm1/2/3 never materialise: the GEMM that writes the residual stream also accumulates each row's sum and sum of
     // squares, and the projection that follows applies mean / rstd in its epilogue on weights pre-multiplied by the LN gain
     float* st1 = ln_slot(M); float* st2 = ln_slot(M); float* st3 = ln_slot(M);
-    GILL_TRY(linear(n.p, C, nullptr, 0, C, M, w.proj_in.w, w.proj_in.b, C, C, nullptr, ACT_NONE, t.p, C, nullptr, st1));
+    GILL_TRY(linear(n.p, C, nullptr, 0, C, M1, w.proj_in.w, w.proj_in.b, C, C, nullptr, ACT_NONE, t.p, C, nullptr, st1));
     const int hw_pad = round_up(HW, 32);   // kv tiles are 32 wide; pad rows hold finite stale data and are masked
     bf16_t* q = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * nh * hw_pad * w.dp);
     bf16_t* k = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * nh * hw_pad * w.dp);
@@ -557,15 +568,24 @@ struct UNetRun {
     // --- self attention
     {
       GemmArgs g;
-      g.M = M; g.N = 3 * hdp; g.K = C; g.K1 = C; g.A = t.p; g.lda = C; g.W = w.wqkv1;
+      g.M = M1; g.N = 3 * hdp; g.K = C; g.K1 = C; g.A = t.p; g.lda = C; g.W = w.wqkv1;
       g.ln_stats = st1; g.ln_colsum = w.s_qkv1; g.bias = w.c_qkv1;
       g.out_mode = OUT_QKV; g.Cq = q; g.Ck = k; g.Cvt = vt; g.heads = nh; g.dp = w.dp; g.dpv = w.dpv;
       g.ntok = HW; g.ntok_pad_q = hw_pad; g.ntok_pad_kv = hw_pad; g.seg_base = 0;
       g.qscale = 1.4426950408889634f / sqrtf((float)w.d);
       GILL_TRY(gemm(g));
     }
+    Bx = Bpre;
     GILL_TRY(attend(q, k, vt, o, HW, HW, hw_pad, hw_pad, w));
-    GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M, w.out1.w, w.out1.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, st2));
+    Bx = Bfull;
+    GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M1, w.out1.w, w.out1.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, st2));
+    if (shared && !dry) {
+      // second half of the pair := first half (residual stream, its LayerNorm row sums, the block input)
+      GILL_CHECK_HIP(hipMemcpyAsync(t.p + (size_t)M1 * C, t.p, sizeof(bf16_t) * (size_t)M1 * C, hipMemcpyDeviceToDevice, s));
+      GILL_CHECK_HIP(hipMemcpyAsync(st2 + (size_t)M1 * 2, st2, sizeof(float) * (size_t)M1 * 2, hipMemcpyDeviceToDevice, s));
+      GILL_CHECK_HIP(hipMemcpyAsync(xd.p, x.p, sizeof(bf16_t) * (size_t)M1 * C, hipMemcpyDeviceToDevice, s));
+      GILL_CHECK_HIP(hipMemcpyAsync(xd.p + (size_t)M1 * C, x.p, sizeof(bf16_t) * (size_t)M1 * C, hipMemcpyDeviceToDevice, s));
+    }
     // --- cross attention (K/V cached per prompt)
     {
       GemmArgs g;
@@ -589,7 +609,7 @@ struct UNetRun {
     }
     GILL_TRY(linear(ffh, 4 * C, nullptr, 0, 4 * C, M, w.ff2.w, w.ff2.b, C, 4 * C, t.p, ACT_NONE, t.p, C));
     // --- proj_out + outer residual
-    GILL_TRY(linear(t.p, C, nullptr, 0, C, M, w.proj_out.w, w.proj_out.b, C, C, x.p, ACT_NONE, out->p, C, out));
+    GILL_TRY(linear(t.p, C, nullptr, 0, C, M, w.proj_out.w, w.proj_out.b, C, C, xd.p, ACT_NONE, out->p, C, out));
     m->arena.release(mk);
     return 0;
   }
@@ -620,10 +640,14 @@ struct UNetRun {
     for (int i = 0; i < 4; ++i) {
       for (int j = 0; j < 2; ++j) {
         Tensor y;
+        // CFG pair: the first resnet and the first transformer block up to its self-attention see identical inputs in
+        // both halves of the batch -> run them on the first half only (xf() widens back to the full batch)
+        const bool share = cfg_pair && i == 0 && j == 0 && Bx % 2 == 0 && temb_bstride == 0;
+        if (share) Bx /= 2;
         GILL_TRY(resnet(x, nullptr, m->down_res[i][j], &y, true));
         x = y;
         // next consumer: resnet norm1 (j == 0) / the downsample conv or the mid block's norm1 (j == 1)
-        if (i < 3) { Tensor z; GILL_TRY(xf(x, m->down_xf[i][j], &z, true)); x = z; }   // next GroupNorm and / or a skip
+        if (i < 3) { Tensor z; GILL_TRY(xf(x, m->down_xf[i][j], &z, true, share)); x = z; }   // next GroupNorm and / or a skip
         skips.push_back(x);
       }
       if (i < 3) {
@@ -671,6 +695,13 @@ static int unet_plan_and_alloc(gill_unet* m) {
   m->kcache.assign(m->n_xf, nullptr); m->vcache.assign(m->n_xf, nullptr);
   UNetRun r{m, nullptr, Bx, nullptr, 0, true};
   GILL_TRY(r.forward(nullptr, nullptr));
+  if (Bx % 2 == 0) {               // the CFG shared-prefix path allocates differently: size for the larger of the two
+    const int gn1 = m->gn_next; const size_t ln1 = m->ln_next;
+    r.cfg_pair = true;
+    GILL_TRY(r.forward(nullptr, nullptr));   // (arena.high is a running maximum)
+    if (gn1 > m->gn_next) m->gn_next = gn1;
+    if (ln1 > m->ln_next) m->ln_next = ln1;
+  }
   const size_t need = m->arena.high + (1 << 20);
   GILL_TRY(m->pool.alloc(&m->arena_mem, need, true));
   m->arena.base = m->arena_mem; m->arena.cap = need; m->arena.dry = false; m->arena.off = 0;
@@ -849,7 +880,7 @@ extern "C" int gill_sd_denoise(gill_unet* m, const void* cond_bf16, const void* 
     // time-embedding row, is staged into a fixed buffer in front of each replay.
     GILL_CHECK_HIP(hipMemcpyAsync(m->temb_cur, m->temb_table + (size_t)i * m->temb_total, sizeof(float) * m->temb_total,
                                   hipMemcpyDeviceToDevice, s));
-    const int gkey = Bx;
+    const int gkey = Bx * 2 + (cfg ? 1 : 0);
     auto git = m->graphs.find(gkey);
     if (git == m->graphs.end() && m->use_graph && m->warmed.count(gkey)) {
       hipGraph_t graph = nullptr;
@@ -859,6 +890,7 @@ extern "C" int gill_sd_denoise(gill_unet* m, const void* cond_bf16, const void* 
       if (!m->cap_stream) GILL_CHECK_HIP(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
       GILL_CHECK_HIP(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
       UNetRun rc{m, m->cap_stream, Bx, m->temb_cur, 0, false};
+      rc.cfg_pair = cfg;
       const int rc_status = rc.forward(m->lat2, m->eps);
       const hipError_t ec = hipStreamEndCapture(m->cap_stream, &graph);
       if (rc_status != 0) { if (graph) (void)hipGraphDestroy(graph); return rc_status; }
@@ -873,6 +905,7 @@ extern "C" int gill_sd_denoise(gill_unet* m, const void* cond_bf16, const void* 
       // first forward of this batch size runs eagerly: it also performs every one-time kernel attribute set-up,
       // which must not happen inside a stream capture
       UNetRun r{m, s, Bx, m->temb_cur, 0, false};
+      r.cfg_pair = cfg;
       GILL_TRY(r.forward(m->lat2, m->eps));
       m->warmed.insert(gkey);
     }

@@ -55,3 +55,29 @@ def main():
 
 if __name__ == "__main__":
   main()
+
+
+def per_shape(dbpath, out=None):
+  """Break the GEMM / attention / GroupNorm kernels down by launch grid (one grid == one layer shape)."""
+  db = sqlite3.connect(dbpath)
+  cur = db.cursor()
+  rows = cur.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x from kernels").fetchall()
+  agg = {}
+  for n, s, e, gx, gy, gz, wx in rows:
+    k = short(n)
+    if not any(t in k for t in ("gemm_", "attention_", "groupnorm_", "conv_out")):
+      continue
+    key = (k, gx // max(wx, 1), gy, gz)
+    a = agg.setdefault(key, [0, 0])
+    a[0] += 1; a[1] += e - s
+  lines = ["", "## per-shape breakdown (grid in workgroups)", "", "| kernel | grid | calls | total ms | avg us |", "|---|---|---|---|---|"]
+  for (k, gx, gy, gz), a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:48]:
+    lines.append(f"| `{k}` | ({gx},{gy},{gz}) | {a[0]} | {a[1] / 1e6:.2f} | {a[1] / a[0] / 1e3:.1f} |")
+  txt = "\n".join(lines) + "\n"
+  if out:
+    open(out, "a").write(txt)
+  print(txt)
+
+
+if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[3] == "--per-shape":
+  per_shape(sys.argv[1], sys.argv[2])
