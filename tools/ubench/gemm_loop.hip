@@ -248,6 +248,117 @@ __global__ __launch_bounds__(512, 1) void k_gemm8(const bf16_t* __restrict__ A, 
   C[(size_t)blockIdx.x * 512 + tid] = result;
 }
 
+
+// BM = 256: 512 threads, waves 4 (M) x 2 (N), each 64 x 80 via 16x16x32 (the production per-wave code), one block per CU.
+template <int STAGES>
+__global__ __launch_bounds__(512, 1) void k_gemm256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, float* __restrict__ C,
+                                                    int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  constexpr int A_ELEMS = 256 * BK, B_ELEMS = BN * BK, BUF = A_ELEMS + B_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = N / BN;
+  const int tile = xcd_tile();
+  const int tn = tile % tiles_n, tm = tile / tiles_n;
+  const int m0 = tm * 256, n0 = tn * BN;
+  const int srow = lane >> 3;
+  const int nsteps = K / BK;
+  const bf16_t* a_ptr[4];
+  const bf16_t* w_ptr[3];
+  for (int i = 0; i < 4; ++i) {     // 32 row groups of 8 -> 4 per wave
+    int row = (i * 8 + w) * 8 + srow;
+    a_ptr[i] = A + (size_t)(m0 + row) * KW + ((lane & 7) ^ (row & 7)) * 8;
+  }
+  const int nw = w < 4 ? 3 : 2;      // 20 row groups of W
+  for (int i = 0; i < 3; ++i) {
+    int g = i * 8 + w; if (g > 19) g = 19;
+    int row = g * 8 + srow;
+    w_ptr[i] = W + (size_t)(n0 + row) * K + ((lane & 7) ^ (row & 7)) * 8;
+  }
+  int kcol = 0;
+  auto issue = [&](int buf) {
+    bf16_t* As = smem + buf * BUF;
+    bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[i],
+                                       (__attribute__((address_space(3))) void*)(As + (i * 8 + w) * 8 * BK), 16, 0, 0);
+      a_ptr[i] += BK;
+    }
+    if (++kcol == KW / BK) { kcol = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_ptr[i] -= KW; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i < nw) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
+                                         (__attribute__((address_space(3))) void*)(Bs + (i * 8 + w) * 8 * BK), 16, 0, 0);
+        w_ptr[i] += BK;
+      }
+    }
+  };
+  const int wm = w >> 1, wn = w & 1;
+  f32x4 acc[4][5];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+  const int frow = lane & 15, fkc = lane >> 4;
+  for (int s = 0; s < STAGES - 1; ++s) if (s < nsteps) issue(s);
+  int buf = 0, buf_issue = STAGES - 1;
+  for (int it = 0; it < nsteps; ++it) {
+    const int rem = nsteps - 1 - it;
+    const int fly = rem < STAGES - 2 ? rem : STAGES - 2;
+    if (w < 4) { if (fly >= 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    else       { if (fly >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_s_barrier();
+    const bf16_t* As = smem + buf * BUF;
+    const bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[4], bfr[5];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + frow;
+        af[i] = *reinterpret_cast<const bf16x8*>(As + row * BK + (((kk * 4 + fkc) ^ (row & 7)) * 8));
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int row = wn * 80 + j * 16 + frow;
+        bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * BK + (((kk * 4 + fkc) ^ (row & 7)) * 8));
+      }
+      if (kk == 0) {
+        if (it + STAGES - 1 < nsteps) issue(buf_issue);
+        buf_issue = (buf_issue + 1 == STAGES) ? 0 : buf_issue + 1;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+  }
+  float result = 0.f;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) result += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  C[(size_t)blockIdx.x * 512 + tid] = result;
+}
+
+template <int STAGES>
+void run256(const bf16_t* A, const bf16_t* W, float* C, int M, int N, int K, const char* what) {
+  constexpr int smem = STAGES * (256 * BK + BN * BK) * 2;
+  hipFuncSetAttribute((const void*)k_gemm256<STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  int grid = (M / 256) * (N / BN);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) k_gemm256<STAGES><<<grid, 512, smem>>>(A, W, C, M, N, K);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  const int R = 20;
+  for (int i = 0; i < R; ++i) k_gemm256<STAGES><<<grid, 512, smem>>>(A, W, C, M, N, K);
+  hipEventRecord(e1); hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double us = ms * 1e3 / R;
+  printf("%-44s stages=%d: %7.1f us  %6.0f TFLOP/s  (%.2f us per K step)  [%s]\n", what, STAGES, us, 2.0 * M * N * K / us / 1e6, us / (K / BK),
+         hipGetErrorString(hipGetLastError()));
+}
+
 template <int STAGES>
 void run8(const bf16_t* A, const bf16_t* W, float* C, int M, int N, int K, const char* what) {
   constexpr int smem = STAGES * (BM * BK + BN * BK) * 2;
@@ -316,6 +427,8 @@ int main(int argc, char** argv) {
   run<1, 1, 0, 1, 2>(A, W, C, M, N, K, "32x32x16 loads+barrier, no LDS reads");
   run<1, 1, 1, 1, 1>(A, W, C, M, N, K, "32x32x16 full, 1 block/CU");
   run<1, 0, 0, 0, 1>(A, W, C, M, N, K, "32x32x16 pure MFMA, 1 block/CU");
+  run256<2>(A, W, C, M, N, K, "256x160 tile, 8 waves 4x2, 1 block/CU");
+  run256<3>(A, W, C, M, N, K, "256x160 tile, 8 waves 4x2, 1 block/CU");
   run8<2>(A, W, C, M, N, K, "K8: 8 waves 128x160, 1 block/CU");
   run8<3>(A, W, C, M, N, K, "K8: 8 waves 128x160, 1 block/CU");
   run8<4>(A, W, C, M, N, K, "K8: 8 waves 128x160, 1 block/CU");
