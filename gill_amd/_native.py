@@ -57,6 +57,7 @@ SYMBOLS: Dict[str, Tuple[object, List[object]]] = {
   "gill_opt_destroy": (None, [_vp]),
   "gill_opt_embed": (_i, [_vp, _vp, _i, _vp, _vp]),
   "gill_opt_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+  "gill_opt_forward_cached": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
   "gill_opt_img_hidden": (_i, [_vp, _vp, C.POINTER(C.c_int32), _i, _i, _i, _vp, _vp, _vp]),
   "gill_opt_last_logits": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
   "gill_mapper_create": (_i, [C.POINTER(_vp), C.POINTER(gill_mapper_config), C.POINTER(gill_tensor), _i]),

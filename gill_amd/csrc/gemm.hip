@@ -106,9 +106,9 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0
       *reinterpret_cast<uint2*>(p.Cq + ((size_t)(b * p.heads + h) * p.ntok_pad_q + t) * p.dp + dd) = o;
     } else if (seg == 1) {
       uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-      *reinterpret_cast<uint2*>(p.Ck + ((size_t)(b * p.heads + h) * p.ntok_pad_kv + t) * p.dp + dd) = o;
+      *reinterpret_cast<uint2*>(p.Ck + ((size_t)(b * p.heads + h) * p.ntok_pad_kv + t + p.kv_tok_offset) * p.dp + dd) = o;
     } else {
-      bf16_t* base = p.Cvt + ((size_t)(b * p.heads + h) * p.dpv + dd) * p.ntok_pad_kv + t;
+      bf16_t* base = p.Cvt + ((size_t)(b * p.heads + h) * p.dpv + dd) * p.ntok_pad_kv + t + p.kv_tok_offset;
 #pragma unroll
       for (int i = 0; i < 4; ++i) base[(size_t)i * p.ntok_pad_kv] = f2bf(v[i]);
       if (dd + 4 == p.dp && p.dpv > p.dp) base[(size_t)4 * p.ntok_pad_kv] = (bf16_t)0x3F80;
@@ -425,8 +425,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) 
       rr[i] = p.ln_stats ? ln_rr[i] : p.alpha; rm[i] = ln_rm[i];
       const int b = m / p.ntok, t = m - b * p.ntok;
       rq[i] = (b * p.heads * p.ntok_pad_q + t) * p.dp;
-      rk[i] = (b * p.heads * p.ntok_pad_kv + t) * p.dp;
-      rv[i] = b * p.heads * p.dpv * p.ntok_pad_kv + t;
+      rk[i] = (b * p.heads * p.ntok_pad_kv + t + p.kv_tok_offset) * p.dp;
+      rv[i] = b * p.heads * p.dpv * p.ntok_pad_kv + t + p.kv_tok_offset;
     }
     const int hd = p.heads * p.dp;
 #pragma unroll

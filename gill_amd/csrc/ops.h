@@ -34,6 +34,7 @@ struct GemmArgs {
   bf16_t* Cq = nullptr; bf16_t* Ck = nullptr; bf16_t* Cvt = nullptr;
   int heads = 0, dp = 0, dpv = 0, ntok = 0, ntok_pad_q = 0, ntok_pad_kv = 0, seg_base = 0;
   float qscale = 1.f;   // multiplies the Q segment: softmax scale * log2(e) (attention.hip works in the log2 domain)
+  int kv_tok_offset = 0;  // K / Vt rows land at token t + kv_tok_offset (appending to a KV cache); Q rows stay at t
   // split-K (0/1 = off).  ws must hold splitk*M*N floats.
   int splitk = 1; float* ws = nullptr;
   // fused GroupNorm statistics of the output: gn_stats[(m / rows_per_batch)][gn_groups][2] += {sum, sum of squares}

@@ -37,6 +37,9 @@ struct gill_opt {
   bf16_t* last_bf = nullptr;  // [8][D]
   int32_t* idx_dev = nullptr; // [B*8 + B*8]
   float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
+  // KV cache of gill_opt_forward_cached (allocated at its first call): per layer K [B][H][Tcap][dp], Vt [B][H][dpv][Tcap]
+  std::vector<bf16_t*> kcache, vcache;
+  int cache_tcap = 0;
 };
 
 // out[row][:] = bf16->f32(emb[row][:]) + pos[t + off][:]
@@ -155,19 +158,26 @@ struct OptRun {
     g.ws = m->splitk_ws;
     return gemm_launch(g, s);
   }
-  // layers over the fp32 stream m->h (B*T rows)
-  int run_layers(int B, int T) {
+  // layers over the fp32 stream m->h (B*T rows).  past < 0: plain causal forward over T tokens.  past >= 0: the T rows are
+  // the tokens past .. past+T-1 of each sequence; their K/V are appended to the handle's cache and they attend to it.
+  int run_layers(int B, int T, int past = -1) {
     const gill_opt_config& c = m->cfg;
     const int D = c.hidden_size, F = c.ffn_dim, R = B * T;
     const int Tpad = round_up(T, 32);
+    const bool cached = past >= 0;
+    const int kvpad = cached ? m->cache_tcap : Tpad;
+    int li = 0;
     for (const OptLayer& L : m->layers) {
+      bf16_t* kbuf = cached ? m->kcache[li] : m->k;
+      bf16_t* vbuf = cached ? m->vcache[li] : m->vt;
+      ++li;
       GILL_TRY(layernorm_launch(m->h, 1, L.ln1g, L.ln1b, m->nbuf, R, D, 1e-5f, s));
       {
         GemmArgs g;
         g.M = R; g.N = 3 * D; g.K = D; g.K1 = D; g.A = m->nbuf; g.lda = D; g.W = L.wqkv; g.bias = L.bqkv;
-        g.out_mode = OUT_QKV; g.Cq = m->q; g.Ck = m->k; g.Cvt = m->vt;
-        g.heads = c.num_heads; g.dp = m->dp; g.dpv = m->dpv; g.ntok = T; g.ntok_pad_q = Tpad; g.ntok_pad_kv = Tpad;
-        g.seg_base = 0;
+        g.out_mode = OUT_QKV; g.Cq = m->q; g.Ck = kbuf; g.Cvt = vbuf;
+        g.heads = c.num_heads; g.dp = m->dp; g.dpv = m->dpv; g.ntok = T; g.ntok_pad_q = Tpad; g.ntok_pad_kv = kvpad;
+        g.seg_base = 0; g.kv_tok_offset = cached ? past : 0;
         g.qscale = 1.4426950408889634f / sqrtf((float)m->dp);   // HF scales q by head_dim^-0.5
         g.splitk = gemm_pick_splitk(R, 3 * D, D, 0);
         if ((size_t)g.splitk * R * 3 * D > m->splitk_ws_floats) g.splitk = 1;
@@ -176,8 +186,8 @@ struct OptRun {
       }
       {
         AttnArgs a;
-        a.Q = m->q; a.K = m->k; a.Vt = m->vt; a.O = m->o;
-        a.B = B; a.H = c.num_heads; a.nq = T; a.nkv = T; a.nq_pad = Tpad; a.nkv_pad = Tpad;
+        a.Q = m->q; a.K = kbuf; a.Vt = vbuf; a.O = m->o;
+        a.B = B; a.H = c.num_heads; a.nq = T; a.nkv = cached ? past + T : T; a.nq_pad = Tpad; a.nkv_pad = kvpad;
         a.dp = m->dp; a.dpv = m->dpv; a.ldo = D; a.scale = 1.0f / sqrtf((float)m->dp); a.causal = 1;
         GILL_TRY(attention_launch(a, s));
       }
@@ -203,6 +213,34 @@ extern "C" int gill_opt_forward(gill_opt* m, const void* inputs_embeds_bf16, int
   OptRun r{m, s};
   GILL_TRY(r.run_layers(B, T));
   if (hidden_out) GILL_TRY(layernorm_f32out_launch(m->h, 1, m->lnfg, m->lnfb, hidden_out, B * T, D, 1e-5f, s));
+  return 0;
+}
+
+extern "C" int gill_opt_forward_cached(gill_opt* m, const void* inputs_embeds_bf16, int B, int T_new, int past_len,
+                                       float* hidden_out, void* stream) {
+  GILL_REQUIRE(m && inputs_embeds_bf16 && hidden_out, "null argument");
+  GILL_REQUIRE(B >= 1 && B <= m->cfg.max_batch && T_new >= 1 && past_len >= 0 && past_len + T_new <= m->cfg.max_seq,
+               "B / past_len + T_new exceed the handle's workspace");
+  GILL_REQUIRE(past_len + T_new + 2 <= m->cfg.max_positions + 2, "sequence longer than the position table");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = m->cfg.hidden_size;
+  if (m->kcache.empty()) {
+    // zero-filled: rows beyond the valid length are masked in attention, but must stay finite (0 * NaN would poison PV)
+    m->cache_tcap = round_up(m->cfg.max_seq, 32);
+    const size_t kn = (size_t)m->cfg.max_batch * m->cfg.num_heads * m->cache_tcap * m->dp;
+    const size_t vn = (size_t)m->cfg.max_batch * m->cfg.num_heads * m->dpv * m->cache_tcap;
+    m->kcache.assign(m->layers.size(), nullptr); m->vcache.assign(m->layers.size(), nullptr);
+    for (size_t l = 0; l < m->layers.size(); ++l) {
+      GILL_TRY(m->pool.alloc(&m->kcache[l], kn, true));
+      GILL_TRY(m->pool.alloc(&m->vcache[l], vn, true));
+    }
+  }
+  hipLaunchKernelGGL(opt_add_pos_kernel, dim3(B * T_new), dim3(256), 0, s, (const bf16_t*)inputs_embeds_bf16, m->pos,
+                     2 + past_len, T_new, D, m->h);
+  GILL_CHECK_HIP(hipGetLastError());
+  OptRun r{m, s};
+  GILL_TRY(r.run_layers(B, T_new, past_len));
+  GILL_TRY(layernorm_f32out_launch(m->h, 1, m->lnfg, m->lnfb, hidden_out, B * T_new, D, 1e-5f, s));
   return 0;
 }
 

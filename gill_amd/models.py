@@ -257,6 +257,17 @@ class GILLModel(nn.Module):
       N.check(N.lib().gill_opt_forward(h, N.ptr(x), B, T, N.ptr(out), N.current_stream()))
     return out
 
+  def _lm_forward_hidden_cached(self, new_embeds: Tensor, past_len: int) -> Tensor:
+    """hidden_states[-1] rows of the tokens past_len .. past_len+T_new-1, computed against the handle's KV cache
+    (gill_opt_forward_cached).  past_len == 0 starts a new sequence."""
+    B, Tn, D = new_embeds.shape
+    h = self._opt_native(B, past_len + Tn)      # never grows mid-sequence: generate() sizes the handle up front
+    x = new_embeds.to(torch.bfloat16).contiguous()
+    out = torch.empty((B, Tn, D), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+      N.check(N.lib().gill_opt_forward_cached(h, N.ptr(x), B, Tn, past_len, N.ptr(out), N.current_stream()))
+    return out
+
   def img_hidden_states(self, labels: Tensor, last_embedding_idx: Tensor):
     """Fast path of forward(mode='generation'): (B,T) ids, (B,) idx -> (raw (B,8,D), embs (B,8,D)) bf16."""
     B, T = labels.shape
@@ -305,8 +316,11 @@ class GILLModel(nn.Module):
 
   def generate(self, embeddings=torch.FloatTensor, max_len: int = 32, temperature: float = 0.0, top_p: float = 1.0,
                min_word_tokens: int = 0, ret_scale_factor: float = 1.0, gen_scale_factor: float = 1.0,
-               filter_value: float = -float('Inf')):
-    """Greedy / top-p decoding without KV cache, as the reference does it (models.py:443-532).
+               filter_value: float = -float('Inf'), use_kv_cache: bool = True):
+    """Greedy / top-p decoding, same loop and outputs as the reference (models.py:443-532).  The reference re-runs the
+    whole sequence through the LM at every step; with use_kv_cache (default) only the tokens appended since the last
+    step go through the layers, against keys/values cached in the native handle — causal attention makes the hidden
+    states of earlier positions independent of later tokens, so the outputs are the same up to rounding.
     Outputs: out (N,T) token ids, output_embeddings list of hidden_states[-1], output_logits list (N, vocab)."""
     with torch.no_grad():
       out = None
@@ -314,8 +328,16 @@ class GILLModel(nn.Module):
       output_logits = []
       dev = embeddings.device
       vocab = self.opt_cfg.vocab_size
+      hidden = None
+      if use_kv_cache:   # the cache lives in the handle: size it for the longest sequence this call can produce
+        self._opt_native(embeddings.shape[0], embeddings.shape[1] + max_len + len(self.retrieval_token_idx))
       for i in range(max_len):
-        hidden = self._lm_forward_hidden(embeddings)                           # :465
+        if use_kv_cache:
+          past = 0 if hidden is None else hidden.shape[1]
+          new_hidden = self._lm_forward_hidden_cached(embeddings[:, past:], past)
+          hidden = new_hidden if hidden is None else torch.cat([hidden, new_hidden], dim=1)
+        else:
+          hidden = self._lm_forward_hidden(embeddings)                         # :465
         for idx in self.args.text_emb_layers:
           output_embeddings.append(hidden.to(embeddings.dtype))                # :467-468
         B, T, D = hidden.shape

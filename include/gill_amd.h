@@ -67,6 +67,14 @@ int gill_opt_embed(gill_opt* h, const int64_t* ids, int n, void* out_bf16, void*
  * hidden_out may be NULL when only gathered rows are wanted (see gill_opt_img_hidden). */
 int gill_opt_forward(gill_opt* h, const void* inputs_embeds_bf16, int B, int T, float* hidden_out, void* stream);
 
+/* KV-cached continuation of the same forward for the decode loop of GILLModel.generate (models.py:464-530; the reference
+ * re-runs the whole sequence every step with use_cache unset).  inputs_embeds (B,T_new,D) bf16 are the tokens
+ * past_len .. past_len+T_new-1 of each sequence; their keys/values are appended to the handle's cache and they attend to
+ * cache[0, past_len) plus, causally, to each other.  past_len = 0 starts a new sequence (prefill).  The caller keeps B
+ * fixed and past_len equal to the number of tokens already fed.  hidden_out (B,T_new,D) fp32 = hidden_states[-1] rows. */
+int gill_opt_forward_cached(gill_opt* h, const void* inputs_embeds_bf16, int B, int T_new, int past_len, float* hidden_out,
+                            void* stream);
+
 /* The fast path of GILLModel.forward(mode='generation') (models.py:180-183, 384-385):
  *   ids (B,T) int64 right-padded, last_idx (B) int32 HOST array = caption_len-1;
  *   raw_out (B,8,D) bf16 = hidden_states[-1][i, last-7:last+1];  emb_out (B,8,D) bf16 = input_embs slice. */

@@ -105,6 +105,31 @@ def test_generate_loop_and_public_api_vs_reference_golden(cuda, gill125):
   assert gen.shape == (1, 77, 768) and mse < 1e-4
 
 
+def test_generate_kv_cache_matches_full_reforward(cuda, gill125):
+  """the KV-cached decode loop against the reference-style full re-forward (which the golden
+  test above pins to the reference's own output): same greedy tokens, same hidden states, batch 2, 12 steps."""
+  ids = synth.synthetic_prompt_ids(2, 9, seed=11)[:, :9].to(cuda)
+  emb = gill125.model.input_embeddings(ids)
+  kw = dict(min_word_tokens=12, temperature=0.0)        # [IMG] suppressed: 12 ordinary greedy steps
+  out_c, embs_c, logits_c = gill125.model.generate(emb, 12, use_kv_cache=True, **kw)
+  out_f, embs_f, logits_f = gill125.model.generate(emb, 12, use_kv_cache=False, **kw)
+  assert out_c.shape == (2, 12)
+  assert out_c.cpu().tolist() == out_f.cpu().tolist()
+  assert len(embs_c) == len(embs_f) == 12 and embs_c[-1].shape == embs_f[-1].shape == (2, 9 + 11, 768)
+  _, rel, cos = _stats("kv-cache vs re-forward hidden", embs_c[-1], embs_f[-1])
+  assert rel < 2e-2 and cos > 0.999
+  fin = torch.isfinite(logits_f[-1])                    # the [IMG] columns are filtered to -inf in both
+  assert torch.equal(fin, torch.isfinite(logits_c[-1]))
+  _, rel_l, _ = _stats("kv-cache vs re-forward last logits", logits_c[-1][fin], logits_f[-1][fin])
+  assert rel_l < 2e-2
+  # a forced 8-token [IMG] block goes through the cache as one multi-token step (T_new = 8)
+  out_i, embs_i, _ = gill125.model.generate(emb[:1], 3, gen_scale_factor=1e5, use_kv_cache=True)
+  out_j, embs_j, _ = gill125.model.generate(emb[:1], 3, gen_scale_factor=1e5, use_kv_cache=False)
+  assert out_i.cpu().tolist() == out_j.cpu().tolist() and out_i.shape[1] == 24
+  _, rel_i, _ = _stats("kv-cache vs re-forward hidden ([IMG] blocks)", embs_i[-1], embs_j[-1])
+  assert rel_i < 2e-2
+
+
 def test_opt_forward_vs_oracle_causal_lengths(cuda, gill125):
   """Single OPT pass at several sequence lengths (kv tile edges 31/32/33, 64, 100) against the oracle."""
   from oracle import opt_ref
