@@ -42,6 +42,11 @@ class gill_unet_config(C.Structure):
               ("max_batch", C.c_int32)]
 
 
+class gill_clip_config(C.Structure):
+  _fields_ = [(n, C.c_int32) for n in ("image_size", "patch_size", "hidden_size", "num_layers", "num_heads", "intermediate_size",
+                                       "max_batch")]
+
+
 class gill_vae_config(C.Structure):
   _fields_ = [("latent_channels", C.c_int32), ("out_channels", C.c_int32), ("block_out_channels", C.c_int32 * 4),
               ("layers_per_block", C.c_int32), ("norm_num_groups", C.c_int32), ("latent_size", C.c_int32),
@@ -60,6 +65,9 @@ SYMBOLS: Dict[str, Tuple[object, List[object]]] = {
   "gill_opt_forward_cached": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
   "gill_opt_img_hidden": (_i, [_vp, _vp, C.POINTER(C.c_int32), _i, _i, _i, _vp, _vp, _vp]),
   "gill_opt_last_logits": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+  "gill_clip_create": (_i, [C.POINTER(_vp), C.POINTER(gill_clip_config), C.POINTER(gill_tensor), _i]),
+  "gill_clip_destroy": (None, [_vp]),
+  "gill_clip_forward": (_i, [_vp, _vp, _i, _vp, _vp]),
   "gill_mapper_create": (_i, [C.POINTER(_vp), C.POINTER(gill_mapper_config), C.POINTER(gill_tensor), _i]),
   "gill_mapper_destroy": (None, [_vp]),
   "gill_mapper_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),

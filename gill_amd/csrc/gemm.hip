@@ -60,6 +60,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == ACT_RELU) return fmaxf(v, 0.f);
   if (act == ACT_SILU) return silu_f(v);
   if (act == ACT_GELU) return gelu_erf_call(v);
+  if (act == ACT_QUICK_GELU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));
   return v;
 }
 

@@ -4,7 +4,7 @@
 #pragma once
 #include "common.h"
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_GEGLU = 4 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_GEGLU = 4, ACT_QUICK_GELU = 5 /* x*sigmoid(1.702x): CLIP */ };
 enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_QKV = 2 };
 
 // C[M,N] = epilogue( alpha * A[M,K] . W[N,K]^T )       (bf16 operands, fp32 MFMA accumulate)

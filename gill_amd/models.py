@@ -32,7 +32,7 @@ from torch import Tensor
 
 from . import _native as N
 from . import layers, utils
-from .synth import OptConfig
+from .synth import ClipConfig, OptConfig
 
 
 class GILLArgs:
@@ -100,7 +100,7 @@ class GILLModel(nn.Module):
   def __init__(self, tokenizer, args: GILLArgs = GILLArgs()):
     super().__init__()
     self.tokenizer = tokenizer
-    self.feature_extractor = None   # CLIP image preprocessing: image prompts are out of scope of this path
+    self.feature_extractor = utils.get_feature_extractor_for_model(args.visual_encoder, train=False)   # models.py:48
     self.image_token = self.tokenizer.cls_token_id
     assert args.text_emb_layers != set(args.text_emb_layers), 'text_emb_layers not unique'
     self.args = args
@@ -126,9 +126,17 @@ class GILLModel(nn.Module):
     self.gen_token_idx = args.gen_token_idx
     self.input_embeddings = _NativeEmbedding(self, self.lm.model.decoder.embed_tokens.weight)
 
-    hidden_size = self._clip_hidden(visual_encoder)
     self.visual_model_name = visual_encoder
-    self.visual_model = None        # frozen CLIP-ViT: not on the text->image path (get_visual_embs 'generation' ignores pixels)
+    # frozen CLIP vision tower (models.py:78-96): a parameter container; its forward runs in libgill_amd (gill_clip_*).
+    # Weights: args.clip_state_dict (synthetic / pre-loaded), a local Hugging Face directory, or absent — then text prompts
+    # work as always and image prompts raise.
+    self.clip_cfg, clip_state = self._load_clip(visual_encoder, getattr(args, 'clip_state_dict', None),
+                                                getattr(args, 'clip_config', None))
+    self.visual_model = _ParamTree(clip_state) if clip_state is not None else None
+    hidden_size = self.clip_cfg.hidden_size if self.clip_cfg is not None else self._clip_hidden(visual_encoder)
+    if self.clip_cfg is not None and self.clip_cfg.image_size != self.feature_extractor.size:
+      self.feature_extractor = utils.ClipImageProcessor(self.clip_cfg.image_size, self.clip_cfg.image_size)
+    self._clip_handle = None
 
     embedding_dim = self.input_embeddings.embedding_dim * self.args.n_visual_tokens
     self.ret_text_hidden_fcs = nn.ModuleList([])
@@ -192,6 +200,54 @@ class GILLModel(nn.Module):
       sd['model.decoder.embed_tokens.weight'] = new
     return cfg, sd
 
+  @staticmethod
+  def _load_clip(name: str, state: Optional[Dict[str, Tensor]], cfg: Optional[ClipConfig]):
+    """(ClipConfig, CLIPVisionModel-named state dict) or (None, None) when no vision weights are available offline."""
+    if state is not None:
+      if cfg is None:
+        D = state['vision_model.embeddings.class_embedding'].shape[0]
+        P = state['vision_model.embeddings.patch_embedding.weight'].shape[-1]
+        ntok = state['vision_model.embeddings.position_embedding.weight'].shape[0]
+        n_layers = 1 + max(int(k.split('.')[3]) for k in state if k.startswith('vision_model.encoder.layers.'))
+        F = state['vision_model.encoder.layers.0.mlp.fc1.weight'].shape[0]
+        cfg = ClipConfig(image_size=int(round((ntok - 1) ** 0.5)) * P, patch_size=P, hidden_size=D, num_layers=n_layers,
+                         num_heads=max(1, D // 64), intermediate_size=F)
+      return cfg, dict(state)
+    if os.path.isdir(name) and os.path.exists(os.path.join(name, 'config.json')):   # local HF directory
+      from transformers import CLIPVisionModel
+      hf = CLIPVisionModel.from_pretrained(name)
+      c = hf.config
+      sd = {(k if k.startswith('vision_model.') else 'vision_model.' + k): v for k, v in hf.state_dict().items()}
+      return ClipConfig(image_size=c.image_size, patch_size=c.patch_size, hidden_size=c.hidden_size,
+                        num_layers=c.num_hidden_layers, num_heads=c.num_attention_heads,
+                        intermediate_size=c.intermediate_size), sd
+    return None, None
+
+  def _clip_native(self, B: int):
+    dev = self.logit_scale.device
+    if dev.type != 'cuda':
+      raise N.GillNativeError('GILLModel runs only on an MI355X through libgill_amd; call .cuda() first.')
+    if self.visual_model is None:
+      raise NotImplementedError('image prompts need the CLIP vision weights (args.clip_state_dict or a local '
+                                'openai/clip-vit-* directory): none were available when this model was built')
+    if self._clip_handle is not None and B <= self._clip_cap:
+      return self._clip_handle
+    if self._clip_handle is not None:
+      N.lib().gill_clip_destroy(self._clip_handle)
+      self._clip_handle = None
+    c = self.clip_cfg
+    cap = max(B, 4)
+    cfg = N.gill_clip_config(image_size=c.image_size, patch_size=c.patch_size, hidden_size=c.hidden_size,
+                             num_layers=c.num_layers, num_heads=c.num_heads, intermediate_size=c.intermediate_size,
+                             max_batch=cap)
+    arr, keep = N.make_tensor_table(self.visual_model.state_dict(), dev)
+    h = C.c_void_p()
+    with torch.cuda.device(dev):
+      N.check(N.lib().gill_clip_create(C.byref(h), C.byref(cfg), arr, len(keep)))
+    del keep
+    self._clip_handle, self._clip_cap = h, cap
+    return h
+
   def _apply(self, fn, *a, **k):
     self.release_native()
     return super()._apply(fn, *a, **k)
@@ -201,6 +257,9 @@ class GILLModel(nn.Module):
       N.lib().gill_opt_destroy(self._opt_handle)
     self._opt_handle = None
     self._opt_cap = (0, 0)
+    if getattr(self, '_clip_handle', None):
+      N.lib().gill_clip_destroy(self._clip_handle)
+    self._clip_handle = None
 
   def refresh_native(self):
     """Call after mutating weights in place once a forward has already run (handles snapshot the weights)."""
@@ -241,8 +300,18 @@ class GILLModel(nn.Module):
       raise ValueError(f"mode should be one of ['captioning', 'retrieval', 'generation'], got {mode} instead.")
     if mode == 'generation':   # models.py:147-148: the image is ignored
       return torch.zeros((pixel_values.shape[0], 1, 768), device=pixel_values.device)
-    raise NotImplementedError("image prompts need the CLIP vision tower, which is outside the MI355X generate_images "
-                              "path (SURVEY.md section 8f rank 3)")
+    # models.py:137-146: pooler_output of the frozen tower -> visual_embeddings / visual_fc -> (B, n_visual_tokens | 1, D)
+    from . import ops
+    px = pixel_values.to(self.logit_scale.device, torch.float32).contiguous()
+    B = px.shape[0]
+    h = self._clip_native(B)
+    pooled = torch.empty((B, self.clip_cfg.hidden_size), device=px.device, dtype=torch.float32)
+    with torch.cuda.device(px.device):
+      N.check(N.lib().gill_clip_forward(h, N.ptr(px), B, N.ptr(pooled), N.current_stream()))
+    fc = self.visual_embeddings if mode == 'captioning' else self.visual_fc
+    out = ops.gemm(pooled.to(torch.bfloat16), fc.weight, bias=fc.bias, out_f32=True)
+    n_tok = self.args.n_visual_tokens if mode == 'captioning' else 1
+    return out.reshape(B, n_tok, -1).to(self.logit_scale.dtype)
 
   def train(self, mode=True):
     super(GILLModel, self).train(mode=mode)   # reference quirk kept: returns None (models.py:155-161)
@@ -450,8 +519,11 @@ class GILL(nn.Module):
           input_embs.append(self.model.input_embeddings(text_ids))
           input_ids.append(text_ids)
         elif type(p).__module__.startswith('PIL'):
-          raise NotImplementedError("image prompts need the CLIP vision tower, which is outside the MI355X "
-                                    "generate_images path (SURVEY.md section 8f rank 3)")
+          # Encode as image (models.py:606-613)
+          pixel_values = utils.get_pixel_values_for_model(self.model.feature_extractor, p)
+          pixel_values = pixel_values.to(device=dev, dtype=self.model.logit_scale.dtype)[None, ...]
+          visual_embs = self.model.get_visual_embs(pixel_values, mode='captioning')   # (1, n_visual_tokens, D)
+          input_embs.append(visual_embs.to(input_embs[0].dtype) if input_embs else visual_embs)
         else:
           raise ValueError(f'Input prompts should be either PIL.Image.Image or str types, got {type(p)} instead.')
       input_embs = torch.cat(input_embs, dim=1)

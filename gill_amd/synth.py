@@ -94,6 +94,47 @@ def opt_state_dict(cfg: OptConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
   return sd
 
 
+# ---------------------------------------------------------------------------------------------- CLIP vision tower
+@dataclass
+class ClipConfig:
+  image_size: int = 224
+  patch_size: int = 14
+  hidden_size: int = 1024
+  num_layers: int = 24
+  num_heads: int = 16
+  intermediate_size: int = 4096
+
+  @staticmethod
+  def vit_l14():
+    return ClipConfig()
+
+  @staticmethod
+  def tiny():          # head dim 64 (a supported attention width), 5 tokens
+    return ClipConfig(image_size=32, patch_size=16, hidden_size=128, num_layers=2, num_heads=2, intermediate_size=256)
+
+
+def clip_state_dict(cfg: ClipConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+  """transformers.CLIPVisionModel parameter names (the vision tower GILLModel holds as `visual_model`)."""
+  sd: Dict[str, torch.Tensor] = {}
+  D, F, P = cfg.hidden_size, cfg.intermediate_size, cfg.patch_size
+  ntok = (cfg.image_size // P) ** 2 + 1
+  vm = "vision_model"
+  sd[f"{vm}.embeddings.class_embedding"] = normal(f"{vm}.embeddings.class_embedding", (D,), seed, 0.5)
+  sd[f"{vm}.embeddings.patch_embedding.weight"] = _matrix(f"{vm}.embeddings.patch_embedding.weight", (D, 3, P, P), seed)
+  sd[f"{vm}.embeddings.position_embedding.weight"] = normal(f"{vm}.embeddings.position_embedding.weight", (ntok, D), seed, 0.25)
+  _norm(sd, f"{vm}.pre_layrnorm", D, seed)       # (sic: the Hugging Face name)
+  for i in range(cfg.num_layers):
+    p = f"{vm}.encoder.layers.{i}"
+    for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+      _linear(sd, f"{p}.self_attn.{n}", D, D, seed)
+    _norm(sd, f"{p}.layer_norm1", D, seed)
+    _linear(sd, f"{p}.mlp.fc1", F, D, seed)
+    _linear(sd, f"{p}.mlp.fc2", D, F, seed)
+    _norm(sd, f"{p}.layer_norm2", D, seed)
+  _norm(sd, f"{vm}.post_layernorm", D, seed)
+  return sd
+
+
 # ---------------------------------------------------------------------------------------------- GILLMapper
 @dataclass
 class MapperConfig:

@@ -86,6 +86,29 @@ int gill_opt_img_hidden(gill_opt* h, const int64_t* ids, const int32_t* last_idx
 int gill_opt_last_logits(gill_opt* h, const float* hidden, int B, int T, float* logits_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Image prompts — the frozen CLIP vision tower (transformers CLIPVisionModel built at gill/models.py:78-96 and called by
+ * GILLModel.get_visual_embs, gill/models.py:129-145: `self.visual_model(pixel_values).pooler_output`).
+ * State-dict names are CLIPVisionModel's ("vision_model.embeddings.patch_embedding.weight",
+ * "vision_model.encoder.layers.0.self_attn.q_proj.weight", "vision_model.pre_layrnorm.weight" (sic), ...).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gill_clip_config {
+  int32_t image_size;         /* 224 */
+  int32_t patch_size;         /* 14 (ViT-L/14) */
+  int32_t hidden_size;        /* 1024 */
+  int32_t num_layers;         /* 24 */
+  int32_t num_heads;          /* 16 */
+  int32_t intermediate_size;  /* 4096 */
+  int32_t max_batch;
+} gill_clip_config;
+typedef struct gill_clip gill_clip;
+
+int gill_clip_create(gill_clip** out, const gill_clip_config* cfg, const gill_tensor* weights, int n_weights);
+void gill_clip_destroy(gill_clip* h);
+
+/* pixel_values (B,3,S,S) fp32 (already resized / normalised)  ->  pooler_output (B, hidden) fp32. */
+int gill_clip_forward(gill_clip* h, const float* pixel_values, int B, float* pooled_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Stage 2 — GILLMapper = gill.layers.TextFcLayer(mode='gill_mapper').forward (layers.py:28-53).
  * State-dict names are TextFcLayer's ("fc.weight", "tfm.encoder.layers.0.self_attn.in_proj_weight",
  * "query_embs", "model.weight", ...).

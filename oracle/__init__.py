@@ -10,8 +10,10 @@ under gill_amd/ does.  It restates, in plain fp32 torch-CPU ops, the algorithm t
            oracle.pipeline_ref   the driver loop gill/custom_sd.py:607-651 and the glue gill/models.py:164-441
            oracle.vae_ref        diffusers AutoencoderKL.decode + uint8 conversion (custom_sd.py:385-392) — NOT in the tree
 
+  image prompts  oracle.clip_ref   transformers CLIPVisionModel + visual_embeddings as called at gill/models.py:129-146
+
 Pinning status
-  * stages 1-2 are PINNED: tests/golden/*.npz hold outputs of the reference's own code
+  * stages 1-2 and the image-prompt branch are PINNED: tests/golden/*.npz hold outputs of the reference's own code
     (gill.layers.TextFcLayer, gill.models.GILLModel.forward/generate, GILL.generate_for_images_and_texts)
     imported from /root/reference by oracle/gen_golden.py, and tests/test_oracle_golden.py checks this
     restatement against them.

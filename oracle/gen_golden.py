@@ -9,6 +9,8 @@ What is executed from the reference, unmodified:
   F2  gill.models.GILLModel.forward(mode='generation')                          (gill/models.py:164-441)
   F3  gill.models.GILLModel.generate(..., gen_scale_factor=1e5)                 (gill/models.py:443-532)
   F4  gill.models.GILL(load_sd=False).generate_for_images_and_texts             (gill/models.py:582-762)
+  F5  gill.models.GILLModel.get_visual_embs(mode='captioning')                  (gill/models.py:129-146)
+  F6  generate_for_images_and_texts([PIL image, text])                          (gill/models.py:606-613)
 Harness shim: `diffusers` / `torchvision` are absent here, so empty stand-in modules are placed in
 sys.modules BEFORE importing gill.models (its stage-3 code is never called: load_sd=False); random-init OPT / CLIP
 models are saved to local dirs whose paths contain 'facebook/opt' and 'clip' (string checks at models.py:56,78); a
@@ -149,6 +151,69 @@ def golden_gillmodel(ref_models, tmp):
   print("F4", repr(ret[0]), ret[1]["decision"], tuple(gen.shape))
 
 
+def golden_visual(ref_models, tmp):
+  """F5-F6: image prompts.  A second reference GILL whose CLIPVisionModel has gill_amd.synth.ClipConfig.tiny() shapes and
+  synth weights: F5 = GILLModel.get_visual_embs(mode='captioning') (gill/models.py:129-146), F6 = the public
+  generate_for_images_and_texts([PIL image, text]) (gill/models.py:606-613 + the 'gen' branch)."""
+  import gill.utils as ref_utils
+  from PIL import Image
+  from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModel, OPTConfig, OPTForCausalLM
+  ccfg = synth.ClipConfig.tiny()
+  ocfg = synth.OptConfig.opt_125m()
+  opt_dir = os.path.join(tmp, "v/facebook/opt-125m-shape")
+  clip_dir = os.path.join(tmp, "v/openai/clip-tiny")
+  hf = OPTForCausalLM(OPTConfig(vocab_size=50272, hidden_size=ocfg.hidden_size, num_hidden_layers=ocfg.num_layers,
+                                ffn_dim=ocfg.ffn_dim, num_attention_heads=ocfg.num_heads, max_position_embeddings=2048,
+                                word_embed_proj_dim=ocfg.hidden_size, do_layer_norm_before=True, dropout=0.0))
+  sd_full = {k: v.bfloat16().float() for k, v in synth.opt_state_dict(
+    synth.OptConfig(vocab_size=50274, hidden_size=768, num_layers=12, num_heads=12, ffn_dim=3072), seed=5).items()}
+  sd_hf = dict(sd_full)
+  sd_hf["model.decoder.embed_tokens.weight"] = sd_full["model.decoder.embed_tokens.weight"][:50272].clone()
+  sd_hf["lm_head.weight"] = sd_hf["model.decoder.embed_tokens.weight"]
+  hf.load_state_dict(sd_hf, strict=True)
+  hf.save_pretrained(opt_dir)
+  CLIPVisionModel(CLIPVisionConfig(hidden_size=ccfg.hidden_size, intermediate_size=ccfg.intermediate_size,
+                                   num_hidden_layers=ccfg.num_layers, num_attention_heads=ccfg.num_heads,
+                                   image_size=ccfg.image_size, patch_size=ccfg.patch_size)).save_pretrained(clip_dir)
+  ref_utils.get_feature_extractor_for_model = lambda name, **kw: CLIPImageProcessor(
+    size={"shortest_edge": ccfg.image_size}, crop_size={"height": ccfg.image_size, "width": ccfg.image_size})
+  tok = synth.HashTokenizer()
+  args = types.SimpleNamespace(freeze_lm=True, freeze_vm=True, opt_version=opt_dir, visual_encoder=clip_dir,
+                               n_visual_tokens=4, ret_emb_dim=256, gen_emb_dim=768, text_emb_layers=[-1],
+                               text_fc_mode="gill_mapper", ret_text_fc_mode="linear", num_tokens=8, num_clip_tokens=77,
+                               retrieval_token_idx=synth.IMG_TOKEN_IDS, gen_token_idx=synth.IMG_TOKEN_IDS)
+  gill = ref_models.GILL(tok, args, load_sd=False, num_gen_images=1)
+  gm = gill.model
+  clip_sd = {k: v.bfloat16().float() for k, v in synth.clip_state_dict(ccfg, seed=13).items()}
+  keys = list(gm.visual_model.state_dict().keys())
+  pref = "" if keys[0].startswith("vision_model.") else "vision_model."       # transformers 5.x dropped the prefix
+  proj = {}
+  synth._linear(proj, "visual_embeddings", 4 * 768, ccfg.hidden_size, 13)
+  proj = {k: v.bfloat16().float() for k, v in proj.items()}
+  with torch.no_grad():
+    gm.visual_model.load_state_dict({k[len(pref):]: v for k, v in clip_sd.items()}, strict=True)
+    gm.visual_embeddings.weight.copy_(proj["visual_embeddings.weight"]); gm.visual_embeddings.bias.copy_(proj["visual_embeddings.bias"])
+    gm.input_embeddings.weight.copy_(sd_full["model.decoder.embed_tokens.weight"])
+    msd = {k: v.bfloat16().float() for k, v in synth.mapper_state_dict(synth.MapperConfig(in_dim=768), seed=7).items()}
+    gm.gen_text_hidden_fcs[0].load_state_dict(msd, strict=True)
+  gill.eval()
+  # ---- F5
+  px = synth.normal("golden_pixel_values", (3, 3, ccfg.image_size, ccfg.image_size), 13)
+  with torch.no_grad():
+    ve = gm.get_visual_embs(px, mode="captioning")
+  # ---- F6: a deterministic RGB image larger than the crop, then a text prompt
+  rng = np.random.default_rng(13)
+  img_arr = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+  text = "a small red fox jumps over the lazy dog"
+  with torch.no_grad():
+    ret = gill.generate_for_images_and_texts([Image.fromarray(img_arr), text], num_words=2, gen_scale_factor=1e5)
+  gen = ret[1]["gen"][0]
+  np.savez_compressed(os.path.join(OUT, "gill_visual_tiny.npz"), pixel_values=px.numpy(), visual_embs=ve.numpy(),
+                      image=img_arr, text=np.array(text), caption=np.array(ret[0]), decision=np.array(str(ret[1]["decision"])),
+                      gen_emb=gen.numpy(), clip_seed=np.int64(13), opt_seed=np.int64(5), mapper_seed=np.int64(7))
+  print("F5", tuple(ve.shape), float(ve.abs().mean()), "F6", repr(ret[0]), ret[1]["decision"], tuple(gen.shape))
+
+
 def main():
   os.makedirs(OUT, exist_ok=True)
   torch.manual_seed(0)
@@ -158,6 +223,7 @@ def main():
   tmp = tempfile.mkdtemp(prefix="gill_golden_")
   try:
     golden_gillmodel(ref_models, tmp)
+    golden_visual(ref_models, tmp)
   finally:
     shutil.rmtree(tmp, ignore_errors=True)
   print("wrote", sorted(os.listdir(OUT)))

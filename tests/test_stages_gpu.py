@@ -130,6 +130,64 @@ def test_generate_kv_cache_matches_full_reforward(cuda, gill125):
   assert rel_i < 2e-2
 
 
+def test_image_prompt_vs_reference_golden(cuda):
+  """CLIP vision tower + visual_embeddings (get_visual_embs) and the public API with a PIL image
+  in the prompt list, against the reference's own outputs (tests/golden/gill_visual_tiny.npz, oracle/gen_golden.py F5-F6)."""
+  from PIL import Image
+  from gill_amd.models import GILL
+  g = np.load(os.path.join(GOLD, "gill_visual_tiny.npz"))
+  ccfg = synth.ClipConfig.tiny()
+  tok = synth.HashTokenizer()
+  ocfg = synth.OptConfig(vocab_size=50274, hidden_size=768, num_layers=12, num_heads=12, ffn_dim=3072)
+  args = SimpleNamespace(freeze_lm=True, freeze_vm=True, opt_version="facebook/opt-125m", visual_encoder="openai/clip-tiny",
+                         n_visual_tokens=4, ret_emb_dim=256, gen_emb_dim=768, text_emb_layers=[-1], text_fc_mode="gill_mapper",
+                         ret_text_fc_mode="linear", num_tokens=8, num_clip_tokens=77, retrieval_token_idx=synth.IMG_TOKEN_IDS,
+                         gen_token_idx=synth.IMG_TOKEN_IDS, opt_state_dict=_bfw(synth.opt_state_dict(ocfg, seed=int(g["opt_seed"]))),
+                         clip_state_dict=_bfw(synth.clip_state_dict(ccfg, seed=int(g["clip_seed"]))), clip_config=ccfg)
+  m = GILL(tok, args, load_sd=False)
+  proj = {}
+  synth._linear(proj, "visual_embeddings", 4 * 768, ccfg.hidden_size, int(g["clip_seed"]))
+  with torch.no_grad():
+    m.model.visual_embeddings.weight.copy_(proj["visual_embeddings.weight"].bfloat16().float())
+    m.model.visual_embeddings.bias.copy_(proj["visual_embeddings.bias"].bfloat16().float())
+  m.model.gen_text_hidden_fcs[0].load_state_dict(_bfw(synth.mapper_state_dict(synth.MapperConfig(in_dim=768), seed=int(g["mapper_seed"]))),
+                                                 strict=True)
+  m = m.eval().bfloat16().cuda()
+  ve = m.model.get_visual_embs(torch.from_numpy(g["pixel_values"]).to(cuda), mode="captioning")
+  assert ve.shape == (3, 4, 768)
+  mse, rel, cos = _stats("get_visual_embs", ve, torch.from_numpy(g["visual_embs"]))
+  assert rel < 3e-2 and cos > 0.999
+  ret = m.generate_for_images_and_texts([Image.fromarray(g["image"]), str(g["text"])], num_words=2, gen_scale_factor=1e5)
+  assert ret[0] == str(g["caption"]) and str(ret[1]["decision"]) == str(g["decision"])
+  gen = ret[1]["gen"][0]
+  mse, _, _ = _stats("public API gen_emb with an image prompt", gen, torch.from_numpy(g["gen_emb"]))
+  assert gen.shape == (1, 77, 768) and mse < 1e-4
+
+
+@pytest.mark.skipif(os.environ.get("GILL_SKIP_SLOW") == "1", reason="slow CPU oracle")
+def test_clip_vit_l14_vs_oracle(cuda):
+  """The full ViT-L/14 geometry the reference uses (224 px, 14 px patches -> K = 588 padded to 640, 257 tokens, 24 layers)."""
+  import ctypes as C
+  from gill_amd import _native as N
+  from oracle import clip_ref
+  cfg = synth.ClipConfig.vit_l14()
+  sd = _bfw(synth.clip_state_dict(cfg, seed=21))
+  px = synth.normal("vitl_px", (2, 3, 224, 224), 21)
+  ref = clip_ref.clip_pooler_output(sd, px, cfg.patch_size, cfg.num_heads)
+  c = N.gill_clip_config(image_size=cfg.image_size, patch_size=cfg.patch_size, hidden_size=cfg.hidden_size, num_layers=cfg.num_layers,
+                         num_heads=cfg.num_heads, intermediate_size=cfg.intermediate_size, max_batch=2)
+  arr, keep = N.make_tensor_table(sd, cuda)
+  h = C.c_void_p()
+  N.check(N.lib().gill_clip_create(C.byref(h), C.byref(c), arr, len(keep)))
+  del keep
+  out = torch.empty((2, cfg.hidden_size), device=cuda, dtype=torch.float32)
+  N.check(N.lib().gill_clip_forward(h, N.ptr(px.to(cuda)), 2, N.ptr(out), N.current_stream()))
+  torch.cuda.synchronize()
+  N.lib().gill_clip_destroy(h)
+  _, rel, cos = _stats("CLIP ViT-L/14 pooler_output", out, ref)
+  assert rel < 3e-2 and cos > 0.999
+
+
 def test_opt_forward_vs_oracle_causal_lengths(cuda, gill125):
   """Single OPT pass at several sequence lengths (kv tile edges 31/32/33, 64, 100) against the oracle."""
   from oracle import opt_ref
