@@ -102,9 +102,15 @@ class TextFcLayer(nn.Module):
       with torch.cuda.device(x.device):
         N.check(N.lib().gill_mapper_forward(h, N.ptr(xb), N.ptr(eb), B, Be, N.ptr(out), N.current_stream()))
       outputs = out.to(x.dtype) if x.dtype != torch.float32 else out
+    elif self.mode == 'linear':
+      # ret_text_fc_mode: one Linear over every token (layers.py:44-49), then the first num_output_tokens tokens
+      from . import ops
+      Bn, T, D = x.shape
+      y = ops.gemm(x.reshape(Bn * T, D), self.model.weight, bias=self.model.bias, out_f32=True).reshape(Bn, T, self.out_dim)
+      if y.shape[1] != self.num_output_tokens:
+        y = y[:, :self.num_output_tokens, :]
+      outputs = y.to(x.dtype) if x.dtype != torch.float32 else y
     else:
-      # 'linear' (ret_text_fc_mode): retrieval head — outside the image-generation hot path
-      raise NotImplementedError("TextFcLayer(mode='linear') belongs to the retrieval branch, which is out of scope "
-                                "of the MI355X generate_images path")
+      raise NotImplementedError(f"TextFcLayer mode {self.mode!r}")
     assert outputs.shape[1] == 1 or (outputs.shape[1] * outputs.shape[2] == self.num_output_tokens * 768), (outputs.shape, self.num_output_tokens)
     return outputs  # (N, T, D)

@@ -13,7 +13,7 @@ New here (NOT in the reference): GILL.generate_images
 per-prompt semantics are the 'gen' branch of generate_for_images_and_texts([p], num_words=2, gen_scale_factor=1e5).
 
 Out of scope of this build (raise NotImplementedError): image prompts / CLIP vision tower, captioning and
-retrieval modes, the retrieval + decision + CLIP-rerank branches.
+retrieval modes.
 """
 from __future__ import annotations
 
@@ -550,6 +550,7 @@ class GILL(nn.Module):
 
       return_outputs = []
       all_ret_idx = [i for i, x in enumerate(generated_ids[0, :] == self.model.retrieval_token_idx[0]) if x][:max_num_rets]
+      seen_image_idx = []  # Avoid showing the same image multiple times.
       last_ret_idx = 0
       if len(all_ret_idx) == 0:
         caption = self.model.tokenizer.batch_decode(generated_ids, skip_special_tokens=True)[0]
@@ -561,9 +562,39 @@ class GILL(nn.Module):
           assert len(self.model.args.text_emb_layers) == 1
           image_outputs = {'gen': [], 'ret': [], 'decision': None}
           if self.emb_matrix is not None:
-            raise NotImplementedError("the retrieval / decision / CLIP-rerank branches (models.py:671-704, 733-753) are "
-                                      "out of scope of the MI355X generate_images path; run with emb_matrix=None")
-          image_outputs['decision'] = ['gen', [0, 1]]
+            # Produce retrieval embedding (models.py:671-676); the Linear and the score GEMV run in libgill_amd
+            from . import ops
+            from PIL import UnidentifiedImageError
+            ret_emb = self.model.ret_text_hidden_fcs[0](raw_emb, None)[:, 0, :]  # (1, 256)
+            ret_emb = ret_emb / ret_emb.norm(dim=-1, keepdim=True)
+            ret_emb = ret_emb.type(self.emb_matrix.dtype)  # (1, 256)
+            scores = self._scores(self.emb_matrix, ret_emb)                         # emb_matrix @ ret_emb.T, (N, 1)
+            for seen_idx in seen_image_idx:   # Downweight seen images.
+              scores[seen_idx, :] -= 1000
+            _, top_image_idx = scores.squeeze().topk(3)
+            for img_idx in top_image_idx:     # Find the first image that does not error out.
+              try:
+                seen_image_idx.append(img_idx)
+                img = utils.get_image_from_url(self.path_array[img_idx])
+                image_outputs['ret'].append((img, 'ret', scores[img_idx].item()))
+                if len(image_outputs) == max_num_rets:
+                  break
+              except (UnidentifiedImageError, ConnectionError, OSError):
+                pass
+            if self.decision_model is not None:   # Make decision with MLP (models.py:698-704)
+              decision_emb = raw_emb[:, 0, :]  # (1, 4096)
+              lin = self.decision_model[1]
+              assert decision_emb.shape[1] == lin.in_features, decision_emb.shape
+              w4 = torch.zeros((4, lin.in_features), device=decision_emb.device, dtype=torch.bfloat16)
+              w4[:lin.out_features] = lin.weight.to(decision_emb.device, torch.bfloat16)
+              b4 = torch.zeros((4,), device=decision_emb.device)
+              b4[:lin.out_features] = lin.bias.to(decision_emb.device).float()
+              decision_logits = ops.gemm(decision_emb, w4, bias=b4, out_f32=True)[:, :lin.out_features]
+              probs = decision_logits.softmax(dim=-1).cpu().float().numpy().tolist()
+              image_outputs['decision'] = [self.idx2dec[decision_logits.argmax().item()]] + probs
+          else:
+            # If no embedding matrix is provided, generate instead.
+            image_outputs['decision'] = ['gen', [0, 1]]
 
           gen_prefix = ''.join([f'[IMG{i}]' for i in range(self.model.args.num_tokens)])
           gen_prefx_ids = self.model.tokenizer(gen_prefix, add_special_tokens=False, return_tensors="pt").input_ids.to(dev)
@@ -588,7 +619,24 @@ class GILL(nn.Module):
                              num_inference_steps=num_inference_steps,
                              output_type="pil" if getattr(self.sd_pipe, "_vae", None) else "latent").images)
             # PIL images when the pipeline holds VAE weights (reference behaviour), else the final latents (4,64,64)
-            image_outputs['gen'] = [(gen_images[0], 0)]
+            if self.emb_matrix is not None and getattr(self.sd_pipe, "_vae", None):
+              # CLIP rerank of the generated images against the retrieval embedding (models.py:733-751)
+              all_gen_pixels = []
+              for img in gen_images:
+                pixel_values = utils.get_pixel_values_for_model(self.model.feature_extractor, img.resize((224, 224)).convert('RGB'))
+                all_gen_pixels.append(pixel_values.to(device=dev, dtype=self.model.logit_scale.dtype))
+              all_gen_pixels = torch.stack(all_gen_pixels, dim=0)
+              gen_visual_embs = self.model.get_visual_embs(all_gen_pixels, mode='retrieval')  # (n, 1, D)
+              gen_visual_embs = gen_visual_embs / gen_visual_embs.norm(dim=-1, keepdim=True)
+              gen_visual_embs = gen_visual_embs.type(self.emb_matrix.dtype)
+              gen_rank_scores = self._scores(gen_visual_embs.reshape(len(gen_images), -1), ret_emb).squeeze()
+              sorted_score_idx = torch.argsort(-gen_rank_scores)
+              if self.num_gen_images > 1:   # Rank images by retrieval score.
+                image_outputs['gen'] = [(gen_images[idx], gen_rank_scores[idx].item()) for idx in sorted_score_idx]
+              else:
+                image_outputs['gen'] = [(gen_images[0], gen_rank_scores.item())]
+            else:
+              image_outputs['gen'] = [(gen_images[0], 0)]
           else:
             image_outputs['gen'] = [gen_emb]
 
@@ -597,6 +645,20 @@ class GILL(nn.Module):
           return_outputs.append(utils.truncate_caption(caption) + f' {gen_prefix}')
           return_outputs.append(image_outputs)
     return return_outputs
+
+  @staticmethod
+  def _scores(matrix: Tensor, query: Tensor) -> Tensor:
+    """matrix (N, D) @ query (1, D).T -> (N, 1) in matrix's dtype, through the native GEMM (the query is padded to the 4
+    output columns the kernel's epilogue writes at a time)."""
+    from . import ops
+    dev = query.device
+    Nq, D = matrix.shape
+    Dp = (D + 63) // 64 * 64
+    a = torch.zeros((Nq, Dp), device=dev, dtype=torch.bfloat16)
+    a[:, :D] = matrix.to(dev)
+    q4 = torch.zeros((4, Dp), device=dev, dtype=torch.bfloat16)
+    q4[0, :D] = query.reshape(-1).to(torch.bfloat16)
+    return ops.gemm(a, q4, out_f32=True)[:, :1].to(matrix.dtype)
 
   # ---- NEW, build-defined batched entry (not a reference function) ---------------------------------------
   @torch.no_grad()

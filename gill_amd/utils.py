@@ -2,6 +2,8 @@
 pre-processing of PIL prompts (gill/utils.py:111-119, gill/models.py:606-613)."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -62,3 +64,19 @@ def get_feature_extractor_for_model(model_name: str, image_size: int = 224, trai
 def get_pixel_values_for_model(feature_extractor, img):
   """reference: gill/utils.py:117-119"""
   return feature_extractor(img.convert('RGB'), return_tensors="pt").pixel_values[0, ...]  # (3, H, W)
+
+
+def get_image_from_url(url: str):
+  """reference: gill/utils.py:24-29 (an http(s) URL through `requests`); additionally accepts a local file path, which is
+  what an offline CC3M mirror provides.  Errors surface as OSError / UnidentifiedImageError like the reference's."""
+  from io import BytesIO
+  from PIL import Image
+  if os.path.exists(url):
+    img = Image.open(url)
+  else:
+    import requests
+    response = requests.get(url)
+    img = Image.open(BytesIO(response.content))
+  img = img.resize((224, 224))
+  img = img.convert('RGB')
+  return img

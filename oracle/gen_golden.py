@@ -11,6 +11,7 @@ What is executed from the reference, unmodified:
   F4  gill.models.GILL(load_sd=False).generate_for_images_and_texts             (gill/models.py:582-762)
   F5  gill.models.GILLModel.get_visual_embs(mode='captioning')                  (gill/models.py:129-146)
   F6  generate_for_images_and_texts([PIL image, text])                          (gill/models.py:606-613)
+  F7  the retrieval branch of the same method (emb_matrix / path_array given)  (gill/models.py:671-696)
 Harness shim: `diffusers` / `torchvision` are absent here, so empty stand-in modules are placed in
 sys.modules BEFORE importing gill.models (its stage-3 code is never called: load_sd=False); random-init OPT / CLIP
 models are saved to local dirs whose paths contain 'facebook/opt' and 'clip' (string checks at models.py:56,78); a
@@ -208,7 +209,40 @@ def golden_visual(ref_models, tmp):
   with torch.no_grad():
     ret = gill.generate_for_images_and_texts([Image.fromarray(img_arr), text], num_words=2, gen_scale_factor=1e5)
   gen = ret[1]["gen"][0]
-  np.savez_compressed(os.path.join(OUT, "gill_visual_tiny.npz"), pixel_values=px.numpy(), visual_embs=ve.numpy(),
+  # ---- F7: retrieval branch (emb_matrix given): ret_text_hidden_fcs Linear -> normalise -> emb_matrix @ ret_emb.T -> top-3
+  # images.  Harness shim: the reference fetches path_array entries over http (utils.get_image_from_url); here the entries
+  # are local PNG files, opened by a stand-in with the same resize/convert steps.
+  n_img = 24
+  img_dir = os.path.join(tmp, "cc3m_stub")
+  os.makedirs(img_dir, exist_ok=True)
+  paths = []
+  for k in range(n_img):
+    arr = np.full((20, 20, 3), (7 * k) % 256, dtype=np.uint8)
+    arr[:, :, 1] = (13 * k + 5) % 256
+    pth = os.path.join(img_dir, f"{k}.png")
+    Image.fromarray(arr).save(pth)
+    paths.append(pth)
+  ref_utils.get_image_from_url = lambda url: Image.open(url).resize((224, 224)).convert("RGB")
+  emb_matrix = synth.normal("cc3m_emb_matrix", (n_img, 256), 13)
+  emb_matrix = emb_matrix / emb_matrix.norm(dim=-1, keepdim=True)
+  rproj = {}
+  synth._linear(rproj, "ret_text_hidden_fcs.0.model", 256, 768, 13)
+  rproj = {k: v.bfloat16().float() for k, v in rproj.items()}
+  with torch.no_grad():
+    gm.ret_text_hidden_fcs[0].model.weight.copy_(rproj["ret_text_hidden_fcs.0.model.weight"])
+    gm.ret_text_hidden_fcs[0].model.bias.copy_(rproj["ret_text_hidden_fcs.0.model.bias"])
+  gill.emb_matrix = emb_matrix
+  gill.path_array = paths
+  with torch.no_grad():
+    ret7 = gill.generate_for_images_and_texts([text], num_words=2, gen_scale_factor=1e5)
+  rets = ret7[1]["ret"]
+  ret_scores = np.array([r[2] for r in rets], dtype=np.float64)
+  ret_ids = np.array([int(np.asarray(r[0])[0, 0, 0]) for r in rets], dtype=np.int64)     # red channel = (7 k) % 256 identifies k
+  print("F7 ret", ret_ids.tolist(), ret_scores.tolist(), ret7[1]["decision"])
+  gill.emb_matrix = None
+  gill.path_array = None
+  np.savez_compressed(os.path.join(OUT, "gill_visual_tiny.npz"), ret_scores=ret_scores, ret_red=ret_ids, n_img=np.int64(n_img),
+                      ret_decision=np.array(str(ret7[1]["decision"])), pixel_values=px.numpy(), visual_embs=ve.numpy(),
                       image=img_arr, text=np.array(text), caption=np.array(ret[0]), decision=np.array(str(ret[1]["decision"])),
                       gen_emb=gen.numpy(), clip_seed=np.int64(13), opt_seed=np.int64(5), mapper_seed=np.int64(7))
   print("F5", tuple(ve.shape), float(ve.abs().mean()), "F6", repr(ret[0]), ret[1]["decision"], tuple(gen.shape))

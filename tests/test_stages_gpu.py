@@ -164,6 +164,113 @@ def test_image_prompt_vs_reference_golden(cuda):
   assert gen.shape == (1, 77, 768) and mse < 1e-4
 
 
+def test_retrieval_branch_vs_reference_golden(cuda, tmp_path):
+  """ret_text_hidden_fcs Linear -> normalise -> emb_matrix @ ret_emb.T -> top-3 local images,
+  against the reference's own scores / picks (golden F7), plus the decision MLP against plain fp32 math."""
+  from PIL import Image
+  from gill_amd.models import GILL
+  g = np.load(os.path.join(GOLD, "gill_visual_tiny.npz"))
+  tok = synth.HashTokenizer()
+  ocfg = synth.OptConfig(vocab_size=50274, hidden_size=768, num_layers=12, num_heads=12, ffn_dim=3072)
+  args = SimpleNamespace(freeze_lm=True, freeze_vm=True, opt_version="facebook/opt-125m", visual_encoder="openai/clip-vit-base-patch16",
+                         n_visual_tokens=4, ret_emb_dim=256, gen_emb_dim=768, text_emb_layers=[-1], text_fc_mode="gill_mapper",
+                         ret_text_fc_mode="linear", num_tokens=8, num_clip_tokens=77, retrieval_token_idx=synth.IMG_TOKEN_IDS,
+                         gen_token_idx=synth.IMG_TOKEN_IDS, opt_state_dict=_bfw(synth.opt_state_dict(ocfg, seed=int(g["opt_seed"]))))
+  n_img = int(g["n_img"])
+  paths = []
+  for k in range(n_img):
+    arr = np.full((20, 20, 3), (7 * k) % 256, dtype=np.uint8)
+    arr[:, :, 1] = (13 * k + 5) % 256
+    p = str(tmp_path / f"{k}.png")
+    Image.fromarray(arr).save(p)
+    paths.append(p)
+  emb_matrix = synth.normal("cc3m_emb_matrix", (n_img, 256), int(g["clip_seed"]))
+  emb_matrix = emb_matrix / emb_matrix.norm(dim=-1, keepdim=True)
+  m = GILL(tok, args, path_array=paths, emb_matrix=emb_matrix, load_sd=False)
+  rproj = {}
+  synth._linear(rproj, "ret_text_hidden_fcs.0.model", 256, 768, int(g["clip_seed"]))
+  with torch.no_grad():
+    m.model.ret_text_hidden_fcs[0].model.weight.copy_(rproj["ret_text_hidden_fcs.0.model.weight"].bfloat16().float())
+    m.model.ret_text_hidden_fcs[0].model.bias.copy_(rproj["ret_text_hidden_fcs.0.model.bias"].bfloat16().float())
+  m.model.gen_text_hidden_fcs[0].load_state_dict(_bfw(synth.mapper_state_dict(synth.MapperConfig(in_dim=768), seed=int(g["mapper_seed"]))),
+                                                 strict=True)
+  dec = torch.nn.Sequential(torch.nn.Dropout(0.5), torch.nn.Linear(768, 2))
+  with torch.no_grad():
+    dec[1].weight.copy_(synth.normal("decision.w", (2, 768), 3, 0.05).bfloat16().float())
+    dec[1].bias.copy_(synth.normal("decision.b", (2,), 3, 0.1))
+  m.decision_model = dec.eval()
+  m = m.eval().bfloat16().cuda()
+  m.emb_matrix = emb_matrix.to(cuda)
+  ret = m.generate_for_images_and_texts([str(g["text"])], num_words=2, gen_scale_factor=1e5)
+  rets = ret[1]["ret"]
+  reds = [int(np.asarray(r[0])[0, 0, 0]) for r in rets]
+  scores = np.array([r[2] for r in rets])
+  print("[retrieval] picks", reds, "scores", scores.tolist(), "reference", g["ret_red"].tolist(), g["ret_scores"].tolist())
+  assert reds == g["ret_red"].tolist() and all(r[1] == "ret" and r[0].size == (224, 224) for r in rets)
+  assert np.abs(scores - g["ret_scores"]).max() < 3e-3
+  # decision head: softmax(Linear(raw_emb[:, 0])) of the first [IMG] hidden state
+  prompt = tok(str(g["text"]), add_special_tokens=True, return_tensors="pt").input_ids.to(cuda)
+  _, embs, _ = m.model.generate(m.model.input_embeddings(prompt), 2, gen_scale_factor=1e5)
+  h0 = embs[-1][:, prompt.shape[1], :].float().cpu()
+  logits = h0 @ dec[1].weight.float().cpu().T + dec[1].bias.float().cpu()
+  exp = logits.softmax(-1)[0].tolist()
+  got = ret[1]["decision"]
+  print("[decision]", got, "expected", exp)
+  assert got[0] == {0: "gen", 1: "ret"}[int(logits.argmax())] and np.abs(np.array(got[1]) - np.array(exp)).max() < 2e-2
+  assert ret[1]["gen"][0].shape == (1, 77, 768)
+
+
+def test_public_api_all_branches_with_sd(cuda, tmp_path):
+  """generate_for_images_and_texts with everything switched on (small models): retrieval, decision, Stable Diffusion with
+  VAE decode to PIL, and the CLIP rerank of the generated images (models.py:724-751)."""
+  from PIL import Image
+  from gill_amd.models import GILL
+  from gill_amd.sd import GillSDPipeline
+  ucfg = synth.UNetConfig(block_out_channels=(64, 128, 256, 256), num_heads=4, cross_attention_dim=768, sample_size=16)
+  uncond = synth.uncond_context(ucfg.ctx_len, ucfg.cross_attention_dim, seed=3).bfloat16().float()
+  vcfg = synth.VAEConfig.tiny(16)
+  pipe = GillSDPipeline(_bfw(synth.unet_state_dict(ucfg, seed=3)), ucfg, uncond, cuda, max_batch=8,
+                        vae_state=_bfw(synth.vae_decoder_state_dict(vcfg, seed=5)), vae_cfg=vcfg)
+  ccfg = synth.ClipConfig.tiny()
+  tok = synth.HashTokenizer()
+  ocfg = synth.OptConfig(vocab_size=50274, hidden_size=768, num_layers=12, num_heads=12, ffn_dim=3072)
+  args = SimpleNamespace(freeze_lm=True, freeze_vm=True, opt_version="facebook/opt-125m", visual_encoder="openai/clip-tiny",
+                         n_visual_tokens=4, ret_emb_dim=256, gen_emb_dim=768, text_emb_layers=[-1], text_fc_mode="gill_mapper",
+                         ret_text_fc_mode="linear", num_tokens=8, num_clip_tokens=77, retrieval_token_idx=synth.IMG_TOKEN_IDS,
+                         gen_token_idx=synth.IMG_TOKEN_IDS, opt_state_dict=_bfw(synth.opt_state_dict(ocfg, seed=5)),
+                         clip_state_dict=_bfw(synth.clip_state_dict(ccfg, seed=13)), clip_config=ccfg)
+  paths = []
+  for k in range(8):
+    p = str(tmp_path / f"{k}.png")
+    Image.fromarray(np.full((12, 12, 3), 20 * k, dtype=np.uint8)).save(p)
+    paths.append(p)
+  emb_matrix = synth.normal("api_emb_matrix", (8, 256), 2)
+  emb_matrix = emb_matrix / emb_matrix.norm(dim=-1, keepdim=True)
+  m = GILL(tok, args, path_array=paths, emb_matrix=emb_matrix, load_sd=True, sd_pipe=pipe, num_gen_images=2)
+  m.model.gen_text_hidden_fcs[0].load_state_dict(_bfw(synth.mapper_state_dict(synth.MapperConfig(in_dim=768), seed=7)), strict=True)
+  m = m.eval().bfloat16().cuda()
+  m.emb_matrix = emb_matrix.to(cuda)
+  text = "two birds on a wire"
+  ret = m.generate_for_images_and_texts([text], num_words=2, gen_scale_factor=1e5, num_inference_steps=4,
+                                        generator=torch.Generator("cpu").manual_seed(5))
+  out = ret[1]
+  assert len(out["ret"]) == 3 and len(out["gen"]) == 2
+  (im0, s0), (im1, s1) = out["gen"]
+  assert im0.size == (128, 128) and im1.size == (128, 128) and np.isfinite([s0, s1]).all() and s0 >= s1
+  # the rerank score of the best image, recomputed: cos(visual_fc(CLIP(image)), ret_text_hidden_fcs(raw_emb)[0])
+  prompt = tok(text, add_special_tokens=True, return_tensors="pt").input_ids.to(cuda)
+  _, embs, _ = m.model.generate(m.model.input_embeddings(prompt), 2, gen_scale_factor=1e5)
+  raw = embs[-1][:, prompt.shape[1]:prompt.shape[1] + 8, :]
+  r = m.model.ret_text_hidden_fcs[0](raw, None)[:, 0, :].float()
+  r = r / r.norm(dim=-1, keepdim=True)
+  from gill_amd import utils
+  px = utils.get_pixel_values_for_model(m.model.feature_extractor, im0.resize((224, 224)).convert("RGB"))[None].to(cuda)
+  v = m.model.get_visual_embs(px, mode="retrieval").float().reshape(1, -1)
+  v = v / v.norm(dim=-1, keepdim=True)
+  print("[rerank] scores", s0, s1, "recomputed best", float((v * r).sum()))
+  assert abs(float((v * r).sum()) - s0) < 2e-2
+
+
 @pytest.mark.skipif(os.environ.get("GILL_SKIP_SLOW") == "1", reason="slow CPU oracle")
 def test_clip_vit_l14_vs_oracle(cuda):
   """The full ViT-L/14 geometry the reference uses (224 px, 14 px patches -> K = 588 padded to 640, 257 tokens, 24 layers)."""
