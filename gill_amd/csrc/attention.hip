@@ -25,12 +25,12 @@
 // DP (padded head dim, multiple of 16): 48 (d=40), 64, 80, 128, 160.  Padding columns of Q/K are exact zeros
 // (zero weight rows); padding rows of Vt (up to dpv = roundup(DP,32)) only feed output rows that are never stored.
 #include "ops.h"
+#include <stdlib.h>
 
-#define ATT_THREADS 512
-#define ATT_QB 256     // queries per workgroup
+// threads per workgroup NTHR = 512 | 256 | 128 (template): one wave per 32 queries, NTHR / 2 queries per workgroup
 #define ATT_KVT 64     // keys per tile
 
-template <int DP>
+template <int DP, int ATT_THREADS>
 struct AttCfg {
   static constexpr int KS = DP / 16;              // QK^T k-steps per 32-key half
   static constexpr int NDT = (DP + 31) / 32;      // 32-row d tiles of O^T
@@ -52,9 +52,10 @@ struct AttCfg {
   static constexpr int SMEM_BYTES = 2 * BUF_ELEMS * 2;
 };
 
-template <int DP>
+template <int DP, int ATT_THREADS>
 __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_kernel(const AttnArgs p) {
-  using Cfg = AttCfg<DP>;
+  using Cfg = AttCfg<DP, ATT_THREADS>;
+  constexpr int ATT_QB = ATT_THREADS / 2;
   constexpr int KS = Cfg::KS, NDT = Cfg::NDT, KSTR = Cfg::KSTR, VSTR = Cfg::VSTR;
   extern __shared__ __attribute__((aligned(16))) unsigned char att_smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(att_smem_raw);
@@ -280,18 +281,30 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
   }
 }
 
-template <int DP>
-static int attention_launch_dp(const AttnArgs& a, hipStream_t s) {
+template <int DP, int NTHR>
+static int attention_launch_inst(const AttnArgs& a, hipStream_t s) {
   static bool attr_set = false;
-  constexpr int smem = AttCfg<DP>::SMEM_BYTES;
+  constexpr int smem = AttCfg<DP, NTHR>::SMEM_BYTES;
   if (!attr_set) {
-    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel<DP, NTHR>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  dim3 grid(cdiv(a.nq, ATT_QB), a.H, a.B);
-  hipLaunchKernelGGL(attention_kernel<DP>, grid, dim3(ATT_THREADS), smem, s, a);
+  dim3 grid(cdiv(a.nq, NTHR / 2), a.H, a.B);
+  hipLaunchKernelGGL((attention_kernel<DP, NTHR>), grid, dim3(NTHR), smem, s, a);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+// 256 queries per workgroup when that still gives every CU a workgroup (measured: level 1, 256 workgroups, is 2 % faster
+// this way; level 2, 64 workgroups, 15-22 % faster with 128-query workgroups); shorter query ranges (UNet levels 1-2, OPT, the
+// mapper) get 128-query workgroups instead of leaving most CUs idle (each workgroup stages the whole K/V itself,
+// which is L2-resident at those sizes)
+template <int DP>
+static int attention_launch_dp(const AttnArgs& a, hipStream_t s) {
+  const int64_t bh = (int64_t)a.H * a.B;
+  static const int forced = [] { const char* e = getenv("GILL_ATT_THREADS"); return e ? atoi(e) : 0; }();   // tests / tools
+  if (forced == 512 || (forced != 256 && cdiv(a.nq, 256) * bh >= 256)) return attention_launch_inst<DP, 512>(a, s);
+  return attention_launch_inst<DP, 256>(a, s);   // (128-thread workgroups would stage 10+ chunks per thread: spills)
 }
 
 int attention_launch(const AttnArgs& a, hipStream_t s) {
