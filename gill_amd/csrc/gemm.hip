@@ -23,7 +23,7 @@
 #include "ops.h"
 #include <stdlib.h>
 
-#define BM 128
+#define BM_HOST 128       // rows of the 4-wave tile, for the host-side split-K heuristic; the kernel's BM is 32 * NWV
 #define BK 64
 #define GEMM_THREADS 256
 
@@ -52,6 +52,7 @@ struct GemmDev {
   int tiles_n;
   int npw;           // N tiles one workgroup walks back to back (plain GEMM, no split-K): the LDS ring keeps flowing
   int groups_n;      // cdiv(tiles_n, npw)
+  int nwv;           // waves per workgroup: 4 (128-row tile) or 2 (64-row tile)
 };
 
 __device__ __noinline__ float gelu_erf_call(float v) { return gelu_erf(v); }  // keeps erff out of the unrolled epilogue
@@ -132,12 +133,15 @@ __device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& 
   rm = mean * rr;
 }
 
-template <int BN, int CONV, int EPI, int STAGES>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) {
+// NWV: waves per workgroup.  4 -> 128-row tile (waves 2 x 2).  2 -> 64-row tile (waves 1 x 2) for problems with so few
+// 128-row tiles that half the CUs would idle (UNet level 2-3 projections: M = 2048 / 512).
+template <int NWV, int BN, int CONV, int EPI, int STAGES>
+__global__ __launch_bounds__(NWV * 64, 2) void gemm_kernel(const GemmDev d) {
+  constexpr int BM = NWV * 32;
   constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
-  // layout: [buf][A tile 128*64 | B tile BN*64]
+  // layout: [buf][A tile BM*64 | B tile BN*64]
   constexpr int A_ELEMS = BM * BK;
   constexpr int B_ELEMS = BN * BK;
   constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) 
   int a_off1[4], a_off2[4], a_fl[4], a_pc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int row = (i * 4 + w) * 8 + srow;
+    int row = (i * NWV + w) * 8 + srow;
     int m = m0 + row;
     if (m > p.M - 1) m = p.M - 1;
     a_fl[i] = 0; a_pc[i] = 0;
@@ -207,13 +211,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) 
     }
   }
   // W rows: BN/32 instructions per wave (BN rows / 8 rows per instr / 4 waves)
-  constexpr int WI = BN / 32;
+  constexpr int WG = BN / 8;                    // 8-row groups of the W tile
+  static_assert(WG % NWV == 0, "every wave stages the same number of W row groups");
+  constexpr int WI = WG / NWV;
   const bf16_t* w_ptr[WI];
   int n_issue = n0;        // first column of the N tile being staged
   auto w_setup = [&]() {
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      int row = (i * 4 + w) * 8 + srow;
+      int row = (i * NWV + w) * 8 + srow;
       int n = n_issue + row;
       if (n > p.N - 1) n = p.N - 1;
       w_ptr[i] = p.W + (size_t)n * p.K + schunk * 8 + kt_beg * BK;
@@ -291,14 +297,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmDev d) 
     bf16_t* Bs = As + A_ELEMS;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      bf16_t* l = As + (i * 4 + w) * 8 * BK;
+      bf16_t* l = As + (i * NWV + w) * 8 * BK;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[i],
                                        (__attribute__((address_space(3))) void*)l, 16, 0, 0);
       a_ptr[i] += BK;
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      bf16_t* l = Bs + (i * 4 + w) * 8 * BK;
+      bf16_t* l = Bs + (i * NWV + w) * 8 * BK;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
                                        (__attribute__((address_space(3))) void*)l, 16, 0, 0);
       w_ptr[i] += BK;
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs 
 int gemm_pick_splitk(int M, int N, int K, int act) {
   if (act == ACT_GEGLU) return 1;
   const int bn = (N % 160 == 0) ? 160 : 128;
-  const int tiles = cdiv(M, BM) * cdiv(N, bn);
+  const int tiles = cdiv(M, BM_HOST) * cdiv(N, bn);
   const int ksteps = K / BK;
   if (tiles >= 384 || ksteps < 8) return 1;
   int s = (512 + tiles / 2) / tiles;   // aim for ~2 workgroups per CU (512 resident slots)
@@ -691,24 +697,28 @@ int gemm_pick_splitk(int M, int N, int K, int act) {
   return s;
 }
 
-template <int BN, int CONV, int EPI, int STAGES>
+template <int NWV, int BN, int CONV, int EPI, int STAGES>
 static int gemm_launch_inst(const GemmDev& d, dim3 grid, hipStream_t s) {
   static bool attr_set = false;
-  constexpr int smem = STAGES * (BM * BK + BN * BK) * (int)sizeof(bf16_t);
+  constexpr int smem = STAGES * (NWV * 32 * BK + BN * BK) * (int)sizeof(bf16_t);
   if (!attr_set) {
-    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<BN, CONV, EPI, STAGES>,
+    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<NWV, BN, CONV, EPI, STAGES>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<BN, CONV, EPI, STAGES>), grid, dim3(GEMM_THREADS), smem, s, d);
+  hipLaunchKernelGGL((gemm_kernel<NWV, BN, CONV, EPI, STAGES>), grid, dim3(NWV * 64), smem, s, d);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
+// d.nwv = 2 selects the 64-row tile (plain GEMMs, 2-deep ring, no split-K)
 template <int BN, int CONV, int EPI>
 static int gemm_launch_stages(const GemmDev& d, dim3 grid, int stages, hipStream_t s) {
-  if (stages == 3) return gemm_launch_inst<BN, CONV, EPI, 3>(d, grid, s);
-  return gemm_launch_inst<BN, CONV, EPI, 2>(d, grid, s);
+  if constexpr (CONV == 0 && EPI != 2) {
+    if (d.nwv == 2) return gemm_launch_inst<2, BN, CONV, EPI, 2>(d, grid, s);
+  }
+  if (stages == 3) return gemm_launch_inst<4, BN, CONV, EPI, 3>(d, grid, s);
+  return gemm_launch_inst<4, BN, CONV, EPI, 2>(d, grid, s);
 }
 
 // tuning knobs (tests / tools): GILL_GEMM_STAGES = 2|3 forces the ring depth, GILL_GEMM_BN = 128|160 the tile width
@@ -728,11 +738,17 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   d.a.splitk = sk;
   d.ksteps_per_split = cdiv(d.ksteps, sk);
   d.tiles_n = cdiv(a.N, BN);
-  const int tiles_m = cdiv(a.M, BM);
   static const int forced = env_int("GILL_GEMM_STAGES");
   int stages = a.stages;
   if (forced == 2 || forced == 3) stages = forced;
   if (stages != 3) stages = 2;
+  // 64-row tiles for plain GEMMs whose 128-row tiling leaves CUs without a tile (GILL_GEMM_BM = 64 | 128 forces it)
+  static const int forced_bm = env_int("GILL_GEMM_BM");
+  d.nwv = 4;
+  if (!a.conv && sk == 1 && stages == 2 && (int64_t)cdiv(a.M, 128) * d.tiles_n < 200 && a.M > 64) d.nwv = 2;
+  if (forced_bm == 128) d.nwv = 4;
+  if (forced_bm == 64 && !a.conv && sk == 1 && stages == 2) d.nwv = 2;
+  const int tiles_m = cdiv(a.M, d.nwv * 32);
   // Short-K GEMMs with many N tiles (GEGLU, QKV: K = 320..1280, 6..80 N tiles) spend most of a tile's life in the first-load
   // latency and the epilogue.  Let one workgroup walk `npw` N tiles back to back instead: the ring is staged across tile
   // boundaries, so the loads of tile t+1 fly during the epilogue of tile t.  Keep ~2 workgroups per CU.
