@@ -676,6 +676,8 @@ class GILL(nn.Module):
     images_local (B_local,512,512,3) uint8 on the device; decoded pixels are never exchanged between ranks."""
     from . import parallel
     dev = self.model.logit_scale.device
+    if (isinstance(prompts, torch.Tensor) and prompts.numel() == 0) or (not isinstance(prompts, torch.Tensor) and len(prompts) == 0):
+      raise ValueError('generate_images: empty prompt batch')
     ids, lens = self._prompt_ids(prompts)
     B_total = ids.shape[0]
     lo, hi = parallel.shard_range(B_total, distributed)

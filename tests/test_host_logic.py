@@ -112,3 +112,9 @@ def test_gill_construction_and_reference_error_behaviour():
   from gill_amd.models import load_gill
   with pytest.raises(ValueError, match="model_args.json"):             # models.py:815-816
     load_gill("/nonexistent")
+  with pytest.raises(ValueError, match="empty prompt batch"):
+    g.generate_images([])
+  # image prompts without CLIP vision weights: a loud NotImplementedError, never a silent skip (and never a CPU fallback)
+  from PIL import Image
+  with pytest.raises((NotImplementedError, RuntimeError)):
+    g.generate_for_images_and_texts([Image.new("RGB", (40, 30)), "x"], num_words=2)
