@@ -42,7 +42,7 @@ struct ResnetW {
 };
 
 struct XfW {  // Transformer2DModel with one BasicTransformerBlock
-  int C = 0, d = 0, dp = 0, dpv = 0, layer_id = 0;
+  int C = 0, heads = 0, d = 0, dp = 0, dpv = 0, layer_id = 0;
   NormW gn;
   LinW proj_in, proj_out;
   NormW ln1, ln2, ln3;
@@ -234,7 +234,7 @@ struct Loader {
     return 0;
   }
   int xf(const std::string& p, int C, int H, int ctx_dim, int layer_id, XfW* x) {
-    x->C = C; x->d = C / H; x->dp = attn_padded_dim(x->d); x->dpv = round_up(x->dp, 32); x->layer_id = layer_id;
+    x->C = C; x->heads = H; x->d = C / H; x->dp = attn_padded_dim(x->d); x->dpv = round_up(x->dp, 32); x->layer_id = layer_id;
     GILL_REQUIRE(x->dp > 0, "unsupported attention head dim");
     const int hdp = H * x->dp;
     GILL_REQUIRE(hdp % 64 == 0, "padded attention width must be a multiple of 64");
@@ -311,7 +311,13 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
   hipStream_t s = nullptr;
   Loader L{wt, m->pool, s};
   const int* ch = cfg->block_out_channels;
-  const int H = cfg->num_heads, ctxd = cfg->cross_attention_dim;
+  const int ctxd = cfg->cross_attention_dim;
+  // heads per resolution level: SD-1.x uses num_heads everywhere, SD-2.x a fixed head dim of 64 (5, 10, 20, 20 heads)
+  int Hl[4];
+  for (int i = 0; i < 4; ++i) {
+    Hl[i] = cfg->heads_per_level[i] > 0 ? cfg->heads_per_level[i] : cfg->num_heads;
+    GILL_REQUIRE(Hl[i] > 0 && ch[i] % Hl[i] == 0, "heads must divide the channel count of their level");
+  }
   const int temb_dim = ch[0] * 4;
   m->temb_dim = temb_dim;
 
@@ -365,14 +371,14 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
     if (i < 3) {
       m->down_xf[i].resize(2);
       for (int j = 0; j < 2; ++j)
-        if ((rc = L.xf(p + ".attentions." + std::to_string(j), ch[i], H, ctxd, layer_id++, &m->down_xf[i][j]))) return fail(rc);
+        if ((rc = L.xf(p + ".attentions." + std::to_string(j), ch[i], Hl[i], ctxd, layer_id++, &m->down_xf[i][j]))) return fail(rc);
       if ((rc = L.conv3(p + ".downsamplers.0.conv", ch[i], ch[i], &m->down_ds[i]))) return fail(rc);
     }
   }
   // mid
   if ((rc = L.resnet("mid_block.resnets.0", ch[3], ch[3], temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[0])))
     return fail(rc);
-  if ((rc = L.xf("mid_block.attentions.0", ch[3], H, ctxd, layer_id++, &m->mid_xf))) return fail(rc);
+  if ((rc = L.xf("mid_block.attentions.0", ch[3], Hl[3], ctxd, layer_id++, &m->mid_xf))) return fail(rc);
   if ((rc = L.resnet("mid_block.resnets.1", ch[3], ch[3], temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[1])))
     return fail(rc);
   // up blocks: UpBlock2D, CrossAttnUpBlock2D x3
@@ -392,7 +398,7 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
     if (i > 0) {
       m->up_xf[i].resize(3);
       for (int j = 0; j < 3; ++j)
-        if ((rc = L.xf(p + ".attentions." + std::to_string(j), outc, H, ctxd, layer_id++, &m->up_xf[i][j]))) return fail(rc);
+        if ((rc = L.xf(p + ".attentions." + std::to_string(j), outc, Hl[3 - i], ctxd, layer_id++, &m->up_xf[i][j]))) return fail(rc);
     }
     if (i < 3)
       if ((rc = L.conv3(p + ".upsamplers.0.conv", outc, outc, &m->up_us[i]))) return fail(rc);
@@ -534,8 +540,8 @@ struct UNetRun {
     if (dry) return 0;
     AttnArgs a;
     a.Q = q; a.K = k; a.Vt = vt; a.O = o;
-    a.B = Bx; a.H = m->cfg.num_heads; a.nq = nq; a.nkv = nkv; a.nq_pad = nq_pad; a.nkv_pad = nkv_pad;
-    a.dp = w.dp; a.dpv = w.dpv; a.ldo = m->cfg.num_heads * w.dp;
+    a.B = Bx; a.H = w.heads; a.nq = nq; a.nkv = nkv; a.nq_pad = nq_pad; a.nkv_pad = nkv_pad;
+    a.dp = w.dp; a.dpv = w.dpv; a.ldo = w.heads * w.dp;
     a.scale = 1.0f / sqrtf((float)w.d);
     return attention_launch(a, s);
   }
@@ -546,7 +552,7 @@ struct UNetRun {
     const int Bpre = Bx, Bfull = shared ? 2 * Bx : Bx;
     Bx = Bfull;                    // every buffer is sized for the full batch
     const int H = x.H, Wd = x.W, C = w.C, HW = H * Wd, M = Bfull * HW, M1 = Bpre * HW;
-    const int nh = m->cfg.num_heads, hdp = nh * w.dp;
+    const int nh = w.heads, hdp = nh * w.dp;
     *out = talloc(H, Wd, C, out_stats);
     const size_t mk = m->arena.mark();
     Tensor n = talloc(H, Wd, C);
@@ -715,8 +721,8 @@ static int unet_plan_and_alloc(gill_unet* m) {
   // cross-attention K/V caches
   m->ctx_pad = round_up(c.ctx_len, 32);
   auto alloc_cache = [&](const XfW& w) -> int {
-    GILL_TRY(m->pool.alloc(&m->kcache[w.layer_id], (size_t)Bx * c.num_heads * m->ctx_pad * w.dp, true));
-    GILL_TRY(m->pool.alloc(&m->vcache[w.layer_id], (size_t)Bx * c.num_heads * w.dpv * m->ctx_pad, true));
+    GILL_TRY(m->pool.alloc(&m->kcache[w.layer_id], (size_t)Bx * w.heads * m->ctx_pad * w.dp, true));
+    GILL_TRY(m->pool.alloc(&m->vcache[w.layer_id], (size_t)Bx * w.heads * w.dpv * m->ctx_pad, true));
     return 0;
   };
   for (int i = 0; i < 3; ++i) for (const XfW& w : m->down_xf[i]) GILL_TRY(alloc_cache(w));
@@ -768,10 +774,10 @@ static int unet_ctx_cache(gill_unet* m, const bf16_t* ctx, int Bx, hipStream_t s
   const gill_unet_config& c = m->cfg;
   auto one = [&](const XfW& w) -> int {
     GemmArgs g;
-    g.M = Bx * c.ctx_len; g.N = 2 * c.num_heads * w.dp; g.K = c.cross_attention_dim; g.K1 = g.K;
+    g.M = Bx * c.ctx_len; g.N = 2 * w.heads * w.dp; g.K = c.cross_attention_dim; g.K1 = g.K;
     g.A = ctx; g.lda = c.cross_attention_dim; g.W = w.wkv2;
     g.out_mode = OUT_QKV; g.Ck = m->kcache[w.layer_id]; g.Cvt = m->vcache[w.layer_id];
-    g.heads = c.num_heads; g.dp = w.dp; g.dpv = w.dpv; g.ntok = c.ctx_len; g.ntok_pad_q = m->ctx_pad;
+    g.heads = w.heads; g.dp = w.dp; g.dpv = w.dpv; g.ntok = c.ctx_len; g.ntok_pad_q = m->ctx_pad;
     g.ntok_pad_kv = m->ctx_pad; g.seg_base = 1;
     return gemm_launch(g, s);
   };
@@ -930,14 +936,19 @@ extern "C" int gill_sd_denoise(gill_unet* m, const void* cond_bf16, const void* 
     else if (n_ets == 2) a.mode = 2;
     else if (n_ets == 3) a.mode = 3;
     else a.mode = 4;
-    // _get_prev_sample (epsilon prediction)
+    // _get_prev_sample
     const double at = ac[t];
     const double ap = prev_t >= 0 ? (double)ac[prev_t] : (double)ac[0];   // set_alpha_to_one = False
     const double bt = 1.0 - at, bp = 1.0 - ap;
     const double sample_coeff = sqrt(ap / at);
     const double denom = at * sqrt(bp) + sqrt(at * bt * ap);
-    a.sample_coeff = (float)sample_coeff;
-    a.eps_coeff = (float)((ap - at) / denom);
+    double sc = sample_coeff, ec = (ap - at) / denom;
+    if (c.v_prediction) {   // the model output is v: eps' = sqrt(a_t) v + sqrt(1 - a_t) sample, folded into the two coefficients
+      sc -= ec * sqrt(bt);
+      ec *= sqrt(at);
+    }
+    a.sample_coeff = (float)sc;
+    a.eps_coeff = (float)ec;
     GILL_TRY(plms_step_launch(a, s));
     ++counter;
   }

@@ -44,9 +44,11 @@ class GillSDPipeline:
     ccfg = N.gill_unet_config(in_channels=cfg.in_channels, out_channels=cfg.out_channels,
                               layers_per_block=cfg.layers_per_block, cross_attention_dim=cfg.cross_attention_dim,
                               num_heads=cfg.num_heads, norm_num_groups=cfg.norm_num_groups,
+                              v_prediction=int(cfg.prediction_type == "v_prediction"),
                               sample_size=cfg.sample_size, ctx_len=cfg.ctx_len, max_batch=max_batch)
     for i in range(4):
       ccfg.block_out_channels[i] = cfg.block_out_channels[i]
+      ccfg.heads_per_level[i] = cfg.heads_per_level[i] if cfg.heads_per_level else 0
     arr, keep = N.make_tensor_table(unet_state, self.device)
     h = C.c_void_p()
     with torch.cuda.device(self.device):
@@ -100,11 +102,18 @@ class GillSDPipeline:
     from safetensors.torch import load_file
     with open(os.path.join(model_dir, "unet", "config.json")) as f:
       c = json.load(f)
-    heads = c["attention_head_dim"] if isinstance(c["attention_head_dim"], int) else c["attention_head_dim"][0]
+    ahd = c["attention_head_dim"]     # diffusers quirk: this field holds the head COUNT(s)
+    heads = ahd if isinstance(ahd, int) else ahd[0]
+    pred = "epsilon"
+    spath = os.path.join(model_dir, "scheduler", "scheduler_config.json")
+    if os.path.exists(spath):
+      with open(spath) as f:
+        pred = json.load(f).get("prediction_type", "epsilon")
     cfg = UNetConfig(in_channels=c["in_channels"], out_channels=c["out_channels"],
                      block_out_channels=tuple(c["block_out_channels"]), layers_per_block=c["layers_per_block"],
                      cross_attention_dim=c["cross_attention_dim"], num_heads=heads,
-                     norm_num_groups=c["norm_num_groups"], sample_size=c["sample_size"])
+                     norm_num_groups=c["norm_num_groups"], sample_size=c["sample_size"],
+                     heads_per_level=None if isinstance(ahd, int) else tuple(ahd), prediction_type=pred)
     wpath = os.path.join(model_dir, "unet", "diffusion_pytorch_model.safetensors")
     sd = load_file(wpath)
     if uncond_embeds is None:

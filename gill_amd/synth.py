@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import zlib
 from dataclasses import dataclass, field
-from typing import Dict, List, Tuple
+from typing import Optional, Dict, List, Tuple
 
 import numpy as np
 import torch
@@ -193,10 +193,26 @@ class UNetConfig:
   norm_num_groups: int = 32
   sample_size: int = 64
   ctx_len: int = 77
+  heads_per_level: Optional[Tuple[int, int, int, int]] = None   # SD-2.x: fixed head dim 64 -> (5, 10, 20, 20) heads
+  prediction_type: str = "epsilon"                              # "v_prediction" for SD-2.1-768
+
+  def heads(self, level: int) -> int:
+    return self.heads_per_level[level] if self.heads_per_level else self.num_heads
 
   @staticmethod
   def sd15():
     return UNetConfig()
+
+  @staticmethod
+  def sd21_768():
+    """BASELINE.json configs[3]: the SD-2.1 768x768 UNet (same topology; head dim 64 at every level, OpenCLIP 1024-d
+    context, 96x96 latents, v-prediction; its Linear proj_in/proj_out are the same maps as SD-1.x's 1x1 convs)."""
+    return UNetConfig(cross_attention_dim=1024, sample_size=96, heads_per_level=(5, 10, 20, 20), prediction_type="v_prediction")
+
+  @staticmethod
+  def tiny_sd2(sample_size=16):
+    return UNetConfig(block_out_channels=(64, 128, 256, 256), cross_attention_dim=128, sample_size=sample_size,
+                      heads_per_level=(1, 2, 4, 4), prediction_type="v_prediction")
 
   @staticmethod
   def tiny(sample_size=16):

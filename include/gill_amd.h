@@ -152,6 +152,8 @@ typedef struct {
   int32_t sample_size;          /* 64 latent pixels per side */
   int32_t ctx_len;              /* 77 */
   int32_t max_batch;            /* largest UNet batch (2 x prompts with CFG) */
+  int32_t heads_per_level[4];   /* all 0: num_heads at every level (SD-1.x); SD-2.x: 5,10,20,20 (head dim 64 everywhere) */
+  int32_t v_prediction;         /* 0: the UNet predicts epsilon (SD-1.x, SD-2.1-base); 1: v (SD-2.1-768) */
 } gill_unet_config;
 
 int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, const gill_tensor* weights, int n_weights);

@@ -36,13 +36,13 @@ def sd_embedding(opt_sd, mapper_sd, num_layers: int, num_heads: int, ids: torch.
 
 def denoise(unet_sd: Dict[str, torch.Tensor], cond: torch.Tensor, uncond: Optional[torch.Tensor], latents: torch.Tensor,
             num_inference_steps: int = 50, guidance_scale: float = 7.5,
-            block_out_channels: Sequence[int] = (320, 640, 1280, 1280), heads: int = 8, groups: int = 32,
-            return_eps: bool = False):
+            block_out_channels: Sequence[int] = (320, 640, 1280, 1280), heads=8, groups: int = 32,
+            return_eps: bool = False, prediction_type: str = "epsilon"):
   """custom_sd.py:588-651 (without VAE decode): cond (B,77,768), uncond (1,77,768), latents (B,4,L,L) fp32."""
   B = cond.shape[0]
   do_cfg = guidance_scale > 1.0
   ctx = torch.cat([uncond.expand(B, -1, -1), cond], 0) if do_cfg else cond     # custom_sd.py:371
-  sched = scheduler_ref.PNDMSchedulerRef()
+  sched = scheduler_ref.PNDMSchedulerRef(prediction_type=prediction_type)
   sched.set_timesteps(num_inference_steps)                                      # :607
   lat = latents.float() * sched.init_noise_sigma                                # :472
   eps_trace = []

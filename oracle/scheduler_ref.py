@@ -21,8 +21,9 @@ class PNDMSchedulerRef:
   order = 1
 
   def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012,
-               steps_offset: int = 1):
+               steps_offset: int = 1, prediction_type: str = "epsilon"):
     self.num_train_timesteps = num_train_timesteps
+    self.prediction_type = prediction_type            # "v_prediction": SD-2.1-768
     self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
     self.alphas = 1.0 - self.betas
     self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
@@ -75,6 +76,8 @@ class PNDMSchedulerRef:
     a_t = self.alphas_cumprod[timestep]
     a_p = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
     b_t, b_p = 1 - a_t, 1 - a_p
+    if self.prediction_type == "v_prediction":        # diffusers PNDMScheduler._get_prev_sample
+      model_output = (a_t ** 0.5) * model_output + (b_t ** 0.5) * sample
     sample_coeff = (a_p / a_t) ** 0.5
     denom = a_t * b_p ** 0.5 + (a_t * b_t * a_p) ** 0.5
     return sample_coeff * sample - (a_p - a_t) * model_output / denom

@@ -86,8 +86,13 @@ def _transformer(sd, p, x, ctx, heads, groups):
   return _conv(sd, p + ".proj_out", h, padding=0) + res
 
 
+def _h(heads, level):
+  """heads: one count for every level (SD-1.x) or one per resolution level (SD-2.x: 5, 10, 20, 20)."""
+  return heads if isinstance(heads, int) else heads[level]
+
+
 def unet_forward(sd: Dict[str, torch.Tensor], sample: torch.Tensor, timesteps: torch.Tensor, ctx: torch.Tensor,
-                 block_out_channels: Sequence[int] = (320, 640, 1280, 1280), heads: int = 8, groups: int = 32) -> torch.Tensor:
+                 block_out_channels: Sequence[int] = (320, 640, 1280, 1280), heads=8, groups: int = 32) -> torch.Tensor:
   """sample (B,4,L,L), timesteps (B,), ctx (B,77,ctx_dim) -> predicted noise (B,4,L,L); all fp32."""
   ch = block_out_channels
   x = sample.float()
@@ -100,20 +105,20 @@ def unet_forward(sd: Dict[str, torch.Tensor], sample: torch.Tensor, timesteps: t
     for j in range(2):
       x = _resnet(sd, f"down_blocks.{i}.resnets.{j}", x, temb, groups)
       if i < 3:
-        x = _transformer(sd, f"down_blocks.{i}.attentions.{j}", x, ctx, heads, groups)
+        x = _transformer(sd, f"down_blocks.{i}.attentions.{j}", x, ctx, _h(heads, i), groups)
       skips.append(x)
     if i < 3:
       x = _conv(sd, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2, padding=1)
       skips.append(x)
   x = _resnet(sd, "mid_block.resnets.0", x, temb, groups)
-  x = _transformer(sd, "mid_block.attentions.0", x, ctx, heads, groups)
+  x = _transformer(sd, "mid_block.attentions.0", x, ctx, _h(heads, 3), groups)
   x = _resnet(sd, "mid_block.resnets.1", x, temb, groups)
   for i in range(4):
     for j in range(3):
       x = torch.cat([x, skips.pop()], dim=1)
       x = _resnet(sd, f"up_blocks.{i}.resnets.{j}", x, temb, groups)
       if i > 0:
-        x = _transformer(sd, f"up_blocks.{i}.attentions.{j}", x, ctx, heads, groups)
+        x = _transformer(sd, f"up_blocks.{i}.attentions.{j}", x, ctx, _h(heads, 3 - i), groups)
     if i < 3:
       x = F.interpolate(x, scale_factor=2.0, mode="nearest")
       x = _conv(sd, f"up_blocks.{i}.upsamplers.0.conv", x)

@@ -356,6 +356,33 @@ def test_denoise_tiny_vs_oracle(cuda):
   assert relb < 8e-2
 
 
+def test_sd2_geometry_tiny_vs_oracle(cuda):
+  """BASELINE.json configs[3] (SD-2.1-768 UNet) as a parity case, reduced width: a different head count at every level
+  (fixed head dim 64), and v-prediction in the PLMS update."""
+  from gill_amd.sd import GillSDPipeline
+  from oracle import pipeline_ref, unet_ref
+  cfg = synth.UNetConfig.tiny_sd2(16)
+  sd = _bfw(synth.unet_state_dict(cfg, seed=4))
+  uncond = synth.uncond_context(cfg.ctx_len, cfg.cross_attention_dim, seed=4).bfloat16().float()
+  pipe = GillSDPipeline(sd, cfg, uncond, cuda, max_batch=8)
+  B = 2
+  x = synth.normal("sd2_x", (B, 4, 16, 16), 9)
+  ctx = synth.normal("sd2_ctx", (B, 77, cfg.cross_attention_dim), 9).bfloat16().float()
+  t = torch.tensor([981.0, 301.0])
+  ref = unet_ref.unet_forward(sd, x, t, ctx, cfg.block_out_channels, cfg.heads_per_level, cfg.norm_num_groups)
+  got = pipe.unet(x, t, ctx)
+  _, rel, cos = _stats("SD-2.x geometry UNet forward", got, ref)
+  assert rel < 5e-2 and cos > 0.998
+  cond = ctx[:1]
+  lat0 = synth.initial_latents(1, 4, 16, seed=1337)
+  refl = pipeline_ref.denoise(sd, cond, uncond, lat0, 8, 7.5, cfg.block_out_channels, cfg.heads_per_level, cfg.norm_num_groups,
+                              prediction_type="v_prediction")
+  gotl = pipe(prompt_embeds=cond, latents=lat0, guidance_scale=7.5, num_inference_steps=8).images
+  _, rell, cosl = _stats("SD-2.x v-prediction denoise 8 steps", gotl, refl)
+  # v-prediction feeds sqrt(1 - a_t) * sample back through the update: bf16 differences compound faster than with epsilon
+  assert rell < 1.5e-1 and cosl > 0.99
+
+
 @pytest.mark.skipif(os.environ.get("GILL_SKIP_SLOW") == "1", reason="slow CPU oracle")
 def test_unet_forward_sd15_vs_oracle(cuda):
   """Full-size SD-1.5 UNet (860 M parameters, 64x64 latents), one forward of batch 2 against the CPU oracle."""
