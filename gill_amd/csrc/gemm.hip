@@ -745,7 +745,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   // 64-row tiles for plain GEMMs whose 128-row tiling leaves CUs without a tile (GILL_GEMM_BM = 64 | 128 forces it)
   static const int forced_bm = env_int("GILL_GEMM_BM");
   d.nwv = 4;
-  if (!a.conv && sk == 1 && stages == 2 && (int64_t)cdiv(a.M, 128) * d.tiles_n < 200 && a.M > 64) d.nwv = 2;
+  if (!a.conv && sk == 1 && stages == 2 && (int64_t)cdiv(a.M, 128) * d.tiles_n < 300 && a.M > 64) d.nwv = 2;   // measured: < 300 +0.3 %, < 520 -3 % end to end
   if (forced_bm == 128) d.nwv = 4;
   if (forced_bm == 64 && !a.conv && sk == 1 && stages == 2) d.nwv = 2;
   const int tiles_m = cdiv(a.M, d.nwv * 32);
