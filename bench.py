@@ -2,17 +2,24 @@
 """Benchmark of the GILL image-generation hot path on MI355X (contract: see the task brief / DESIGN.md section 6).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU)
+  (N > 1: one rank per GPU.  Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` the ranks read
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; a plain `python bench.py --gpus N` re-executes itself under torch.distributed.run
+  on 127.0.0.1 with a free port.)
 
 A "step" = one pass of the hot path over one batch of synthetic prompts: token ids -> frozen OPT-6.7B forward ->
 8 [IMG] hidden states -> GILLMapper -> (B,77,768) -> SD-1.5 UNet CFG/PLMS loop (50 steps = 51 UNet calls of batch 2B)
--> final latents, all-gathered over ranks.  Workload at every N: BASELINE.json configs[1] per GPU (4 prompts/GPU,
-weak scaling); inputs (ids, weights, initial latents) are resident in HBM before the timed region.
+-> final latents, all-gathered over ranks -> VAE decode of the local shard to uint8 512x512.  Workload: N = 1 is
+BASELINE.json configs[1] (4 prompts on the GPU); N > 1 is configs[2] (8 prompts per GPU: batch 64 over 8), weak scaling
+over N >= 2; --prompts-per-gpu overrides.  Inputs (ids, weights, initial latents) are resident in HBM before the timed
+region.  EVERY timed step's latents are kept and checked after the timed region (finite, and within REL_STEP_TOL of the
+first step's: the workload repeats the same inputs); a violation prints the per-step table and exits non-zero.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 UNET_TFLOP_PER_SAMPLE_FORWARD = 0.8032   # 401.6 GMAC, SD-1.5, 64x64 latents
 PEAK_BF16_TFLOPS = 2500.0                # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+REL_STEP_TOL = 2e-2                      # rel-L2 of a step's final latents vs the first timed step's (same inputs every step)
 
 
 def gpu_state_dict(builder, cfg, dev, seed):
@@ -97,17 +105,51 @@ def build_model(dev, opt_cfg, unet_cfg, max_prompts):
   return g
 
 
-def pmc_traffic_gb(prompts_per_step):
-  """HBM bytes of one step from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE /
-  WRITE_SIZE over this very command, corrected as MI355X_MICROARCH.md prescribes), scaled to this run's prompts per step.
-  bench.py cannot run a profiler around itself; None when the file is absent."""
-  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-  if not os.path.exists(path):
-    return None
-  with open(path) as f:
-    t = json.load(f)
-  kb = t["FETCH_SIZE_kb_hot_path"] * t["gfx950_fetch_correction"] + t["WRITE_SIZE_kb_hot_path"]
-  return kb * 1024.0 / 1e9 * (prompts_per_step / 4.0)
+SETUP_KERNELS = ("at::native", "__amd_rocclr", "convert_", "relayout", "pad_head", "scatter_rows", "permute", "ln_fold",
+                 "vec_add", "cast_")   # weight set-up / torch's own kernels: not the hot path
+
+
+def pmc_traffic_live(a):
+  """HBM bytes of ONE step of this very workload, measured now: two rocprofv3 passes (--pmc FETCH_SIZE, then --pmc WRITE_SIZE;
+  counters only, no trace domains) over a child `bench.py --steps 1 --warmup 0 --child-pmc` with the same prompts / steps, summed
+  over every dispatch of the hot-path kernels and corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE on gfx950 tallies
+  128-B requests as 64 B: x2; both counters are in KiB).  The child runs the forward eagerly (GILL_NO_GRAPH=1) so that every
+  kernel is a dispatch of its own for the counter service.  Returns (GB per step, detail dict) or (None, reason)."""
+  import csv
+  import glob
+  import shutil
+  import tempfile
+  rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+  if not os.path.exists(rocprof):
+    return None, "rocprofv3 not found"
+  tot = {}
+  t0 = time.time()
+  for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    d = tempfile.mkdtemp(prefix=f"gill_pmc_{ctr}_", dir="/tmp")
+    env = dict(os.environ, GILL_NO_GRAPH="1", TMPDIR="/tmp")
+    cmd = [rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+           "--steps", "1", "--warmup", "0", "--child-pmc", "--prompts-per-gpu", str(a.prompts_per_gpu),
+           "--infer-steps", str(a.infer_steps), "--prompt-len", str(a.prompt_len)]
+    try:
+      r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=a.pmc_timeout)
+    except subprocess.TimeoutExpired:
+      shutil.rmtree(d, ignore_errors=True)
+      return None, f"rocprofv3 --pmc {ctr} pass exceeded {a.pmc_timeout} s"
+    kb, n = 0.0, 0
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+      with open(f) as fh:
+        for row in csv.DictReader(fh):
+          if row["Counter_Name"] != ctr or any(t in row["Kernel_Name"] for t in SETUP_KERNELS):
+            continue
+          kb += float(row["Counter_Value"])
+          n += 1
+    shutil.rmtree(d, ignore_errors=True)
+    if r.returncode != 0 or n == 0:
+      return None, f"rocprofv3 --pmc {ctr} pass failed (rc {r.returncode}, {n} dispatches): {r.stdout.decode(errors='replace')[-300:]}"
+    tot[ctr] = (kb, n)
+  gb = (tot["FETCH_SIZE"][0] * 2.0 + tot["WRITE_SIZE"][0]) * 1024.0 / 1e9
+  return gb, {"FETCH_SIZE_KiB_raw": tot["FETCH_SIZE"][0], "WRITE_SIZE_KiB": tot["WRITE_SIZE"][0], "gfx950_fetch_correction": 2.0,
+              "dispatches": tot["FETCH_SIZE"][1], "passes_s": round(time.time() - t0, 1)}
 
 
 def kernel_rooflines(dev):
@@ -158,29 +200,48 @@ def cpu_baseline(n_infer_steps):
   t_map = time.time() - t0
   per_image = (n_infer_steps + 1) * t_unet + t_map
   return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
-          "sample": f"1 SD-1.5 UNet forward of the CFG pair (batch 2, 1.61 TFLOP): {t_unet:.2f} s; GILLMapper B=1: {t_map * 1e3:.0f} ms; "
+          "sample": f"UNet loop + GILLMapper only: 1 SD-1.5 UNet forward of the CFG pair (batch 2, 1.61 TFLOP): {t_unet:.2f} s; GILLMapper B=1: {t_map * 1e3:.0f} ms; "
                     f"extrapolated x{n_infer_steps + 1} UNet calls per image (OPT forward excluded from the sample)"}
+
+
+def respawn_under_torchrun(a):
+  """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+  with socket.socket() as sk:
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+  env = dict(os.environ)
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=2)
-  ap.add_argument("--warmup", type=int, default=1)
-  ap.add_argument("--prompts-per-gpu", type=int, default=4)
+  ap.add_argument("--steps", type=int, default=5)
+  ap.add_argument("--warmup", type=int, default=2)
+  ap.add_argument("--prompts-per-gpu", type=int, default=0, help="default: 4 at --gpus 1 (BASELINE configs[1]), 8 at --gpus > 1 (configs[2])")
   ap.add_argument("--infer-steps", type=int, default=50)
   ap.add_argument("--prompt-len", type=int, default=24)
   ap.add_argument("--small", action="store_true", help="opt-125m shapes (debug only; not the benchmark config)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
+  ap.add_argument("--pmc-timeout", type=int, default=300)
+  ap.add_argument("--child-pmc", action="store_true", help=argparse.SUPPRESS)   # the profiled child of pmc_traffic_live
   a = ap.parse_args()
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local = int(os.environ.get("LOCAL_RANK", "0"))
+  if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    respawn_under_torchrun(a)
   if world > 1:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
   assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+  if a.prompts_per_gpu <= 0:
+    a.prompts_per_gpu = 4 if a.gpus == 1 else 8
   dev = torch.device("cuda", local)
   torch.cuda.set_device(dev)
 
@@ -192,7 +253,8 @@ def main():
   ids = synth.synthetic_prompt_ids(P * world, a.prompt_len, seed=0)[:, :a.prompt_len]   # [IMG] ids are appended by generate_images
   lat0 = synth.initial_latents(P * world, 4, unet_cfg.sample_size, seed=1337).to(dev)
 
-  # HIP events around the UNet loop (same stream the kernels are launched on: torch's current stream)
+  # HIP events around the UNet loop: recorded on torch's current stream, which gill_sd_denoise fences its private launch stream
+  # to on both sides (event record -> stream wait), so the pair brackets exactly the loop's kernels
   ev = {"t": []}
   orig_call = g.sd_pipe.__class__.__call__
 
@@ -224,12 +286,13 @@ def main():
     step()
   ev["t"].clear()
   vae_ev.clear()
+  kept = []
   if world > 1:
     dist.barrier()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   for _ in range(a.steps):
-    out, images = step()
+    kept.append(step())      # (latents of all ranks, uint8 images of this rank): 0.25 + 3 MiB per prompt, checked below
   if world > 1:
     dist.barrier()
   torch.cuda.synchronize()
@@ -238,26 +301,65 @@ def main():
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
-  assert out.shape == (P * world, 4, unet_cfg.sample_size, unet_cfg.sample_size) and bool(torch.isfinite(out).all())
-  assert images.shape == (P, 512, 512, 3) and images.dtype == torch.uint8
+  if a.child_pmc:
+    return
+
+  # every timed step must have produced the same finite result (same inputs each step; fp32 atomics in the fused
+  # GroupNorm / LayerNorm sums are the only run-to-run difference)
+  ref_lat, ref_img = kept[0][0].float(), kept[0][1].float()
+  table, ok = [], True
+  for i, (lat, img) in enumerate(kept):
+    shape_ok = tuple(lat.shape) == (P * world, 4, unet_cfg.sample_size, unet_cfg.sample_size) and \
+        tuple(img.shape) == (P, 512, 512, 3) and img.dtype == torch.uint8
+    lat = lat.float()
+    n_bad = int((~torch.isfinite(lat)).sum().item())
+    rel = float(((lat - ref_lat).norm() / ref_lat.norm()).item()) if n_bad == 0 else float("nan")
+    img_mad = float((img.float() - ref_img).abs().mean().item())
+    img_std = float(img.float().std().item())
+    good = shape_ok and n_bad == 0 and rel <= REL_STEP_TOL and img_std > 1.0
+    ok &= good
+    table.append((i, shape_ok, n_bad, rel, img_mad, img_std, good))
+  okt = torch.tensor([1 if ok else 0], device=dev)
+  if world > 1:
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+  if not ok:
+    print(f"[bench rank {rank}] OUTPUT CHECK FAILED (tolerance rel-L2 {REL_STEP_TOL} vs the first timed step):", file=sys.stderr)
+    for row in table:
+      print("  step %3d shape_ok=%s nonfinite=%d rel_l2_vs_step0=%.3e image_mean_abs_diff=%.3f image_std=%.2f %s" %
+            (row[:6] + ("ok" if row[6] else "BAD",)), file=sys.stderr)
+  if int(okt.item()) == 0:
+    if world > 1:
+      dist.destroy_process_group()
+    sys.exit(3)
+  max_rel = max(r[3] for r in table)
 
   if rank == 0:
     images = P * world * a.steps
     value = images / dt
-    unet_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev["t"]) / max(1, len(ev["t"]))   # per sd_pipe call (P prompts)
+    unet_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev["t"]) / max(1, len(ev["t"]))   # per sd_pipe call (<= 8 prompts)
     vae_ms = sum(e0.elapsed_time(e1) for e0, e1 in vae_ev) / max(1, len(vae_ev))
-    flop_per_call = UNET_TFLOP_PER_SAMPLE_FORWARD * 2 * (a.infer_steps + 1) * P
+    per_call = min(P, 8)                                                               # gen_max_bs = 8 chunks (models.py:726)
+    flop_per_call = UNET_TFLOP_PER_SAMPLE_FORWARD * 2 * (a.infer_steps + 1) * per_call
     achieved = flop_per_call / (unet_ms * 1e-3)
+    traffic, traffic_detail = (None, "skipped (--no-pmc or N > 1)")
+    if world == 1 and not a.no_pmc and not a.small:
+      del kept
+      traffic, traffic_detail = pmc_traffic_live(a)
+    cfg_name = "configs[1]" if (world == 1 and P == 4) else ("configs[2]" if P == 8 else "custom")
     rec = {
       "metric": "512x512 images/sec/node, OPT-6.7B+SD1.5 50-step", "value": value, "unit": "images/s",
       "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-      "config": {"workload": f"{'opt-125m' if a.small else 'opt-6.7b'} + GILLMapper + SD-1.5 UNet (random-init weights of the "
-                             f"exact shapes), {P} prompts/GPU x {world} GPU, prompt {a.prompt_len}+8 [IMG] tokens, "
-                             f"{a.infer_steps} PLMS steps ({a.infer_steps + 1} UNet calls, CFG 7.5, batch {2 * P}), final latents "
-                             f"all-gathered, then VAE decode of the local shard to uint8 512x512 ({vae_ms:.1f} ms per {P} images)", "parallelism": f"dp{world}"},
+      "config": {"workload": f"BASELINE {cfg_name}: {'opt-125m' if a.small else 'opt-6.7b'} + GILLMapper + SD-1.5 UNet + VAE decoder "
+                             f"(random-init weights of the exact shapes), {P} prompts/GPU x {world} GPU = batch {P * world}, prompt "
+                             f"{a.prompt_len}+8 [IMG] tokens, {a.infer_steps} PLMS steps ({a.infer_steps + 1} UNet calls, CFG 7.5, UNet batch "
+                             f"{2 * per_call}), final latents all-gathered, then VAE decode of the local shard to uint8 512x512 "
+                             f"({vae_ms:.1f} ms per {P} images)", "parallelism": f"dp{world}", "prompts_per_gpu": P},
+      "output_check": {"steps_checked": len(table), "max_rel_l2_vs_first_step": max_rel, "tolerance": REL_STEP_TOL, "all_finite": True},
       "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                   "frac": achieved / PEAK_BF16_TFLOPS, "traffic": pmc_traffic_gb(P), "traffic_unit": "GB per step (PMC, profiles/r01_pmc_traffic.json)",
+                   "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                   "traffic_unit": "GB of HBM traffic per step (all hot-path kernels of the step; live rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes)",
+                   "traffic_detail": traffic_detail,
                    "kernel": "SD-1.5 UNet denoise loop (gill_sd_denoise: MFMA GEMM/implicit-conv + flash attention kernels)",
                    "algorithmic_tflop_per_launch": flop_per_call, "avg_launch_ms": unet_ms},
     }

@@ -293,7 +293,52 @@ int skinny_gemm_launch(const bf16_t* x, const bf16_t* W, int M, int N, int K, fl
 }
 
 // ---------------------------------------------------------------- CFG + PLMS
-__global__ __launch_bounds__(256) void plms_step_kernel(const PlmsStepArgs a) {
+__global__ __launch_bounds__(256) void zero_bytes_kernel(uint4* dst, int64_t n16) {
+  const uint4 z = {0u, 0u, 0u, 0u};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) dst[i] = z;
+}
+__global__ __launch_bounds__(256) void copy_bytes_kernel(uint4* dst, const uint4* src, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+int zero_bytes_launch(void* dst, size_t bytes, hipStream_t s) {
+  GILL_REQUIRE(((uintptr_t)dst & 15) == 0 && (bytes & 15) == 0, "zero_bytes: 16-byte alignment required");
+  if (bytes == 0) return 0;
+  hipLaunchKernelGGL(zero_bytes_kernel, dim3(grid_for((int64_t)(bytes / 16))), dim3(256), 0, s, (uint4*)dst, (int64_t)(bytes / 16));
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+int copy_bytes_launch(void* dst, const void* src, size_t bytes, hipStream_t s) {
+  GILL_REQUIRE((((uintptr_t)dst | (uintptr_t)src) & 15) == 0 && (bytes & 15) == 0, "copy_bytes: 16-byte alignment required");
+  if (bytes == 0) return 0;
+  hipLaunchKernelGGL(copy_bytes_kernel, dim3(grid_for((int64_t)(bytes / 16))), dim3(256), 0, s, (uint4*)dst, (const uint4*)src,
+                     (int64_t)(bytes / 16));
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void sd_stage_kernel(const SdLoopArgs a) {
+  const int step = a.ctr[0];          // nobody writes ctr[0] while this kernel runs
+  const int64_t total = (int64_t)a.B * a.n;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = t0; i < total; i += stride) {
+    const float v = a.lat[i];
+    a.lat2[i] = v;                    // scale_model_input is the identity for PNDM (custom_sd.py:630-631)
+    if (a.cfg) a.lat2[total + i] = v;
+  }
+  const float* row = a.temb_table + (size_t)step * a.temb_total;
+  for (int64_t i = t0; i < a.temb_total; i += stride) a.temb_cur[i] = row[i];
+  if (t0 == 0) a.ctr[1] = step;
+}
+int sd_stage_launch(const SdLoopArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(sd_stage_kernel, dim3(grid_for((int64_t)a.B * a.n)), dim3(256), 0, s, a);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void plms_step_kernel(const SdLoopArgs a) {
+  const int step = a.ctr[1];          // written by this step's stage kernel; nobody writes it while this kernel runs
+  const PlmsRow r = a.rows[step];
   const int64_t total = (int64_t)a.B * a.n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float e = a.eps[i];
@@ -304,31 +349,32 @@ __global__ __launch_bounds__(256) void plms_step_kernel(const PlmsStepArgs a) {
     float sample = a.lat[i];
     float ep;
     float* ets = a.ets;
-    if (a.mode == 0) {            // counter 0: plain step, remember the sample
+    if (r.mode == 0) {            // counter 0: plain step, remember the sample
       ep = e;
       a.cur_sample[i] = sample;
-      ets[(size_t)a.slot_new * total + i] = e;
-    } else if (a.mode == 1) {     // counter 1: average with ets[-1], restart from the remembered sample
-      ep = 0.5f * (e + ets[(size_t)a.s1 * total + i]);
+      ets[(size_t)r.slot_new * total + i] = e;
+    } else if (r.mode == 1) {     // counter 1: average with ets[-1], restart from the remembered sample
+      ep = 0.5f * (e + ets[(size_t)r.s1 * total + i]);
       sample = a.cur_sample[i];
     } else {
-      ets[(size_t)a.slot_new * total + i] = e;
+      ets[(size_t)r.slot_new * total + i] = e;
       const float e1 = e;
-      const float e2 = ets[(size_t)a.s1 * total + i];
-      if (a.mode == 2) ep = (3.f * e1 - e2) * 0.5f;
+      const float e2 = ets[(size_t)r.s1 * total + i];
+      if (r.mode == 2) ep = (3.f * e1 - e2) * 0.5f;
       else {
-        const float e3 = ets[(size_t)a.s2 * total + i];
-        if (a.mode == 3) ep = (23.f * e1 - 16.f * e2 + 5.f * e3) * (1.f / 12.f);
+        const float e3 = ets[(size_t)r.s2 * total + i];
+        if (r.mode == 3) ep = (23.f * e1 - 16.f * e2 + 5.f * e3) * (1.f / 12.f);
         else {
-          const float e4 = ets[(size_t)a.s3 * total + i];
+          const float e4 = ets[(size_t)r.s3 * total + i];
           ep = (55.f * e1 - 59.f * e2 + 37.f * e3 - 9.f * e4) * (1.f / 24.f);
         }
       }
     }
-    a.lat[i] = a.sample_coeff * sample - a.eps_coeff * ep;
+    a.lat[i] = r.sample_coeff * sample - r.eps_coeff * ep;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.ctr[0] = step + 1;   // read only by the next step's stage kernel
 }
-int plms_step_launch(const PlmsStepArgs& a, hipStream_t s) {
+int plms_step_launch(const SdLoopArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(plms_step_kernel, dim3(grid_for((int64_t)a.B * a.n)), dim3(256), 0, s, a);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;

@@ -47,6 +47,36 @@ struct DevPool {
   ~DevPool() { for (void* p : ptrs) (void)hipFree(p); }
 };
 
+// An engine's private launch stream, fenced to the caller's stream with two events: enter() makes the private stream
+// wait for everything the caller enqueued so far, leave() makes the caller's stream wait for the engine's work.
+struct StreamFence {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  int enter(hipStream_t caller) {
+    if (!stream) {
+      GILL_CHECK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+      GILL_CHECK_HIP(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+      GILL_CHECK_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+    }
+    GILL_CHECK_HIP(hipEventRecord(ev_in, caller));
+    GILL_CHECK_HIP(hipStreamWaitEvent(stream, ev_in, 0));
+    return 0;
+  }
+  int leave(hipStream_t caller) {
+    GILL_CHECK_HIP(hipEventRecord(ev_out, stream));
+    GILL_CHECK_HIP(hipStreamWaitEvent(caller, ev_out, 0));
+    return 0;
+  }
+  ~StreamFence() {
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_out) (void)hipEventDestroy(ev_out);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  StreamFence() = default;
+  StreamFence(const StreamFence&) = delete;
+  StreamFence& operator=(const StreamFence&) = delete;
+};
+
 struct WeightTable {
   std::unordered_map<std::string, const gill_tensor*> map;
   WeightTable(const gill_tensor* w, int n) { for (int i = 0; i < n; ++i) if (w[i].name) map[w[i].name] = &w[i]; }

@@ -107,20 +107,38 @@ int conv_out_launch(const bf16_t* x, const bf16_t* w /*[Cout][9][Cin]*/, const f
 // skinny GEMV-ish: out[M][N] (f32) = x[M][K] (bf16) . W[N][K]^T ; M <= 8, any N (lm_head)
 int skinny_gemm_launch(const bf16_t* x, const bf16_t* W, int M, int N, int K, float* out, hipStream_t s);
 // classifier-free guidance + PLMS update on fp32 NCHW latents (see unet.hip for the coefficient layout)
-struct PlmsStepArgs {
-  const float* eps;      // [2B][n] : uncond rows then cond rows
-  float* lat;            // [B][n] in/out
-  float* cur_sample;     // [B][n] saved sample (PLMS warm-up)
-  float* ets;            // [4][B][n] ring of past eps'
-  int B; int64_t n;      // n = C*H*W per sample
-  float guidance;
-  int cfg;               // 1: eps holds [uncond | cond] halves and guidance is applied; 0: eps is [B][n]
+// One row per UNet call of a denoise loop, computed on the host once per call of gill_sd_denoise and read by the
+// device: the loop's only per-step inputs.  The step index itself lives on the device (SdLoopArgs::ctr), so replaying one
+// captured UNet step N times needs no host-side per-step argument and no copy between replays.
+struct PlmsRow {
   int mode;              // 0: first step, 1: repeated step, 2..4: multistep orders
   int slot_new;          // ring slot to write the new guided eps into (-1: don't store)
   int s1, s2, s3;        // ring slots of ets[-2], ets[-3], ets[-4] where needed (ets[-1] = new / slot of last)
   float sample_coeff, eps_coeff;   // x_prev = sample_coeff * sample - eps_coeff * eps'
 };
-int plms_step_launch(const PlmsStepArgs& a, hipStream_t s);
+struct SdLoopArgs {
+  const PlmsRow* rows;   // [ncalls] on device
+  int* ctr;              // ctr[0]: next step (written by the PLMS kernel only), ctr[1]: current step (written by the stage kernel only)
+  const float* temb_table; int temb_total;   // [ncalls][temb_total] -> temb_cur
+  float* temb_cur;
+  const float* eps;      // [2B][n] : uncond rows then cond rows
+  float* lat;            // [B][n] in/out
+  float* lat2;           // [2B][n] (or [B][n]): the UNet input = cat([latents] * 2)
+  float* cur_sample;     // [B][n] saved sample (PLMS warm-up)
+  float* ets;            // [4][B][n] ring of past eps'
+  int B; int64_t n;      // n = C*H*W per sample
+  float guidance;
+  int cfg;               // 1: eps holds [uncond | cond] halves and guidance is applied; 0: eps is [B][n]
+};
+// plain device-side fill / copy kernels for use INSIDE a captured forward: hipMemsetAsync / hipMemcpyAsync become memset /
+// memcpy graph nodes, whose replay was not reliable (profiles/r02_soak_bisect.md).  16-byte aligned pointers and sizes.
+int zero_bytes_launch(void* dst, size_t bytes, hipStream_t s);
+int copy_bytes_launch(void* dst, const void* src, size_t bytes, hipStream_t s);
+// first kernel of a step: latents -> UNet input (both CFG halves), time-embedding row of the current step -> temb_cur
+int sd_stage_launch(const SdLoopArgs& a, hipStream_t s);
+// last kernel of a step: CFG combine + PLMS update of the latents (custom_sd.py:641-646), then step counter + 1
+int plms_step_launch(const SdLoopArgs& a, hipStream_t s);
+
 // weight re-layout helpers (run once at engine creation)
 int conv_weight_relayout_launch(const void* w, int dtype, int Cout, int Cin, bf16_t* out /*[Cout][9][Cin]*/, hipStream_t s);
 int convert_to_bf16_launch(const void* src, int dtype, int64_t n, bf16_t* dst, hipStream_t s);

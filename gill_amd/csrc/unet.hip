@@ -78,6 +78,15 @@ struct Arena {
 
 }  // namespace
 
+struct GraphKey {
+  int Bx, cfg; float guidance;
+  bool operator<(const GraphKey& o) const {
+    if (Bx != o.Bx) return Bx < o.Bx;
+    if (cfg != o.cfg) return cfg < o.cfg;
+    return guidance < o.guidance;
+  }
+};
+
 struct gill_unet {
   gill_unet_config cfg;
   DevPool pool;
@@ -119,14 +128,17 @@ struct gill_unet {
   float* ets = nullptr;         // [4][B][4*L*L]
   bf16_t* ctx_full = nullptr;   // [2B][77][768]
   float* temb_cur = nullptr;    // [temb_total]: time-embedding row of the step being replayed
+  PlmsRow* plms_rows = nullptr; // [temb_rows_cap]: per-step PLMS coefficients of the running loop
+  int* step_ctr = nullptr;      // [2]: next / current step of the running loop (SdLoopArgs::ctr)
   // hipGraph of one UNet forward per UNet batch size (captured after the first eager forward of that size)
-  std::map<int, hipGraphExec_t> graphs;
-  std::set<int> warmed;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  std::set<GraphKey> warmed;
   bool use_graph = true;
-  hipStream_t cap_stream = nullptr;
+  // The denoise loop runs on the handle's private stream, fenced to the caller's stream by events (capture needs a
+  // non-NULL stream anyway; see DESIGN.md "hipGraph replay and the NULL stream").
+  StreamFence fence;
   ~gill_unet() {
     for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
-    if (cap_stream) (void)hipStreamDestroy(cap_stream);
   }
 };
 
@@ -587,10 +599,10 @@ struct UNetRun {
     GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M1, w.out1.w, w.out1.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, st2));
     if (shared && !dry) {
       // second half of the pair := first half (residual stream, its LayerNorm row sums, the block input)
-      GILL_CHECK_HIP(hipMemcpyAsync(t.p + (size_t)M1 * C, t.p, sizeof(bf16_t) * (size_t)M1 * C, hipMemcpyDeviceToDevice, s));
-      GILL_CHECK_HIP(hipMemcpyAsync(st2 + (size_t)M1 * 2, st2, sizeof(float) * (size_t)M1 * 2, hipMemcpyDeviceToDevice, s));
-      GILL_CHECK_HIP(hipMemcpyAsync(xd.p, x.p, sizeof(bf16_t) * (size_t)M1 * C, hipMemcpyDeviceToDevice, s));
-      GILL_CHECK_HIP(hipMemcpyAsync(xd.p + (size_t)M1 * C, x.p, sizeof(bf16_t) * (size_t)M1 * C, hipMemcpyDeviceToDevice, s));
+      GILL_TRY(copy_bytes_launch(t.p + (size_t)M1 * C, t.p, sizeof(bf16_t) * (size_t)M1 * C, s));
+      GILL_TRY(copy_bytes_launch(st2 + (size_t)M1 * 2, st2, sizeof(float) * (size_t)M1 * 2, s));
+      GILL_TRY(copy_bytes_launch(xd.p, x.p, sizeof(bf16_t) * (size_t)M1 * C, s));
+      GILL_TRY(copy_bytes_launch(xd.p + (size_t)M1 * C, x.p, sizeof(bf16_t) * (size_t)M1 * C, s));
     }
     // --- cross attention (K/V cached per prompt)
     {
@@ -629,8 +641,8 @@ struct UNetRun {
     m->gn_next = 0;
     m->ln_next = 0;
     if (!dry) {
-      GILL_CHECK_HIP(hipMemsetAsync(m->gn_stats, 0, sizeof(float) * (size_t)m->gn_slots * m->gn_slot_floats, s));
-      GILL_CHECK_HIP(hipMemsetAsync(m->ln_stats, 0, sizeof(float) * m->ln_floats, s));
+      GILL_TRY(zero_bytes_launch(m->gn_stats, sizeof(float) * (size_t)m->gn_slots * m->gn_slot_floats, s));
+      GILL_TRY(zero_bytes_launch(m->ln_stats, sizeof(float) * m->ln_floats, s));
     }
     std::vector<Tensor> skips;
     Tensor x = talloc(L, L, ch[0], true);
@@ -743,6 +755,8 @@ static int unet_plan_and_alloc(gill_unet* m) {
   GILL_TRY(m->pool.alloc(&m->ets, (size_t)4 * Bx * n_lat));
   GILL_TRY(m->pool.alloc(&m->ctx_full, (size_t)Bx * c.ctx_len * c.cross_attention_dim));
   GILL_TRY(m->pool.alloc(&m->temb_cur, (size_t)m->temb_total));
+  GILL_TRY(m->pool.alloc(&m->plms_rows, (size_t)m->temb_rows_cap));
+  GILL_TRY(m->pool.alloc(&m->step_ctr, (size_t)2));
   { const char* e = getenv("GILL_NO_GRAPH"); m->use_graph = !(e && e[0] == '1'); }
   return 0;
 }
@@ -838,15 +852,26 @@ extern "C" int gill_pndm_schedule(int num_steps, int32_t* timesteps_out, double*
   return (int)ts.size();
 }
 
+static int sd_denoise_on(gill_unet* m, const void* cond_bf16, const void* uncond_bf16, const float* latents0, int B,
+                         int num_steps, float guidance, float* latents_out, hipStream_t s);
+
 extern "C" int gill_sd_denoise(gill_unet* m, const void* cond_bf16, const void* uncond_bf16, const float* latents0, int B,
                                int num_steps, float guidance, float* latents_out, void* stream) {
   GILL_REQUIRE(m && cond_bf16 && latents0 && latents_out, "null argument");
+  hipStream_t caller = (hipStream_t)stream;
+  GILL_TRY(m->fence.enter(caller));
+  const int rc = sd_denoise_on(m, cond_bf16, uncond_bf16, latents0, B, num_steps, guidance, latents_out, m->fence.stream);
+  GILL_TRY(m->fence.leave(caller));
+  return rc;
+}
+
+static int sd_denoise_on(gill_unet* m, const void* cond_bf16, const void* uncond_bf16, const float* latents0, int B,
+                         int num_steps, float guidance, float* latents_out, hipStream_t s) {
   GILL_REQUIRE(num_steps >= 2 && num_steps <= 1000, "num_steps out of range");
   const bool cfg = guidance > 1.0f;     // do_classifier_free_guidance (custom_sd.py:588)
   const int Bx = cfg ? 2 * B : B;
   GILL_REQUIRE(B >= 1 && Bx <= m->cfg.max_batch, "batch exceeds the UNet handle's max_batch");
   GILL_REQUIRE(!cfg || uncond_bf16 != nullptr, "uncond embedding required when guidance > 1");
-  hipStream_t s = (hipStream_t)stream;
   const gill_unet_config& c = m->cfg;
   const int L = c.sample_size;
   const int64_t n_lat = (int64_t)c.in_channels * L * L;
@@ -858,7 +883,48 @@ extern "C" int gill_sd_denoise(gill_unet* m, const void* cond_bf16, const void* 
   const int ncalls = (int)ts.size();
   GILL_REQUIRE(ncalls <= m->temb_rows_cap, "too many steps for the time-embedding scratch");
 
-  // hoisted: time-embedding table for every call, prompt K/V caches
+  // the PLMS schedule of every call (host arithmetic in double, like the scheduler's numpy/torch-CPU tables)
+  std::vector<PlmsRow> rows(ncalls);
+  {
+    int counter = 0, n_ets = 0, last = -1;
+    for (int i = 0; i < ncalls; ++i) {
+      int t = ts[i];
+      int prev_t = t - ratio;
+      PlmsRow& a = rows[i];
+      a.slot_new = -1; a.s1 = a.s2 = a.s3 = 0;
+      if (counter != 1) {
+        a.slot_new = (last + 1) & 3;
+        a.s1 = last & 3; a.s2 = (last + 3) & 3; a.s3 = (last + 2) & 3;
+        last = a.slot_new;
+        if (n_ets < 4) ++n_ets;
+      } else {
+        prev_t = t; t = t + ratio;
+        a.s1 = last & 3;
+      }
+      if (n_ets == 1 && counter == 0) a.mode = 0;
+      else if (n_ets == 1 && counter == 1) a.mode = 1;
+      else if (n_ets == 2) a.mode = 2;
+      else if (n_ets == 3) a.mode = 3;
+      else a.mode = 4;
+      // _get_prev_sample
+      const double at = ac[t];
+      const double ap = prev_t >= 0 ? (double)ac[prev_t] : (double)ac[0];   // set_alpha_to_one = False
+      const double bt = 1.0 - at, bp = 1.0 - ap;
+      const double sample_coeff = sqrt(ap / at);
+      const double denom = at * sqrt(bp) + sqrt(at * bt * ap);
+      double sc = sample_coeff, ec = (ap - at) / denom;
+      if (c.v_prediction) {   // the model output is v: eps' = sqrt(a_t) v + sqrt(1 - a_t) sample, folded into the two coefficients
+        sc -= ec * sqrt(bt);
+        ec *= sqrt(at);
+      }
+      a.sample_coeff = (float)sc;
+      a.eps_coeff = (float)ec;
+      ++counter;
+    }
+  }
+  GILL_CHECK_HIP(hipMemcpyAsync(m->plms_rows, rows.data(), sizeof(PlmsRow) * ncalls, hipMemcpyHostToDevice, s));
+  GILL_CHECK_HIP(hipMemsetAsync(m->step_ctr, 0, sizeof(int) * 2, s));
+  // hoisted: time-embedding table for every call (its stream sync also covers the host `rows` buffer), prompt K/V caches
   std::vector<float> tf(ncalls);
   for (int i = 0; i < ncalls; ++i) tf[i] = (float)ts[i];
   GILL_TRY(unet_time_table(m, tf.data(), ncalls, s));
@@ -875,30 +941,32 @@ extern "C" int gill_sd_denoise(gill_unet* m, const void* cond_bf16, const void* 
   GILL_TRY(unet_ctx_cache(m, m->ctx_full, Bx, s));
   GILL_CHECK_HIP(hipMemcpyAsync(m->lat, latents0, sizeof(float) * n_lat * B, hipMemcpyDeviceToDevice, s));
 
-  int counter = 0, n_ets = 0, last = -1;
+  // One loop step = stage kernel (latents -> UNet input, time-embedding row of the device-side step counter) + UNet forward
+  // (~390 launches at ~10+ us of host time each: at small batch the GPU outruns the host) + CFG/PLMS kernel (reads its
+  // coefficients from the device-side table, bumps the counter).  The step is captured ONCE per batch size into a hipGraph
+  // and replayed ncalls times back to back: nothing but graph launches sits between two steps.
+  SdLoopArgs la;
+  la.rows = m->plms_rows; la.ctr = m->step_ctr; la.temb_table = m->temb_table; la.temb_total = m->temb_total;
+  la.temb_cur = m->temb_cur; la.eps = m->eps; la.lat = m->lat; la.lat2 = m->lat2; la.cur_sample = m->cur_sample; la.ets = m->ets;
+  la.B = B; la.n = n_lat; la.guidance = guidance; la.cfg = cfg ? 1 : 0;
+  auto one_step = [&](hipStream_t st) -> int {
+    GILL_TRY(sd_stage_launch(la, st));
+    UNetRun r{m, st, Bx, m->temb_cur, 0, false};
+    r.cfg_pair = cfg;
+    GILL_TRY(r.forward(m->lat2, m->eps));
+    return plms_step_launch(la, st);
+  };
+  // the graph bakes in B, guidance and the CFG flag besides the buffer addresses
+  const GraphKey gkey{Bx, cfg ? 1 : 0, guidance};
   for (int i = 0; i < ncalls; ++i) {
-    // latent_model_input = cat([latents]*2); scale_model_input is the identity for PNDM
-    GILL_CHECK_HIP(hipMemcpyAsync(m->lat2, m->lat, sizeof(float) * n_lat * B, hipMemcpyDeviceToDevice, s));
-    if (cfg)
-      GILL_CHECK_HIP(hipMemcpyAsync(m->lat2 + n_lat * B, m->lat, sizeof(float) * n_lat * B, hipMemcpyDeviceToDevice, s));
-    // One UNet forward is ~520 kernel launches at ~10+ us of host time each: at small batch the GPU outruns the host.
-    // So the forward is captured ONCE per batch size into a hipGraph and replayed; the only per-step input, the
-    // time-embedding row, is staged into a fixed buffer in front of each replay.
-    GILL_CHECK_HIP(hipMemcpyAsync(m->temb_cur, m->temb_table + (size_t)i * m->temb_total, sizeof(float) * m->temb_total,
-                                  hipMemcpyDeviceToDevice, s));
-    const int gkey = Bx * 2 + (cfg ? 1 : 0);
     auto git = m->graphs.find(gkey);
     if (git == m->graphs.end() && m->use_graph && m->warmed.count(gkey)) {
       hipGraph_t graph = nullptr;
       hipGraphExec_t exec = nullptr;
-      // the caller's stream may be the legacy default stream, which cannot be captured: record on a private stream
-      // (capture only records the launches), replay on the caller's stream
-      if (!m->cap_stream) GILL_CHECK_HIP(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
-      GILL_CHECK_HIP(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
-      UNetRun rc{m, m->cap_stream, Bx, m->temb_cur, 0, false};
-      rc.cfg_pair = cfg;
-      const int rc_status = rc.forward(m->lat2, m->eps);
-      const hipError_t ec = hipStreamEndCapture(m->cap_stream, &graph);
+      // s is the handle's private stream (never the legacy NULL stream, which cannot be captured)
+      GILL_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+      const int rc_status = one_step(s);
+      const hipError_t ec = hipStreamEndCapture(s, &graph);
       if (rc_status != 0) { if (graph) (void)hipGraphDestroy(graph); return rc_status; }
       GILL_CHECK_HIP(ec);
       GILL_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
@@ -908,49 +976,11 @@ extern "C" int gill_sd_denoise(gill_unet* m, const void* cond_bf16, const void* 
     if (git != m->graphs.end()) {
       GILL_CHECK_HIP(hipGraphLaunch(git->second, s));
     } else {
-      // first forward of this batch size runs eagerly: it also performs every one-time kernel attribute set-up,
+      // first step of this batch size runs eagerly: it also performs every one-time kernel attribute set-up,
       // which must not happen inside a stream capture
-      UNetRun r{m, s, Bx, m->temb_cur, 0, false};
-      r.cfg_pair = cfg;
-      GILL_TRY(r.forward(m->lat2, m->eps));
+      GILL_TRY(one_step(s));
       m->warmed.insert(gkey);
     }
-
-    int t = ts[i];
-    int prev_t = t - ratio;
-    PlmsStepArgs a;
-    a.eps = m->eps; a.lat = m->lat; a.cur_sample = m->cur_sample; a.ets = m->ets;
-    a.B = B; a.n = n_lat; a.guidance = guidance; a.cfg = cfg ? 1 : 0;
-    a.slot_new = -1; a.s1 = a.s2 = a.s3 = 0;
-    if (counter != 1) {
-      a.slot_new = (last + 1) & 3;
-      a.s1 = last & 3; a.s2 = (last + 3) & 3; a.s3 = (last + 2) & 3;
-      last = a.slot_new;
-      if (n_ets < 4) ++n_ets;
-    } else {
-      prev_t = t; t = t + ratio;
-      a.s1 = last & 3;
-    }
-    if (n_ets == 1 && counter == 0) a.mode = 0;
-    else if (n_ets == 1 && counter == 1) a.mode = 1;
-    else if (n_ets == 2) a.mode = 2;
-    else if (n_ets == 3) a.mode = 3;
-    else a.mode = 4;
-    // _get_prev_sample
-    const double at = ac[t];
-    const double ap = prev_t >= 0 ? (double)ac[prev_t] : (double)ac[0];   // set_alpha_to_one = False
-    const double bt = 1.0 - at, bp = 1.0 - ap;
-    const double sample_coeff = sqrt(ap / at);
-    const double denom = at * sqrt(bp) + sqrt(at * bt * ap);
-    double sc = sample_coeff, ec = (ap - at) / denom;
-    if (c.v_prediction) {   // the model output is v: eps' = sqrt(a_t) v + sqrt(1 - a_t) sample, folded into the two coefficients
-      sc -= ec * sqrt(bt);
-      ec *= sqrt(at);
-    }
-    a.sample_coeff = (float)sc;
-    a.eps_coeff = (float)ec;
-    GILL_TRY(plms_step_launch(a, s));
-    ++counter;
   }
   GILL_CHECK_HIP(hipMemcpyAsync(latents_out, m->lat, sizeof(float) * n_lat * B, hipMemcpyDeviceToDevice, s));
   return 0;

@@ -320,7 +320,7 @@ struct VRun {
     m->arena.off = 0;
     m->gn_next = 0;
     if (!dry) {
-      GILL_CHECK_HIP(hipMemsetAsync(m->gn_stats, 0, sizeof(float) * (size_t)m->gn_slots * m->gn_slot_floats, s));
+      GILL_TRY(zero_bytes_launch(m->gn_stats, sizeof(float) * (size_t)m->gn_slots * m->gn_slot_floats, s));   // (kernel, not a memset node: capturable)
       const int64_t total = (int64_t)B * c.latent_channels * L * L;
       int blocks = (int)((total + 255) / 256);
       hipLaunchKernelGGL(vae_latent_prep_kernel, dim3(blocks), dim3(256), 0, s, latents, m->pq_w, m->pq_b,

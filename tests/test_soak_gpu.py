@@ -1,0 +1,69 @@
+"""Repeatability of the full-size hot path on the MI355X (BASELINE configs[1]: opt-6.7b geometry + GILLMapper + SD-1.5 UNet,
+4 prompts, 50 PLMS steps = 51 UNet calls of the CFG batch 8, VAE decode), called back to back the way bench.py and the
+reference's serving loop call it: on torch's default (legacy NULL) stream, with no synchronisation between calls.
+
+Round 1 shipped a loop that returned wrong / non-finite latents after a dozen calls: its captured UNet forward held
+hipMemsetAsync / hipMemcpyAsync graph nodes, whose replay was unreliable once other work was queued on the NULL stream
+(profiles/r02_soak_bisect.md).  This test is the guard: every call's latents must be finite and equal to the first call's up to
+the fp32-atomics noise of the fused GroupNorm / LayerNorm sums."""
+import pytest
+import torch
+
+from gill_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+N_CALLS = 32
+REL_TOL = 2e-2          # measured run-to-run rel-L2 of the 50-step latents: 7.2e-3 .. 7.4e-3 (fp32 atomics in the statistics sums)
+
+
+@pytest.fixture(scope="module")
+def gill_full(cuda):
+  import bench
+  return bench.build_model(cuda, synth.OptConfig.opt_6_7b(), synth.UNetConfig.sd15(), 4)
+
+
+def test_generate_images_sd15_soak(cuda, gill_full):
+  g = gill_full
+  ids = synth.synthetic_prompt_ids(4, 24, seed=0)[:, :24]
+  lat0 = synth.initial_latents(4, 4, 64, seed=1337).to(cuda)
+  outs = []
+  for _ in range(N_CALLS):     # no sync inside: the host runs ahead of the GPU exactly as in bench.py's timed loop
+    outs.append(g.generate_images(ids, num_inference_steps=50, guidance_scale=7.5, latents=lat0, decode=True))
+  torch.cuda.synchronize()
+  ref_lat, ref_img = outs[0][0].float(), outs[0][1].float()
+  assert ref_lat.shape == (4, 4, 64, 64) and outs[0][1].shape == (4, 512, 512, 3) and outs[0][1].dtype == torch.uint8
+  assert ref_img.std().item() > 1.0          # a real image, not a constant
+  worst = 0.0
+  for i, (lat, img) in enumerate(outs):
+    lat = lat.float()
+    assert bool(torch.isfinite(lat).all()), f"call {i}: non-finite latents"
+    rel = ((lat - ref_lat).norm() / ref_lat.norm()).item()
+    worst = max(worst, rel)
+    assert rel <= REL_TOL, f"call {i}: latents differ from call 0 by rel-L2 {rel:.3e} (tolerance {REL_TOL})"
+    mad = (img.float() - ref_img).abs().mean().item()
+    assert mad < 3.0, f"call {i}: decoded image differs from call 0 by {mad:.2f} grey levels on average"
+  print(f"[soak] {N_CALLS} calls, worst rel-L2 vs call 0 = {worst:.3e}")
+
+
+def test_generate_images_sd15_soak_side_stream_and_interleaved_torch_work(cuda, gill_full):
+  """Same workload with (a) a non-default caller stream and (b) unrelated torch kernels queued on the caller's stream between
+  calls: the denoise loop is fenced to its private stream by events and must not care."""
+  g = gill_full
+  ids = synth.synthetic_prompt_ids(4, 24, seed=0)[:, :24]
+  lat0 = synth.initial_latents(4, 4, 64, seed=1337).to(cuda)
+  ref = g.generate_images(ids, num_inference_steps=50, guidance_scale=7.5, latents=lat0, decode=False).float()
+  torch.cuda.synchronize()
+  scratch = torch.zeros(16 << 20, device=cuda)
+  side = torch.cuda.Stream()
+  for caller in (None, side):
+    outs = []
+    with torch.cuda.stream(caller) if caller is not None else torch.cuda.stream(torch.cuda.current_stream()):
+      for _ in range(8):
+        outs.append(g.generate_images(ids, num_inference_steps=50, guidance_scale=7.5, latents=lat0, decode=False))
+        for _ in range(200):
+          scratch.add_(1.0)
+    torch.cuda.synchronize()
+    for i, lat in enumerate(outs):
+      rel = ((lat.float() - ref).norm() / ref.norm()).item()
+      assert rel <= REL_TOL, f"caller={'side' if caller is not None else 'null'} call {i}: rel-L2 {rel:.3e}"
