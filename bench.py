@@ -31,7 +31,8 @@ sys.path.insert(0, ROOT)
 
 UNET_TFLOP_PER_SAMPLE_FORWARD = 0.8032   # 401.6 GMAC, SD-1.5, 64x64 latents
 PEAK_BF16_TFLOPS = 2500.0                # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-REL_STEP_TOL = 2e-2                      # rel-L2 of a step's final latents vs the first timed step's (same inputs every step)
+REL_STEP_TOL = 1e-6                      # rel-L2 of a step's final latents vs the first timed step's: same inputs every step and
+                                         # fixed-order reductions everywhere, so the steps are bit-identical (0 expected)
 
 
 def gpu_state_dict(builder, cfg, dev, seed):
@@ -304,8 +305,7 @@ def main():
   if a.child_pmc:
     return
 
-  # every timed step must have produced the same finite result (same inputs each step; fp32 atomics in the fused
-  # GroupNorm / LayerNorm sums are the only run-to-run difference)
+  # every timed step must have produced the same finite result (same inputs each step; no atomics on the path)
   ref_lat, ref_img = kept[0][0].float(), kept[0][1].float()
   table, ok = [], True
   for i, (lat, img) in enumerate(kept):

@@ -74,7 +74,7 @@ SYMBOLS: Dict[str, Tuple[object, List[object]]] = {
   "gill_unet_create": (_i, [C.POINTER(_vp), C.POINTER(gill_unet_config), C.POINTER(gill_tensor), _i]),
   "gill_unet_destroy": (None, [_vp]),
   "gill_unet_forward": (_i, [_vp, _vp, C.POINTER(C.c_float), _vp, _i, _vp, _vp]),
-  "gill_sd_denoise": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
+  "gill_sd_denoise": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _f, _vp, _vp]),
   "gill_vae_create": (_i, [C.POINTER(_vp), C.POINTER(gill_vae_config), C.POINTER(gill_tensor), _i]),
   "gill_vae_destroy": (None, [_vp]),
   "gill_vae_decode": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),

@@ -131,9 +131,9 @@ extern "C" int gill_op_groupnorm(const void* x1, int C1, const void* x2, int C2,
                                  const float* gamma, const float* beta, float eps, int silu, void* y, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   DevBuf stats;
-  GILL_TRY(stats.alloc(sizeof(float) * 2 * (size_t)groups * B));
+  GILL_TRY(stats.alloc(sizeof(float) * groupnorm_stats_floats(B, HW, groups)));
   GILL_TRY(groupnorm_launch((const bf16_t*)x1, C1, (const bf16_t*)x2, C2, B, HW, groups, gamma, beta, eps, silu,
-                            (bf16_t*)y, (float*)stats.p, s, 0));
+                            (bf16_t*)y, (float*)stats.p, s));
   GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
 }

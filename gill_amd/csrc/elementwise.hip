@@ -44,6 +44,24 @@ int embed_tokens_launch(const int64_t* ids, const bf16_t* table, int vocab, cons
   return 0;
 }
 
+// out[row][:] = table[ids[row]][:]   (bf16 rows copied as they are: what nn.Embedding returns for a bf16 table)
+__global__ __launch_bounds__(256) void embed_rows_bf16_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ table,
+                                                              int vocab, int D, bf16_t* __restrict__ out) {
+  const int row = blockIdx.x;
+  int64_t id = ids[row];
+  if (id < 0) id = 0;
+  if (id >= vocab) id = vocab - 1;
+  const uint32_t* e = reinterpret_cast<const uint32_t*>(table + (size_t)id * D);
+  uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)row * D);
+  for (int c = threadIdx.x; c < D / 2; c += blockDim.x) o[c] = e[c];
+}
+int embed_rows_bf16_launch(const int64_t* ids, const bf16_t* table, int vocab, int n, int D, bf16_t* out, hipStream_t s) {
+  GILL_REQUIRE(D % 2 == 0, "embedding dim must be even");
+  hipLaunchKernelGGL(embed_rows_bf16_kernel, dim3(n), dim3(256), 0, s, ids, table, vocab, D, out);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const TS* __restrict__ src, const int32_t* __restrict__ idx, int D,
                                                           TD* __restrict__ dst) {

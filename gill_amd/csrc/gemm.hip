@@ -125,7 +125,14 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0
 //         s_barrier) — for grids of ~one workgroup per CU where co-residency cannot do the hiding.
 // folded LayerNorm: rstd and mean*rstd of A's row m from the producer's {sum, sum of squares}
 __device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& rr, float& rm) {
-  const float2 st = *reinterpret_cast<const float2*>(p.ln_stats + (size_t)m * 2);
+  // the producer's per-plane partial sums of this row, added in plane order (fixed order: bit-reproducible)
+  const int R = p.ln_rows ? p.ln_rows : p.M;
+  if (m >= R) m -= R;
+  float2 st = *reinterpret_cast<const float2*>(p.ln_stats + (size_t)m * 2);
+  for (int pl = 1; pl < p.ln_planes; ++pl) {
+    const float2 v = *reinterpret_cast<const float2*>(p.ln_stats + ((size_t)pl * R + m) * 2);
+    st.x += v.x; st.y += v.y;
+  }
   const float invk = 1.f / (float)p.K;
   const float mean = st.x * invk;
   const float var = fmaxf(st.y * invk - mean * mean, 0.f);
@@ -481,14 +488,11 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_kernel(const GemmDev d) {
       vrow[i] = p.rowvec ? (m / p.rows_per_batch) * p.rowvec_bstride : 0;
     }
     // fused GroupNorm statistics of the OUTPUT tensor (consumed by the next GroupNorm: saves its whole stats pass).
-    // The 64 rows of a wave belong to one sample (rows_per_batch % 64 == 0); per-(sample, group) sum / sum of squares
-    // go through LDS bins [2 row halves][64 groups][2] (the tile ring is dead by now) and one global atomic per bin.
-    float* red = reinterpret_cast<float*>(smem);
-    if (p.gn_stats) {
-      __syncthreads();
-      red[tid] = 0.f;
-      __syncthreads();
-    }
+    // The 64 rows of a wave belong to one slab of one sample (rows_per_batch % 64 == 0).  Fixed-order reduction: 4 rows in the
+    // lane, 16 row lanes by xor-shuffles, one LDS cell per (row half, column) written once (the tile ring is dead by now),
+    // then one thread per (row half, bin, moment) adds the bin's gn_cg columns and stores the partial: no atomics anywhere.
+    float* red = reinterpret_cast<float*>(smem);     // [2 moments][2 row halves][BN]
+    if (p.gn_stats) __syncthreads();                 // every wave is done reading the ring
     float rws[4] = {0.f, 0.f, 0.f, 0.f}, rwq[4] = {0.f, 0.f, 0.f, 0.f};   // row sums for a following (folded) LayerNorm
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -535,72 +539,75 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_kernel(const GemmDev d) {
         for (int e = 0; e < 4; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
       }
       if (p.gn_stats) {
-        // the 4 columns of this lane fall into one group, or straddle two when cg % 4 != 0
-        const int g0 = n / p.gn_cg, g3 = (n + 3) / p.gn_cg;
-        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const bool lo = (g0 == g3) || ((n + e) / p.gn_cg == g0);
-          s0 += lo ? gs[e] : 0.f; q0 += lo ? gq[e] : 0.f;
-          s1 += lo ? 0.f : gs[e]; q1 += lo ? 0.f : gq[e];
-        }
-        atomicAdd(&red[(wm * 64 + g0) * 2], s0);
-        atomicAdd(&red[(wm * 64 + g0) * 2 + 1], q0);
-        if (g3 != g0) {
-          atomicAdd(&red[(wm * 64 + g3) * 2], s1);
-          atomicAdd(&red[(wm * 64 + g3) * 2 + 1], q1);
+          float a = gs[e], q = gq[e];
+#pragma unroll
+          for (int off = 1; off < 16; off <<= 1) { a += __shfl_xor(a, off, 64); q += __shfl_xor(q, off, 64); }
+          if (frow == 0) {
+            const int c = wn * (BN / 2) + j * 16 + fkc * 4 + e;
+            red[wm * BN + c] = a;
+            red[2 * BN + wm * BN + c] = q;
+          }
         }
       }
     }
     if (p.row_stats) {
-      // a row's BN/2 columns of this wave sit in the 4 lanes {frow, frow+16, frow+32, frow+48}
+      // a row's BN/2 columns of this wave sit in the 4 lanes {frow, frow+16, frow+32, frow+48}; plane = (N tile, wave column)
+      float* plane = p.row_stats + (size_t)((n0 / BN) * 2 + wn) * p.M * 2;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         rws[i] += __shfl_xor(rws[i], 16, 64); rwq[i] += __shfl_xor(rwq[i], 16, 64);
         rws[i] += __shfl_xor(rws[i], 32, 64); rwq[i] += __shfl_xor(rwq[i], 32, 64);
-        if (fkc == 0 && mok[i]) {
-          atomicAdd(p.row_stats + (size_t)(mrow + i * 16) * 2, rws[i]);
-          atomicAdd(p.row_stats + (size_t)(mrow + i * 16) * 2 + 1, rwq[i]);
-        }
+        if (fkc == 0 && mok[i]) *reinterpret_cast<float2*>(plane + (size_t)(mrow + i * 16) * 2) = make_float2(rws[i], rwq[i]);
       }
     }
     if (p.gn_stats) {
       __syncthreads();
-      const int half = tid >> 7, g = (tid >> 1) & 63, which = tid & 1;
-      const int mfirst = m0 + half * 64;
-      const float val = red[tid];
-      if (mfirst < p.M && g < p.gn_groups && val != 0.f)
-        atomicAdd(&p.gn_stats[((size_t)(mfirst / p.rows_per_batch) * p.gn_groups + g) * 2 + which], val);
+      constexpr int HALVES = BM / 64;
+      const int bins_tile = BN / p.gn_cg;            // gemm_fused_gn_ok(): BN % gn_cg == 0
+      if (tid < 2 * HALVES * bins_tile) {
+        const int which = tid & 1, half = (tid >> 1) % HALVES, lb = (tid >> 1) / HALVES;
+        const int mfirst = m0 + half * 64;
+        const int bin = n0 / p.gn_cg + lb;
+        if (mfirst < p.M && bin < p.gn_groups) {
+          const float* src = red + which * 2 * BN + half * BN + lb * p.gn_cg;
+          float a = 0.f;
+          for (int c = 0; c < p.gn_cg; ++c) a += src[c];
+          const int b = mfirst / p.rows_per_batch;
+          const int slab = (mfirst - b * p.rows_per_batch) / GN_SLAB_ROWS;
+          const int nslab = p.rows_per_batch / GN_SLAB_ROWS;
+          p.gn_stats[(((size_t)b * nslab + slab) * p.gn_groups + bin) * 2 + which] = a;
+        }
+      }
     }
   }
   }   // N tiles of this workgroup
 }
 
 // split-K reduction + epilogue
-// Block = 16*R rows x 64 columns (thread: one float4 column, R rows), so the fused GroupNorm statistics reduce through
-// 64 LDS bins to one global atomic per (group, moment) per block, like the in-kernel epilogue.  R = 4 for large outputs,
-// R = 1 when the output is small (many splits of a short M): more workgroups to pull the partials out of HBM/L2.
-template <int R>
-__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs p) {
-  __shared__ float red[2 * 64];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int n = blockIdx.x * 64 + tx * 4;
-  const int mbase = blockIdx.y * (16 * R);
-  if (p.gn_stats) {
-    if (threadIdx.x < 128) red[threadIdx.x] = 0.f;
-    __syncthreads();
-  }
+// Block = 64 rows x W columns (W = 80 when the fused GroupNorm bins need it, else 64), 16 row lanes x W/4 column quads:
+// thread = one float4 column quad of rows ty, ty+16, ty+32, ty+48.  The partials of every split are summed in split order.
+// Fused statistics are fixed-order like the in-kernel epilogue's: per-row / per-column cells in LDS written once each, then
+// one thread per output sum adds them in index order (row sums -> plane blockIdx.x of row_stats, bins -> this slab's
+// GroupNorm partial).
+template <int W>
+__global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArgs p) {
+  constexpr int QW = W / 4;                     // column quads per row
+  __shared__ float2 rowp[64][QW];               // per (row, quad) {sum, sum of squares} of the bf16-rounded outputs
+  __shared__ float2 colp[16][W];                // per (row lane, column) {sum, sum of squares} over the lane's 4 rows
+  const int tx = threadIdx.x % QW, ty = threadIdx.x / QW;
+  const int n = blockIdx.x * W + tx * 4;
+  const int mbase = blockIdx.y * 64;
   float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
-  float rsum[R], rsq[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) { rsum[r] = 0.f; rsq[r] = 0.f; }
+  float rsum[4] = {0.f, 0.f, 0.f, 0.f}, rsq[4] = {0.f, 0.f, 0.f, 0.f};
   if (n < p.N) {
     // all partial loads of the thread's 4 rows are issued before any epilogue store (a store in between would fence the
     // next row's loads): 4 rows x 4 splits = 16 independent 16-B loads in flight per pass
-    float4 s[R];
-    const float* src[R];
+    float4 s[4];
+    const float* src[4];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < 4; ++r) {
       int m = mbase + ty + 16 * r;
       if (m > p.M - 1) m = p.M - 1;
       s[r] = make_float4(0, 0, 0, 0);
@@ -609,26 +616,26 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs 
     const size_t zstride = (size_t)p.M * p.N;
     int z = 0;
     for (; z + 4 <= p.splitk; z += 4) {
-      float4 v[R][4];
+      float4 v[4][4];
 #pragma unroll
-      for (int r = 0; r < R; ++r)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[r][u] = *reinterpret_cast<const float4*>(src[r] + (size_t)(z + u) * zstride);
 #pragma unroll
-      for (int r = 0; r < R; ++r)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int u = 0; u < 4; ++u) { s[r].x += v[r][u].x; s[r].y += v[r][u].y; s[r].z += v[r][u].z; s[r].w += v[r][u].w; }
     }
     for (; z < p.splitk; ++z) {
-      float4 v[R];
+      float4 v[4];
 #pragma unroll
-      for (int r = 0; r < R; ++r) v[r] = *reinterpret_cast<const float4*>(src[r] + (size_t)z * zstride);
+      for (int r = 0; r < 4; ++r) v[r] = *reinterpret_cast<const float4*>(src[r] + (size_t)z * zstride);
 #pragma unroll
-      for (int r = 0; r < R; ++r) { s[r].x += v[r].x; s[r].y += v[r].y; s[r].z += v[r].z; s[r].w += v[r].w; }
+      for (int r = 0; r < 4; ++r) { s[r].x += v[r].x; s[r].y += v[r].y; s[r].z += v[r].z; s[r].w += v[r].w; }
     }
     const float4 cs = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + n) : make_float4(0, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < 4; ++r) {
       const int m = mbase + ty + 16 * r;
       if (m >= p.M) continue;
       if (p.ln_stats) {
@@ -641,43 +648,64 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs 
       store4(p, m, n, s[r].x, s[r].y, s[r].z, s[r].w, fin);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { gs[e] += fin[e]; gq[e] += fin[e] * fin[e]; }
-      rsum[r] = 0.f; rsq[r] = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float q = bf2f(f2bf(fin[e])); rsum[r] += q; rsq[r] += q * q; }
     }
   }
   if (p.row_stats) {
-    // the 16 threads tx = 0..15 of a row hold its 64 columns of this block: reduce, one atomic pair per row per block
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float a = rsum[r], q = rsq[r];
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) { a += __shfl_xor(a, off, 64); q += __shfl_xor(q, off, 64); }
-      const int m = mbase + ty + 16 * r;
-      if (tx == 0 && m < p.M) { atomicAdd(p.row_stats + (size_t)m * 2, a); atomicAdd(p.row_stats + (size_t)m * 2 + 1, q); }
+    for (int r = 0; r < 4; ++r) rowp[ty + 16 * r][tx] = make_float2(rsum[r], rsq[r]);
+    __syncthreads();
+    if (threadIdx.x < 64 && mbase + (int)threadIdx.x < p.M) {
+      int nq = (p.N - blockIdx.x * W + 3) / 4;
+      if (nq > QW) nq = QW;
+      float a = 0.f, q = 0.f;
+      for (int t = 0; t < nq; ++t) { a += rowp[threadIdx.x][t].x; q += rowp[threadIdx.x][t].y; }
+      *reinterpret_cast<float2*>(p.row_stats + ((size_t)blockIdx.x * p.M + mbase + threadIdx.x) * 2) = make_float2(a, q);
     }
   }
   if (p.gn_stats) {
-    if (n < p.N) {
-      const int g0 = n / p.gn_cg, g3 = (n + 3) / p.gn_cg;
-      float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool lo = (g0 == g3) || ((n + e) / p.gn_cg == g0);
-        s0 += lo ? gs[e] : 0.f; q0 += lo ? gq[e] : 0.f;
-        s1 += lo ? 0.f : gs[e]; q1 += lo ? 0.f : gq[e];
-      }
-      atomicAdd(&red[g0 * 2], s0); atomicAdd(&red[g0 * 2 + 1], q0);
-      if (g3 != g0) { atomicAdd(&red[g3 * 2], s1); atomicAdd(&red[g3 * 2 + 1], q1); }
-    }
+    for (int e = 0; e < 4; ++e) colp[ty][tx * 4 + e] = make_float2(gs[e], gq[e]);
     __syncthreads();
-    if (threadIdx.x < 128) {
-      const int g = threadIdx.x >> 1, which = threadIdx.x & 1;
-      const float val = red[threadIdx.x];
-      if (g < p.gn_groups && val != 0.f && mbase < p.M)
-        atomicAdd(&p.gn_stats[((size_t)(mbase / p.rows_per_batch) * p.gn_groups + g) * 2 + which], val);
+    const int bins_blk = W / p.gn_cg;            // gemm_fused_gn_ok(): W % gn_cg == 0
+    if ((int)threadIdx.x < 2 * bins_blk && mbase < p.M) {
+      const int which = threadIdx.x & 1, lb = threadIdx.x >> 1;
+      const int bin = blockIdx.x * bins_blk + lb;
+      if (bin < p.gn_groups) {
+        float a = 0.f;
+        for (int r = 0; r < 16; ++r)
+          for (int c = 0; c < p.gn_cg; ++c) { const float2 v = colp[r][lb * p.gn_cg + c]; a += which ? v.y : v.x; }
+        const int b = mbase / p.rows_per_batch;
+        const int slab = (mbase - b * p.rows_per_batch) / GN_SLAB_ROWS;
+        const int nslab = p.rows_per_batch / GN_SLAB_ROWS;
+        p.gn_stats[(((size_t)b * nslab + slab) * p.gn_groups + bin) * 2 + which] = a;
+      }
     }
   }
+}
+
+// width of the split-K reducer's blocks: 80 when the fused GroupNorm bins do not divide 64 (UNet: 5 / 10 / 20 / 40 channels)
+static inline int reduce_width(const GemmArgs& a) { return (a.gn_stats && 64 % a.gn_cg != 0) ? 80 : 64; }
+static inline int tile_width(const GemmArgs& a) {
+  if (a.act == ACT_GEGLU) return 128;
+  static const int forced_bn = [] { const char* v = getenv("GILL_GEMM_BN"); return v ? atoi(v) : 0; }();
+  int bn = a.bn;
+  if (forced_bn == 128 || forced_bn == 160) bn = forced_bn;
+  // measured on MI355X (profiles/r01_sweep_gemm_tiles.md): the 128x160 tile (5 N sub-tiles per wave: more MFMAs per LDS
+  // byte) beats 128x128 by 15-40 % on every UNet width, all of which are multiples of 160
+  if (bn != 128 && bn != 160) bn = (a.N % 160 == 0) ? 160 : 128;
+  return bn;
+}
+int gemm_row_planes(const GemmArgs& a) {
+  if (a.splitk > 1) return cdiv(a.N, reduce_width(a));
+  return 2 * cdiv(a.N, tile_width(a));
+}
+bool gemm_fused_gn_ok(int N, int cg) {
+  if (cg < 1 || N % cg != 0 || N / cg > 64) return false;
+  const int bn = (N % 160 == 0) ? 160 : 128;
+  // in-kernel epilogue: bins must not straddle N tiles; split-K reducer: nor its 64- or 80-column blocks
+  return bn % cg == 0 && (64 % cg == 0 || (80 % cg == 0 && N % 80 == 0));
 }
 
 int gemm_pick_splitk(int M, int N, int K, int act) {
@@ -777,10 +805,10 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     else GILL_TRY((gemm_launch_stages<BN, 0, 0>(d, grid, stages, s)));
   }
   if (sk > 1) {
-    if ((int64_t)cdiv(a.N, 64) * cdiv(a.M, 64) >= 1024)
-      hipLaunchKernelGGL(gemm_splitk_reduce_kernel<4>, dim3(cdiv(a.N, 64), cdiv(a.M, 64)), dim3(256), 0, s, d.a);
+    if (reduce_width(a) == 80)
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel<80>, dim3(cdiv(a.N, 80), cdiv(a.M, 64)), dim3(320), 0, s, d.a);
     else
-      hipLaunchKernelGGL(gemm_splitk_reduce_kernel<1>, dim3(cdiv(a.N, 64), cdiv(a.M, 16)), dim3(256), 0, s, d.a);
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel<64>, dim3(cdiv(a.N, 64), cdiv(a.M, 64)), dim3(256), 0, s, d.a);
     GILL_CHECK_HIP(hipGetLastError());
   }
   return 0;
@@ -811,13 +839,15 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   }
   if (a.gn_stats) {
     GILL_REQUIRE(a.out_mode != OUT_QKV && a.act != ACT_GEGLU, "fused GroupNorm statistics need the row-major epilogue");
-    GILL_REQUIRE(a.gn_cg >= 2, "fused GroupNorm statistics: bins of at least 2 channels");
-    GILL_REQUIRE(a.rows_per_batch % 64 == 0 && a.gn_groups > 0 && a.gn_groups <= 64 && a.gn_cg * a.gn_groups == a.N,
-                 "fused GroupNorm statistics: rows per sample must be a multiple of 64 and groups must tile N");
+    GILL_REQUIRE(a.rows_per_batch % GN_SLAB_ROWS == 0 && a.gn_groups > 0 && a.gn_groups <= 64 && a.gn_cg * a.gn_groups == a.N,
+                 "fused GroupNorm statistics: rows per sample must be a multiple of 64 and bins must tile N");
+    GILL_REQUIRE(gemm_fused_gn_ok(a.N, a.gn_cg) && tile_width(a) % a.gn_cg == 0,
+                 "fused GroupNorm statistics: bins must not straddle output tiles");
   }
   if (a.row_stats)
     GILL_REQUIRE(a.out_mode == OUT_BF16 && a.act != ACT_GEGLU, "row statistics need the bf16 row-major epilogue");
   if (a.ln_stats) {
+    GILL_REQUIRE(a.ln_planes >= 1, "folded LayerNorm: ln_planes must be >= 1");
     GILL_REQUIRE(a.ln_colsum != nullptr && !a.conv && a.K1 == a.K, "folded LayerNorm: column sums missing / single-source plain GEMM only");
     GILL_REQUIRE(a.act == ACT_GEGLU || a.out_mode == OUT_QKV, "folded LayerNorm is implemented in the GEGLU and QKV epilogues");
     GILL_REQUIRE(a.alpha == 1.f, "folded LayerNorm: alpha must be 1");
@@ -831,12 +861,7 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
     return gemm_launch_bn<128>(a, s);
   }
   if (a.out_mode == OUT_QKV) GILL_REQUIRE(a.dp % 4 == 0 && a.heads > 0 && a.ntok > 0, "bad QKV scatter geometry");
-  static const int forced_bn = env_int("GILL_GEMM_BN");
-  int bn = a.bn;
-  if (forced_bn == 128 || forced_bn == 160) bn = forced_bn;
-  // measured on MI355X (profiles/r01_sweep_gemm_tiles.md): the 128x160 tile (5 N sub-tiles per wave: more MFMAs per LDS
-  // byte) beats 128x128 by 15-40 % on every UNet width, all of which are multiples of 160
-  if (bn != 128 && bn != 160) bn = (a.N % 160 == 0) ? 160 : 128;
+  const int bn = tile_width(a);
   if (bn == 160) return gemm_launch_bn<160>(a, s);
   return gemm_launch_bn<128>(a, s);
 }

@@ -108,18 +108,19 @@ extern "C" int gill_mapper_create(gill_mapper** out, const gill_mapper_config* c
   const size_t Ti = cfg->num_input_tokens, To = cfg->num_output_tokens;
   const size_t To_pad = round_up((int)To, 32), Ti_pad = round_up((int)Ti, 32);
   const size_t tok_pad = To_pad > Ti_pad ? To_pad : Ti_pad;
+  const size_t Tm = To > Ti ? To : Ti;   // nbuf / ff / o serve the encoder (B*Ti rows) and the decoder (B*To rows)
   const int H = cfg->num_heads;
   if ((rc = m->pool.alloc(&m->x0, B * Ti * cfg->in_dim))) return fail(rc);
   if ((rc = m->pool.alloc(&m->h_enc, B * Ti * Hd))) return fail(rc);
   if ((rc = m->pool.alloc(&m->h_dec, B * To * Hd))) return fail(rc);
-  if ((rc = m->pool.alloc(&m->nbuf, B * To * Hd))) return fail(rc);
+  if ((rc = m->pool.alloc(&m->nbuf, B * Tm * Hd))) return fail(rc);
   if ((rc = m->pool.alloc(&m->mem, B * Ti * Hd))) return fail(rc);
-  if ((rc = m->pool.alloc(&m->ff, B * To * F))) return fail(rc);
+  if ((rc = m->pool.alloc(&m->ff, B * Tm * F))) return fail(rc);
   if ((rc = m->pool.alloc(&m->q, B * H * tok_pad * m->dp))) return fail(rc);
   if ((rc = m->pool.alloc(&m->k, B * H * tok_pad * m->dp))) return fail(rc);
   if ((rc = m->pool.alloc(&m->vt, B * H * m->dpv * tok_pad))) return fail(rc);
-  if ((rc = m->pool.alloc(&m->o, B * To * Hd))) return fail(rc);
-  m->splitk_ws_floats = (size_t)16 * B * To * (size_t)(F > 3 * Hd ? F : 3 * Hd);
+  if ((rc = m->pool.alloc(&m->o, B * Tm * Hd))) return fail(rc);
+  m->splitk_ws_floats = (size_t)16 * B * Tm * (size_t)(F > 3 * Hd ? F : 3 * Hd);
   if ((rc = m->pool.alloc(&m->splitk_ws, m->splitk_ws_floats, false))) return fail(rc);
   if (hipDeviceSynchronize() != hipSuccess) { gill_set_error("mapper create: device sync failed"); return fail(-1); }
   *out = m;

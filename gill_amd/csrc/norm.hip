@@ -170,8 +170,6 @@ int layernorm_f32out_launch(const void* x, int x_f32, const float* gamma, const 
 // per-group partial (sum, sumsq) are reduced through LDS and added atomically into stats.
 // The mean is shifted by the first pixel's value of the group to tame E[x^2]-E[x]^2
 // cancellation: stats hold sums of (x - ref[b][g]) with ref = bf16 value at pixel 0.
-#define GN_ROWS 32
-#define GN_APPLY_ROWS 32
 
 typedef __attribute__((ext_vector_type(4))) unsigned int gn_u32x4;
 
@@ -179,61 +177,65 @@ __device__ __forceinline__ float gn_ref_value(const bf16_t* x1, int C1, const bf
   return (ch < C1) ? bf2f(x1[(size_t)b * HW * C1 + ch]) : bf2f(x2[(size_t)b * HW * C2 + (ch - C1)]);
 }
 
-// Pass 1 (stats).  Block = (b, slab of GN_ROWS pixels).  A thread owns one 8-channel octet (16-B loads, a wave
-// covers 1 KiB of a row) and walks the slab's pixels with a stride of (256 / octets-per-row) row lanes; its four
-// channel pairs are reduced into per-group LDS bins, then one global atomic per (group, moment) per block.
-// `stats` must be zero on entry.
+// Pass 1 (stats).  Block = (b, slab of GN_STATS_ROWS pixels).  A thread owns one 8-channel octet (16-B loads, a wave
+// covers 1 KiB of a row) and walks the slab's pixels with a stride of (256 / octets-per-row) row lanes.  Fixed-order
+// reduction (bit-reproducible): every thread parks its four channel-pair sums in its own LDS cell, then thread g adds the
+// cells of group g — row lanes outer, channel pairs inner — and stores the slab's partial
+// stats[(b * nslab + slab) * groups + g] = {sum, sum of squares}.  Nothing to zero, no atomics.
 __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __restrict__ x1, int C1,
                                                               const bf16_t* __restrict__ x2, int C2, int HW,
                                                               int groups, float* __restrict__ stats) {
-  __shared__ float red[2 * 64];  // up to 64 groups
+  __shared__ float2 cell[256][4];   // [thread][channel pair] of the current 2048-channel chunk
   const int C = C1 + C2;
   const int cg = C / groups;
   const int nvec = C / 8;
   const int b = blockIdx.y;
-  const int p0 = blockIdx.x * GN_ROWS;
-  int p1 = p0 + GN_ROWS;
+  const int p0 = blockIdx.x * GN_STATS_ROWS;
+  int p1 = p0 + GN_STATS_ROWS;
   if (p1 > HW) p1 = HW;
-  for (int i = threadIdx.x; i < 2 * groups; i += blockDim.x) red[i] = 0.f;
-  __syncthreads();
+  float gsum = 0.f, gsq = 0.f;        // thread g < groups: running sums of group g over the channel chunks
   for (int obase = 0; obase < nvec; obase += 256) {
     const int ow = (nvec - obase) < 256 ? (nvec - obase) : 256;
     const int lanes = 256 / ow;
     const int rl = threadIdx.x / ow;
-    if (rl >= lanes) continue;
-    const int o = obase + threadIdx.x - rl * ow;
-    const int c = o * 8;
-    const bf16_t* src; int cs, cc;
-    if (c < C1) { src = x1; cs = C1; cc = c; } else { src = x2; cs = C2; cc = c - C1; }
-    const bf16_t* base = src + (size_t)b * HW * cs + cc;
-    int g[4]; float sm[4], sq[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      g[j] = (c + 2 * j) / cg;
-      sm[j] = 0.f; sq[j] = 0.f;
-    }
-    // plain sums (no shift): no dependent gather in front of the streaming loads; fp32 E[x^2]-E[x]^2 is accurate to
-    // ~1e-7 * (1 + mean^2/var), ample for bf16 activations
+    float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rl < lanes) {
+      const int o = obase + threadIdx.x - rl * ow;
+      const int c = o * 8;
+      const bf16_t* src; int cs, cc;
+      if (c < C1) { src = x1; cs = C1; cc = c; } else { src = x2; cs = C2; cc = c - C1; }
+      const bf16_t* base = src + (size_t)b * HW * cs + cc;
+      // plain sums (no shift): fp32 E[x^2]-E[x]^2 is accurate to ~1e-7 * (1 + mean^2/var), ample for bf16 activations
 #pragma unroll 8
-    for (int p = p0 + rl; p < p1; p += lanes) {
-      const gn_u32x4 u = *reinterpret_cast<const gn_u32x4*>(base + (size_t)p * cs);
+      for (int p = p0 + rl; p < p1; p += lanes) {
+        const gn_u32x4 u = *reinterpret_cast<const gn_u32x4*>(base + (size_t)p * cs);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float a = bf2f((bf16_t)(u[j] & 0xffff));
-        const float bq = bf2f((bf16_t)(u[j] >> 16));
-        sm[j] += a + bq;
-        sq[j] += a * a + bq * bq;
+        for (int j = 0; j < 4; ++j) {
+          const float a = bf2f((bf16_t)(u[j] & 0xffff));
+          const float bq = bf2f((bf16_t)(u[j] >> 16));
+          sm[j] += a + bq;
+          sq[j] += a * a + bq * bq;
+        }
       }
     }
-    // merge pairs that share a group before touching LDS
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j < 3 && g[j] == g[j + 1]) { sm[j + 1] += sm[j]; sq[j + 1] += sq[j]; }
-      else { atomicAdd(&red[2 * g[j]], sm[j]); atomicAdd(&red[2 * g[j] + 1], sq[j]); }
+    for (int j = 0; j < 4; ++j) cell[threadIdx.x][j] = make_float2(sm[j], sq[j]);
+    __syncthreads();
+    if ((int)threadIdx.x < groups) {
+      // channel pairs of group g inside this chunk: pair index q = channel / 2, chunk covers pairs [obase*4, (obase+ow)*4)
+      int q0 = threadIdx.x * (cg / 2), q1 = q0 + cg / 2;
+      if (q0 < obase * 4) q0 = obase * 4;
+      if (q1 > (obase + ow) * 4) q1 = (obase + ow) * 4;
+      for (int r = 0; r < lanes; ++r)
+        for (int q = q0; q < q1; ++q) {
+          const float2 v = cell[r * ow + (q >> 2) - obase][q & 3];
+          gsum += v.x; gsq += v.y;
+        }
     }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 2 * groups; i += blockDim.x) atomicAdd(&stats[(size_t)b * groups * 2 + i], red[i]);
+  if ((int)threadIdx.x < groups)
+    *reinterpret_cast<float2*>(stats + (((size_t)b * gridDim.x + blockIdx.x) * groups + threadIdx.x) * 2) = make_float2(gsum, gsq);
 }
 
 // Pass 2: normalize + affine (+ SiLU), 8 channels (16 B) per thread.  cg % 2 == 0 is enough:
@@ -242,8 +244,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ x2, int C2, int HW, int groups,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, int silu,
-                                                              const float* __restrict__ stats1, int nb1, int r1,
-                                                              const float* __restrict__ stats2, int nb2, int r2, int o2,
+                                                              const float* __restrict__ stats1, int nb1, int r1, int ns1,
+                                                              const float* __restrict__ stats2, int nb2, int r2, int o2, int ns2,
                                                               bf16_t* __restrict__ y, int rows, int cc) {
   // block = (slab of `rows` pixels, sample b, chunk of cc <= 256 channels).  Phase 1: fold statistics and affine into
   // per-channel (scale, shift) in LDS — one channel per thread, so the dependent loads of the prologue are paid once,
@@ -257,30 +259,49 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
   const float inv_n = 1.f / ((float)cg * (float)HW);
   float* scale = gn_ss - c0;          // indexed by absolute channel
   float* shift = gn_ss + 256 - c0;
-  // The sums arrive in BINS of bin1 (bin2) channels: stats1 covers channels [0, sc1) of the (concatenated) input, stats2
-  // the rest.  Producers accumulate bins finer than a group so that the same sums serve this tensor's own GroupNorm and
-  // the wider groups of a later skip concatenation; a group's sum is the sum of the bins it covers.
+  // The sums arrive in BINS of bin1 (bin2) channels, as ns1 (ns2) per-slab PARTIALS per (sample, bin) that their producer
+  // wrote once each: stats[(b * ns + slab) * nb + bin] = {sum, sum of squares}.  stats1 covers channels [0, sc1) of the
+  // (concatenated) input, stats2 the rest.  Producers use bins finer than a group so that the same sums serve this tensor's
+  // own GroupNorm and the wider groups of a later skip concatenation.
+  // Phase 0: the block's bins are totalled over the slabs in slab order (fixed order: bit-reproducible), one (bin, moment)
+  // per thread with four interleaved accumulators combined in a fixed tree; totals land in LDS.
+  __shared__ float gn_tot[2][128][2];   // [statistics block][bin][moment]
+  {
+    const int t = threadIdx.x;
+    const int blk = t >> 7, bin = (t >> 1) & 63, which = t & 1;
+    const float* st = blk ? stats2 : stats1;
+    const int nb = blk ? nb2 : nb1, ns = blk ? ns2 : ns1;
+    for (int bb = bin; bb < nb; bb += 64) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      if (st) {
+        const float* src = st + ((size_t)b * ns * nb + bb) * 2 + which;
+        const size_t step = (size_t)nb * 2;
+        int sl = 0;
+        for (; sl + 4 <= ns; sl += 4) {
+          a0 += src[(size_t)sl * step]; a1 += src[(size_t)(sl + 1) * step];
+          a2 += src[(size_t)(sl + 2) * step]; a3 += src[(size_t)(sl + 3) * step];
+        }
+        for (; sl < ns; ++sl) a0 += src[(size_t)sl * step];
+      }
+      gn_tot[blk][bb][which] = (a0 + a1) + (a2 + a3);
+    }
+  }
+  __syncthreads();
   for (int ch = c0 + threadIdx.x; ch < c0 + cc; ch += blockDim.x) {
     const int g = ch / cg;
     // bin index space (no divisions): group g covers bins [g*r1, (g+1)*r1) of block 1 (clipped to its nb1 bins) and bins
     // [g*r2 - o2, (g+1)*r2 - o2) of block 2 (clipped at 0); r = bins per group, o2 = block-1 channels in units of bin2
-    float a = 0.f, q = 0.f;       // every channel thread adds up its group's few bins itself (L2-hot, no extra barrier)
+    float a = 0.f, q = 0.f;
     {
       int e = (g + 1) * r1;
       if (e > nb1) e = nb1;
-      for (int bin = g * r1; bin < e; ++bin) {
-        const float2 v = *reinterpret_cast<const float2*>(stats1 + ((size_t)b * nb1 + bin) * 2);
-        a += v.x; q += v.y;
-      }
+      for (int bin = g * r1; bin < e; ++bin) { a += gn_tot[0][bin][0]; q += gn_tot[0][bin][1]; }
     }
     if (stats2) {
       int s0 = g * r2 - o2;
       const int e = s0 + r2;
       if (s0 < 0) s0 = 0;
-      for (int bin = s0; bin < e; ++bin) {
-        const float2 v = *reinterpret_cast<const float2*>(stats2 + ((size_t)b * nb2 + bin) * 2);
-        a += v.x; q += v.y;
-      }
+      for (int bin = s0; bin < e; ++bin) { a += gn_tot[1][bin][0]; q += gn_tot[1][bin][1]; }
     }
     const float sm = a * inv_n;         // E[x]
     const float sq = q * inv_n;         // E[x^2]
@@ -320,21 +341,18 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
 }
 
 int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups, const float* gamma,
-                     const float* beta, float eps, int silu, bf16_t* y, float* stats, hipStream_t s, int stats_prezeroed) {
+                     const float* beta, float eps, int silu, bf16_t* y, float* stats, hipStream_t s) {
   const int C = C1 + C2;
   GILL_REQUIRE(groups <= 64 && C % groups == 0 && (C / groups) % 2 == 0, "groupnorm: channels/group must be even");
   GILL_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "groupnorm: channel counts must be multiples of 8");
   GILL_REQUIRE(C2 == 0 || x2 != nullptr, "groupnorm: second source missing");
-  // stats_prezeroed: 0 = zero `stats` here, 1 = caller zeroed it, 2 = `stats` already holds {sum, sum of squares}
-  // (accumulated by the producing GEMM's epilogue): skip the statistics pass entirely
-  if (stats_prezeroed != 2) {
-    if (!stats_prezeroed) GILL_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(float) * 2 * groups * B, s));
-    dim3 g1(cdiv(HW, GN_ROWS), B);
-    hipLaunchKernelGGL(groupnorm_stats_kernel, g1, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, stats);
-    GILL_CHECK_HIP(hipGetLastError());
-  }
-  // `stats` holds one {sum, sum of squares} per group of the whole (concatenated) input
-  return groupnorm_apply_launch(x1, C1, x2, C2, B, HW, groups, gamma, beta, eps, silu, y, stats, C / groups, C, nullptr, 0, s);
+  GILL_REQUIRE(stats != nullptr, "groupnorm: statistics scratch missing");
+  const int nslab = cdiv(HW, GN_STATS_ROWS);
+  dim3 g1(nslab, B);
+  hipLaunchKernelGGL(groupnorm_stats_kernel, g1, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, stats);
+  GILL_CHECK_HIP(hipGetLastError());
+  // `stats` holds nslab partial {sum, sum of squares} per group of the whole (concatenated) input
+  return groupnorm_apply_launch(x1, C1, x2, C2, B, HW, groups, gamma, beta, eps, silu, y, stats, C / groups, C, nslab, nullptr, 0, 0, s);
 }
 
 static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
@@ -342,8 +360,8 @@ static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t
 // Normalise from sums accumulated elsewhere (GEMM / conv epilogues): stats1 = [B][sc1 / bin1][2] over the first sc1 channels,
 // stats2 = [B][(C - sc1) / bin2][2] over the rest (nullptr when stats1 covers everything).
 int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups, const float* gamma,
-                           const float* beta, float eps, int silu, bf16_t* y, const float* stats1, int bin1, int sc1,
-                           const float* stats2, int bin2, hipStream_t s) {
+                           const float* beta, float eps, int silu, bf16_t* y, const float* stats1, int bin1, int sc1, int nslab1,
+                           const float* stats2, int bin2, int nslab2, hipStream_t s) {
   const int C = C1 + C2;
   GILL_REQUIRE(groups <= 64 && C % groups == 0 && (C / groups) % 2 == 0, "groupnorm: channels/group must be even");
   GILL_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "groupnorm: channel counts must be multiples of 8");
@@ -352,17 +370,21 @@ int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, i
   GILL_REQUIRE(groupnorm_bins_align(C / groups, sc1, bin1, (stats2 || sc1 < C) ? bin2 : 0),
                "groupnorm: group boundaries must fall on statistics bin boundaries");
   GILL_REQUIRE(sc1 == C || (stats2 != nullptr && bin2 > 0 && (C - sc1) % bin2 == 0), "groupnorm: second statistics block missing");
+  GILL_REQUIRE(nslab1 >= 1 && (stats2 == nullptr || nslab2 >= 1), "groupnorm: partial counts missing");
+  GILL_REQUIRE(sc1 / bin1 <= 128 && (stats2 == nullptr || (C - sc1) / bin2 <= 128), "groupnorm: more than 128 statistics bins per block");
   const int cg = C / groups;   // bins_align() guarantees cg, sc1 (and the block-2 offsets) are whole numbers of bins
   // channel chunks of <= 256 (whole 8-channel vectors); slabs of 32 rows, fewer while the grid is short of ~4 blocks per CU
   int nch = cdiv(C, 256);
   while (C % (8 * nch) != 0) ++nch;
   const int cc = C / nch;
-  int rows = GN_APPLY_ROWS;
+  // slabs of 64 rows (every block first totals its sample's partial sums: fat blocks amortise that prologue), fewer while the
+  // grid is short of ~4 blocks per CU
+  int rows = 64;
   while (rows > 4 && (int64_t)cdiv(HW, rows) * B * nch < 1024) rows >>= 1;
   dim3 g2(cdiv(HW, rows), B, nch);
   hipLaunchKernelGGL(groupnorm_apply_kernel, g2, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, gamma, beta,
-                     eps, silu, stats1, sc1 / bin1, cg / bin1, stats2, stats2 ? (C - sc1) / bin2 : 0, stats2 ? cg / bin2 : 0,
-                     stats2 ? sc1 / bin2 : 0, y, rows, cc);
+                     eps, silu, stats1, sc1 / bin1, cg / bin1, nslab1, stats2, stats2 ? (C - sc1) / bin2 : 0, stats2 ? cg / bin2 : 0,
+                     stats2 ? sc1 / bin2 : 0, stats2 ? nslab2 : 0, y, rows, cc);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -37,20 +37,32 @@ struct GemmArgs {
   int kv_tok_offset = 0;  // K / Vt rows land at token t + kv_tok_offset (appending to a KV cache); Q rows stay at t
   // split-K (0/1 = off).  ws must hold splitk*M*N floats.
   int splitk = 1; float* ws = nullptr;
-  // fused GroupNorm statistics of the output: gn_stats[(m / rows_per_batch)][gn_groups][2] += {sum, sum of squares}
-  // over each group of gn_cg output channels (row-major epilogue only; gn_stats zeroed by the caller)
+  // Both kinds of fused statistics are FIXED-ORDER: a producer writes each partial sum exactly once (no atomics, nothing to
+  // zero), the consumer adds the partials in index order, so two runs of the same launch sequence are bit-identical.
+  // fused GroupNorm statistics of the output: gn_stats[(b * nslab + slab) * gn_groups + g][2] = {sum, sum of squares} of the
+  // gn_cg channels of bin g over the 64 output rows of slab `slab` of sample b = m / rows_per_batch (nslab = rows_per_batch
+  // / GN_SLAB_ROWS; row-major epilogue only; the tile width must be a multiple of gn_cg: gemm_fused_gn_ok())
   float* gn_stats = nullptr; int gn_groups = 0; int gn_cg = 0;
   // LayerNorm folded into the NEXT GEMM: LN(x) W^T + b = rstd (x (g*W)^T - mean * colsum(g*W)) + (beta W^T + b).
-  //  producer: row_stats[m][2] += {sum, sum of squares} of each bf16-rounded output row (row-major bf16 epilogue; zeroed
-  //            by the caller);
-  //  consumer: ln_stats = the producer's row_stats of A, ln_colsum[n] = sum_k W'[n,k] (W' = g*W is what `W` holds, and
-  //            `bias` holds beta W^T + b); mean/rstd over K with eps ln_eps.  GEGLU and QKV epilogues (+ split-K reducer).
+  //  producer: row_stats[(plane * M + m)][2] = {sum, sum of squares} of the bf16-rounded outputs of row m in the columns of
+  //            plane `plane` (row-major bf16 epilogue); gemm_row_planes() tells how many planes this launch writes;
+  //  consumer: ln_stats = the producer's row_stats of A over ln_planes planes, ln_colsum[n] = sum_k W'[n,k] (W' = g*W is what
+  //            `W` holds, and `bias` holds beta W^T + b); mean/rstd over K with eps ln_eps.  GEGLU and QKV epilogues
+  //            (+ split-K reducer).
   float* row_stats = nullptr;
-  const float* ln_stats = nullptr; const float* ln_colsum = nullptr; float ln_eps = 1e-5f;
+  //            ln_rows (0 = M): rows per plane; rows m >= ln_rows read the sums of row m - ln_rows (a batch whose second half
+  //            repeats the first: the shared classifier-free-guidance prefix).
+  const float* ln_stats = nullptr; int ln_planes = 1; int ln_rows = 0; const float* ln_colsum = nullptr; float ln_eps = 1e-5f;
   // tuning: LDS ring depth (2|3, 0 = default 2) and tile width (128|160, 0 = by divisibility)
   int stages = 0; int bn = 0;
 };
 int gemm_launch(const GemmArgs& a, hipStream_t s);
+#define GN_SLAB_ROWS 64        // rows per fused GroupNorm-statistics partial
+#define GEMM_MAX_ROW_PLANES(N) (((N) + 63) / 64 > 2 * (((N) + 127) / 128) ? ((N) + 63) / 64 : 2 * (((N) + 127) / 128))
+// planes of row_stats this launch writes (depends on the tile width and on split-K, both fixed by the arguments)
+int gemm_row_planes(const GemmArgs& a);
+// can a GEMM with N output columns produce fused GroupNorm statistics for bins of cg channels?
+bool gemm_fused_gn_ok(int N, int cg);
 // heuristic split-K factor for under-filled grids
 int gemm_pick_splitk(int M, int N, int K, int act);
 
@@ -74,18 +86,24 @@ int layernorm_f32out_launch(const void* x, int x_f32, const float* gamma, const 
                             int rows, int C, float eps, hipStream_t s);
 
 // GroupNorm (+ optional SiLU) over NHWC bf16, input = channel-concat of up to two tensors.
-//   stats: [B][groups][2] fp32 scratch (zeroed inside).
+//   stats: fp32 scratch of groupnorm_stats_floats(B, HW, groups) floats (per-slab partial sums, written here).
+#define GN_STATS_ROWS 32       // pixels per partial of the stand-alone statistics pass
+static inline size_t groupnorm_stats_floats(int B, int HW, int groups) {
+  return (size_t)B * ((HW + GN_STATS_ROWS - 1) / GN_STATS_ROWS) * groups * 2;
+}
 int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups,
                      const float* gamma, const float* beta, float eps, int silu, bf16_t* y,
-                     float* stats, hipStream_t s, int stats_prezeroed = 0);
-// normalise from sums accumulated in bins by producer epilogues (see norm.hip); groupnorm_bins_align() tells whether a
-// (channels per group, split point, bin sizes) combination is usable
+                     float* stats, hipStream_t s);
+// normalise from per-slab partial sums written in bins by producer epilogues (GemmArgs::gn_stats layout: nslab1 / nslab2
+// partials per (sample, bin)); groupnorm_bins_align() tells whether a (channels per group, split point, bin sizes)
+// combination is usable
 int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups, const float* gamma,
-                           const float* beta, float eps, int silu, bf16_t* y, const float* stats1, int bin1, int sc1,
-                           const float* stats2, int bin2, hipStream_t s);
+                           const float* beta, float eps, int silu, bf16_t* y, const float* stats1, int bin1, int sc1, int nslab1,
+                           const float* stats2, int bin2, int nslab2, hipStream_t s);
 bool groupnorm_bins_align(int cg, int sc1, int bin1, int bin2);
 
 // ---- small elementwise / gather kernels ----
+int embed_rows_bf16_launch(const int64_t* ids, const bf16_t* table, int vocab, int n, int D, bf16_t* out, hipStream_t s);
 int embed_tokens_launch(const int64_t* ids, const bf16_t* table, int vocab, const bf16_t* pos_table, int pos_offset,
                         int B, int T, int D, float* out_f32, hipStream_t s);
 int gather_rows_launch(const void* src, int src_f32, const int32_t* row_idx, int nrows, int D, void* dst, int dst_f32,

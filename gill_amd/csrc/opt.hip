@@ -133,13 +133,9 @@ extern "C" void gill_opt_destroy(gill_opt* h) { delete h; }
 extern "C" int gill_opt_embed(gill_opt* m, const int64_t* ids, int n, void* out_bf16, void* stream) {
   GILL_REQUIRE(m && ids && out_bf16 && n > 0, "bad argument");
   hipStream_t s = (hipStream_t)stream;
-  // embedding rows are bf16 already: gather = pure row copy.  ids are int64 on device -> widen-free gather kernel
-  // (embed_tokens_launch adds positions and emits fp32, which is not what models.py:180 returns).
-  DevBuf tmp;
-  GILL_TRY(tmp.alloc(sizeof(float) * (size_t)n * m->cfg.hidden_size));
-  GILL_TRY(embed_tokens_launch(ids, m->embed, m->cfg.vocab_size, nullptr, 0, 1, n, m->cfg.hidden_size, (float*)tmp.p, s));
-  GILL_TRY(cast_f32_to_bf16_launch((const float*)tmp.p, (bf16_t*)out_bf16, (int64_t)n * m->cfg.hidden_size, s));
-  GILL_CHECK_HIP(hipStreamSynchronize(s));
+  // embedding rows are bf16 already: the lookup is a pure row copy (no allocation, no sync: both pointers are the caller's
+  // device memory and the call is stream-ordered like every other entry point)
+  GILL_TRY(embed_rows_bf16_launch(ids, m->embed, m->cfg.vocab_size, n, m->cfg.hidden_size, (bf16_t*)out_bf16, s));
   return 0;
 }
 

@@ -57,9 +57,12 @@ struct XfW {  // Transformer2DModel with one BasicTransformerBlock
   LinW ff2;                   // [C][4C]
 };
 
-// stats: optional slot [Bx][groups][2] that the PRODUCING GEMM epilogue fills with this tensor's GroupNorm sums
+// stats: optional slot [Bx][H*W/64][C/sbin][2] that the PRODUCING GEMM epilogue fills with this tensor's per-slab GroupNorm
+// partial sums (GemmArgs::gn_stats: written once each, added in slab order by the consumer)
 // sbin: channels per statistics bin (C/64: finer than a group, so the sums also serve the wider groups of a skip concat)
 struct Tensor { bf16_t* p = nullptr; int H = 0, W = 0, C = 0; float* stats = nullptr; int sbin = 0; };
+// row sums feeding a folded LayerNorm: [planes][rows][2], planes fixed by the producing GEMM's tiling (gemm_row_planes)
+struct RowStats { float* p = nullptr; int planes = 1; };
 
 struct Arena {
   unsigned char* base = nullptr;
@@ -106,9 +109,9 @@ struct gill_unet {
   // workspace
   Arena arena;
   unsigned char* arena_mem = nullptr;
-  float* gn_stats = nullptr;      // pool of pre-zeroed [Bx][groups][2] slots, one per GroupNorm call of a forward
-  int gn_slots = 0, gn_slot_floats = 0, gn_next = 0;
-  float* ln_stats = nullptr;      // pre-zeroed per-forward pool of [rows][2] row sums feeding the folded LayerNorms
+  float* gn_stats = nullptr;      // per-forward pool of GroupNorm partial-sum slots (bump-allocated; the dry run sizes it)
+  size_t gn_floats = 0, gn_next = 0;
+  float* ln_stats = nullptr;      // per-forward pool of the row-sum planes feeding the folded LayerNorms
   size_t ln_floats = 0, ln_next = 0;
   float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
   std::vector<bf16_t*> kcache, vcache;   // per transformer layer: [Bx][H][ctx_pad][dp] / [Bx][H][dpv][ctx_pad]
@@ -440,24 +443,26 @@ struct UNetRun {
   // so everything before the first cross-attention runs once on the first half (gill_sd_denoise sets this)
   bool cfg_pair = false;
 
-  float* stats_slot() {   // next pre-zeroed slot of the per-forward pool (the dry run counts them)
-    float* p = dry ? nullptr : m->gn_stats + (size_t)m->gn_next * m->gn_slot_floats;
-    ++m->gn_next;
+  float* stats_slot(size_t floats) {   // next slot of the per-forward GroupNorm partial-sum pool (the dry run sizes it)
+    float* p = dry ? (float*)(uintptr_t)16 : m->gn_stats + m->gn_next;
+    m->gn_next += (floats + 3) & ~(size_t)3;
     return p;
   }
-  float* ln_slot(int rows) {   // [rows][2] floats of the per-forward LayerNorm row-sum pool (the dry run sizes it)
-    float* p = dry ? (float*)(uintptr_t)16 : m->ln_stats + m->ln_next;
-    m->ln_next += (size_t)rows * 2;
-    return p;
+  RowStats ln_slot(int rows, int C) {   // row-sum planes of a [rows][C] residual stream (sized for any tiling of C columns)
+    RowStats r;
+    r.p = dry ? (float*)(uintptr_t)16 : m->ln_stats + m->ln_next;
+    m->ln_next += (size_t)rows * 2 * GEMM_MAX_ROW_PLANES(C);
+    return r;
   }
   Tensor talloc(int H, int W, int C, bool want_stats = false) {
     Tensor t; t.H = H; t.W = W; t.C = C;
     t.p = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * H * W * C);
-    if (want_stats && (H * W) % 64 == 0 && C % m->cfg.norm_num_groups == 0) {
-      // (the epilogue's 4 consecutive columns may straddle two bins, not more: bins of at least 2 channels)
-      t.sbin = (C % 64 == 0 && C / 64 >= 2) ? C / 64 : C / m->cfg.norm_num_groups;
-      t.stats = stats_slot();
-      if (dry) t.stats = (float*)(uintptr_t)16;   // non-null marker so the dry run takes the same branches
+    if (want_stats && (H * W) % GN_SLAB_ROWS == 0 && C % m->cfg.norm_num_groups == 0) {
+      const int sbin = (C % 64 == 0 && C / 64 >= 2) ? C / 64 : C / m->cfg.norm_num_groups;
+      if (gemm_fused_gn_ok(C, sbin)) {
+        t.sbin = sbin;
+        t.stats = stats_slot((size_t)Bx * (H * W / GN_SLAB_ROWS) * (C / sbin) * 2);
+      }
     }
     return t;
   }
@@ -472,9 +477,10 @@ struct UNetRun {
     g.ws = m->splitk_ws;
     return 0;
   }
-  int gemm(GemmArgs& g) {
+  int gemm(GemmArgs& g, RowStats* rs = nullptr) {
     if (dry) return 0;
     pick_sk(g);
+    if (rs) { g.row_stats = rs->p; rs->planes = gemm_row_planes(g); }
     return gemm_launch(g, s);
   }
   int gnorm(const Tensor& x1, const Tensor* x2, const NormW& n, float eps, int silu, const Tensor& y) {
@@ -482,15 +488,16 @@ struct UNetRun {
     const int C = x1.C + (x2 ? x2->C : 0);
     const bool ready = x1.stats != nullptr && (x2 == nullptr || x2->stats != nullptr) &&
                        groupnorm_bins_align(C / m->cfg.norm_num_groups, x1.C, x1.sbin, x2 ? x2->sbin : 0);
-    float* stats = ready ? nullptr : stats_slot();
+    const int HW = x1.H * x1.W;
+    float* stats = ready ? nullptr : stats_slot(groupnorm_stats_floats(Bx, HW, m->cfg.norm_num_groups));
     if (dry) return 0;
-    GILL_REQUIRE(m->gn_next <= m->gn_slots, "internal: GroupNorm stats pool exhausted");
+    GILL_REQUIRE(m->gn_next <= m->gn_floats, "internal: GroupNorm stats pool exhausted");
     if (ready)
-      return groupnorm_apply_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, x1.H * x1.W, m->cfg.norm_num_groups,
-                                    n.g, n.b, eps, silu, y.p, x1.stats, x1.sbin, x1.C, x2 ? x2->stats : nullptr,
-                                    x2 ? x2->sbin : 0, s);
-    return groupnorm_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, x1.H * x1.W, m->cfg.norm_num_groups, n.g,
-                            n.b, eps, silu, y.p, stats, s, 1);
+      return groupnorm_apply_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, HW, m->cfg.norm_num_groups,
+                                    n.g, n.b, eps, silu, y.p, x1.stats, x1.sbin, x1.C, HW / GN_SLAB_ROWS,
+                                    x2 ? x2->stats : nullptr, x2 ? x2->sbin : 0, x2 ? HW / GN_SLAB_ROWS : 0, s);
+    return groupnorm_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, HW, m->cfg.norm_num_groups, n.g,
+                            n.b, eps, silu, y.p, stats, s);
   }
   // 3x3 conv (pad 1) over x1 (++ x2): stride 1|2, optional fused nearest-2x upsample
   int conv(const Tensor& x1, const Tensor* x2, const ConvW& w, int stride, int ups, const float* rowvec, int rv_bstride,
@@ -508,12 +515,12 @@ struct UNetRun {
   }
   int linear(const bf16_t* A, int lda, const bf16_t* A2, int lda2, int K1, int M, const bf16_t* W, const float* b, int N,
              int K, const bf16_t* resid, int act, bf16_t* out, int ldc, const Tensor* ystats = nullptr,
-             float* row_stats = nullptr) {
+             RowStats* row_stats = nullptr) {
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.K1 = K1; g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.W = W; g.bias = b;
-    g.resid = resid; g.ldr = N; g.act = act; g.C = out; g.ldc = ldc; g.row_stats = row_stats;
+    g.resid = resid; g.ldr = N; g.act = act; g.C = out; g.ldc = ldc;
     if (ystats) fuse_stats(g, *ystats);
-    return gemm(g);
+    return gemm(g, row_stats);
   }
 
   // out_stats: the output feeds a single-source GroupNorm next (accumulate its sums in conv2's epilogue)
@@ -576,8 +583,8 @@ struct UNetRun {
     Tensor t = talloc(H, Wd, C);   // transformer residual stream
     // norm1/2/3 never materialise: the GEMM that writes the residual stream also accumulates each row's sum and sum of
     // squares, and the projection that follows applies mean / rstd in its epilogue on weights pre-multiplied by the LN gain
-    float* st1 = ln_slot(M); float* st2 = ln_slot(M); float* st3 = ln_slot(M);
-    GILL_TRY(linear(n.p, C, nullptr, 0, C, M1, w.proj_in.w, w.proj_in.b, C, C, nullptr, ACT_NONE, t.p, C, nullptr, st1));
+    RowStats st1 = ln_slot(M, C), st2 = ln_slot(M, C), st3 = ln_slot(M, C);
+    GILL_TRY(linear(n.p, C, nullptr, 0, C, M1, w.proj_in.w, w.proj_in.b, C, C, nullptr, ACT_NONE, t.p, C, nullptr, &st1));
     const int hw_pad = round_up(HW, 32);   // kv tiles are 32 wide; pad rows hold finite stale data and are masked
     bf16_t* q = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * nh * hw_pad * w.dp);
     bf16_t* k = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * nh * hw_pad * w.dp);
@@ -587,7 +594,7 @@ struct UNetRun {
     {
       GemmArgs g;
       g.M = M1; g.N = 3 * hdp; g.K = C; g.K1 = C; g.A = t.p; g.lda = C; g.W = w.wqkv1;
-      g.ln_stats = st1; g.ln_colsum = w.s_qkv1; g.bias = w.c_qkv1;
+      g.ln_stats = st1.p; g.ln_planes = st1.planes; g.ln_colsum = w.s_qkv1; g.bias = w.c_qkv1;
       g.out_mode = OUT_QKV; g.Cq = q; g.Ck = k; g.Cvt = vt; g.heads = nh; g.dp = w.dp; g.dpv = w.dpv;
       g.ntok = HW; g.ntok_pad_q = hw_pad; g.ntok_pad_kv = hw_pad; g.seg_base = 0;
       g.qscale = 1.4426950408889634f / sqrtf((float)w.d);
@@ -596,11 +603,11 @@ struct UNetRun {
     Bx = Bpre;
     GILL_TRY(attend(q, k, vt, o, HW, HW, hw_pad, hw_pad, w));
     Bx = Bfull;
-    GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M1, w.out1.w, w.out1.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, st2));
+    GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M1, w.out1.w, w.out1.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, &st2));
     if (shared && !dry) {
       // second half of the pair := first half (residual stream, its LayerNorm row sums, the block input)
       GILL_TRY(copy_bytes_launch(t.p + (size_t)M1 * C, t.p, sizeof(bf16_t) * (size_t)M1 * C, s));
-      GILL_TRY(copy_bytes_launch(st2 + (size_t)M1 * 2, st2, sizeof(float) * (size_t)M1 * 2, s));
+      // (out1 ran on M1 rows: its row-sum planes are [planes][M1][2]; the consumer below wraps rows >= M1 onto them)
       GILL_TRY(copy_bytes_launch(xd.p, x.p, sizeof(bf16_t) * (size_t)M1 * C, s));
       GILL_TRY(copy_bytes_launch(xd.p + (size_t)M1 * C, x.p, sizeof(bf16_t) * (size_t)M1 * C, s));
     }
@@ -608,20 +615,20 @@ struct UNetRun {
     {
       GemmArgs g;
       g.M = M; g.N = hdp; g.K = C; g.K1 = C; g.A = t.p; g.lda = C; g.W = w.wq2;
-      g.ln_stats = st2; g.ln_colsum = w.s_q2; g.bias = w.c_q2;
+      g.ln_stats = st2.p; g.ln_planes = st2.planes; g.ln_rows = M1; g.ln_colsum = w.s_q2; g.bias = w.c_q2;
       g.out_mode = OUT_QKV; g.Cq = q; g.Ck = k; g.Cvt = vt; g.heads = nh; g.dp = w.dp; g.dpv = w.dpv;
       g.ntok = HW; g.ntok_pad_q = hw_pad; g.ntok_pad_kv = hw_pad; g.seg_base = 0;
       g.qscale = 1.4426950408889634f / sqrtf((float)w.d);
       GILL_TRY(gemm(g));
     }
     GILL_TRY(attend(q, m->kcache[w.layer_id], m->vcache[w.layer_id], o, HW, m->cfg.ctx_len, hw_pad, m->ctx_pad, w));
-    GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M, w.out2.w, w.out2.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, st3));
+    GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M, w.out2.w, w.out2.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, &st3));
     // --- GEGLU feed-forward
     bf16_t* ffh = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)M * 4 * C);
     {
       GemmArgs g;
       g.M = M; g.N = 8 * C; g.K = C; g.K1 = C; g.A = t.p; g.lda = C; g.W = w.wff1; g.bias = w.bff1;
-      g.ln_stats = st3; g.ln_colsum = w.s_ff1;
+      g.ln_stats = st3.p; g.ln_planes = st3.planes; g.ln_colsum = w.s_ff1;
       g.act = ACT_GEGLU; g.C = ffh; g.ldc = 4 * C;
       GILL_TRY(gemm(g));
     }
@@ -640,10 +647,7 @@ struct UNetRun {
     m->arena.off = 0;
     m->gn_next = 0;
     m->ln_next = 0;
-    if (!dry) {
-      GILL_TRY(zero_bytes_launch(m->gn_stats, sizeof(float) * (size_t)m->gn_slots * m->gn_slot_floats, s));
-      GILL_TRY(zero_bytes_launch(m->ln_stats, sizeof(float) * m->ln_floats, s));
-    }
+    // (the statistics pools need no zeroing: every partial sum is written exactly once by its producer)
     std::vector<Tensor> skips;
     Tensor x = talloc(L, L, ch[0], true);
     {
@@ -714,7 +718,7 @@ static int unet_plan_and_alloc(gill_unet* m) {
   UNetRun r{m, nullptr, Bx, nullptr, 0, true};
   GILL_TRY(r.forward(nullptr, nullptr));
   if (Bx % 2 == 0) {               // the CFG shared-prefix path allocates differently: size for the larger of the two
-    const int gn1 = m->gn_next; const size_t ln1 = m->ln_next;
+    const size_t gn1 = m->gn_next; const size_t ln1 = m->ln_next;
     r.cfg_pair = true;
     GILL_TRY(r.forward(nullptr, nullptr));   // (arena.high is a running maximum)
     if (gn1 > m->gn_next) m->gn_next = gn1;
@@ -723,9 +727,8 @@ static int unet_plan_and_alloc(gill_unet* m) {
   const size_t need = m->arena.high + (1 << 20);
   GILL_TRY(m->pool.alloc(&m->arena_mem, need, true));
   m->arena.base = m->arena_mem; m->arena.cap = need; m->arena.dry = false; m->arena.off = 0;
-  m->gn_slots = m->gn_next + 1;             // counted by the dry run
-  m->gn_slot_floats = Bx * 64 * 2;
-  GILL_TRY(m->pool.alloc(&m->gn_stats, (size_t)m->gn_slots * m->gn_slot_floats));
+  m->gn_floats = m->gn_next + 64;           // counted by the dry run
+  GILL_TRY(m->pool.alloc(&m->gn_stats, m->gn_floats));
   m->ln_floats = m->ln_next + 64;           // counted by the dry run (max batch)
   GILL_TRY(m->pool.alloc(&m->ln_stats, m->ln_floats));
   m->splitk_ws_floats = (size_t)48 << 20;   // 192 MiB of fp32 partials
@@ -852,20 +855,22 @@ extern "C" int gill_pndm_schedule(int num_steps, int32_t* timesteps_out, double*
   return (int)ts.size();
 }
 
-static int sd_denoise_on(gill_unet* m, const void* cond_bf16, const void* uncond_bf16, const float* latents0, int B,
+static int sd_denoise_on(gill_unet* m, const void* cond_bf16, const void* uncond_bf16, int n_uncond, const float* latents0, int B,
                          int num_steps, float guidance, float* latents_out, hipStream_t s);
 
-extern "C" int gill_sd_denoise(gill_unet* m, const void* cond_bf16, const void* uncond_bf16, const float* latents0, int B,
-                               int num_steps, float guidance, float* latents_out, void* stream) {
+extern "C" int gill_sd_denoise(gill_unet* m, const void* cond_bf16, const void* uncond_bf16, int n_uncond, const float* latents0,
+                               int B, int num_steps, float guidance, float* latents_out, void* stream) {
   GILL_REQUIRE(m && cond_bf16 && latents0 && latents_out, "null argument");
+  GILL_REQUIRE(guidance <= 1.0f || uncond_bf16 == nullptr || n_uncond == 1 || n_uncond == B,
+               "negative embeddings: batch must be 1 or B");
   hipStream_t caller = (hipStream_t)stream;
   GILL_TRY(m->fence.enter(caller));
-  const int rc = sd_denoise_on(m, cond_bf16, uncond_bf16, latents0, B, num_steps, guidance, latents_out, m->fence.stream);
+  const int rc = sd_denoise_on(m, cond_bf16, uncond_bf16, n_uncond, latents0, B, num_steps, guidance, latents_out, m->fence.stream);
   GILL_TRY(m->fence.leave(caller));
   return rc;
 }
 
-static int sd_denoise_on(gill_unet* m, const void* cond_bf16, const void* uncond_bf16, const float* latents0, int B,
+static int sd_denoise_on(gill_unet* m, const void* cond_bf16, const void* uncond_bf16, int n_uncond, const float* latents0, int B,
                          int num_steps, float guidance, float* latents_out, hipStream_t s) {
   GILL_REQUIRE(num_steps >= 2 && num_steps <= 1000, "num_steps out of range");
   const bool cfg = guidance > 1.0f;     // do_classifier_free_guidance (custom_sd.py:588)
@@ -931,8 +936,9 @@ static int sd_denoise_on(gill_unet* m, const void* cond_bf16, const void* uncond
   // prompt_embeds = cat([negative_prompt_embeds.repeat(B), prompt_embeds])  (custom_sd.py:365-371)
   if (cfg) {
     for (int b = 0; b < B; ++b)
-      GILL_CHECK_HIP(hipMemcpyAsync(m->ctx_full + (size_t)b * ctx_elems, uncond_bf16, sizeof(bf16_t) * ctx_elems,
-                                    hipMemcpyDeviceToDevice, s));
+      GILL_CHECK_HIP(hipMemcpyAsync(m->ctx_full + (size_t)b * ctx_elems,
+                                    (const bf16_t*)uncond_bf16 + (n_uncond == B ? (size_t)b * ctx_elems : 0),
+                                    sizeof(bf16_t) * ctx_elems, hipMemcpyDeviceToDevice, s));
     GILL_CHECK_HIP(hipMemcpyAsync(m->ctx_full + (size_t)B * ctx_elems, cond_bf16, sizeof(bf16_t) * ctx_elems * B,
                                   hipMemcpyDeviceToDevice, s));
   } else {

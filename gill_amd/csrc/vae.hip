@@ -60,7 +60,7 @@ struct gill_vae {
   // workspace
   VArena arena;
   unsigned char* arena_mem = nullptr;
-  float* gn_stats = nullptr; int gn_slots = 0, gn_slot_floats = 0, gn_next = 0;
+  float* gn_stats = nullptr; size_t gn_floats = 0, gn_next = 0;   // per-decode pool of GroupNorm partial-sum slots
   float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
   float* lat_prep = nullptr;   // [B][4][L][L] after scaling + post_quant_conv
   float* img_f32 = nullptr;    // [B][3][8L][8L]
@@ -197,18 +197,17 @@ struct VRun {
   int B;
   bool dry;
 
-  float* stats_slot() {
-    float* p = dry ? nullptr : m->gn_stats + (size_t)m->gn_next * m->gn_slot_floats;
-    ++m->gn_next;
+  float* stats_slot(size_t floats) {
+    float* p = dry ? (float*)(uintptr_t)16 : m->gn_stats + m->gn_next;
+    m->gn_next += (floats + 3) & ~(size_t)3;
     return p;
   }
   VTensor talloc(int H, int W, int C, bool want_stats) {
     VTensor t; t.H = H; t.W = W; t.C = C;
     t.p = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)B * H * W * C);
-    if (want_stats && (H * W) % 64 == 0) {
-      t.stats = stats_slot();
-      if (dry) t.stats = (float*)(uintptr_t)16;
-    }
+    const int G = m->cfg.norm_num_groups;
+    if (want_stats && (H * W) % GN_SLAB_ROWS == 0 && C % G == 0 && gemm_fused_gn_ok(C, C / G))
+      t.stats = stats_slot((size_t)B * (H * W / GN_SLAB_ROWS) * G * 2);
     return t;
   }
   void fuse_stats(GemmArgs& g, const VTensor& y) {
@@ -225,10 +224,13 @@ struct VRun {
   }
   int gnorm(const VTensor& x, const NormW& n, int silu, const VTensor& y) {
     const bool ready = x.stats != nullptr;
-    float* stats = ready ? x.stats : stats_slot();
+    const int HW = x.H * x.W, G = m->cfg.norm_num_groups;
+    float* stats = ready ? x.stats : stats_slot(groupnorm_stats_floats(B, HW, G));
     if (dry) return 0;
-    return groupnorm_launch(x.p, x.C, nullptr, 0, B, x.H * x.W, m->cfg.norm_num_groups, n.g, n.b, 1e-6f, silu, y.p, stats, s,
-                            ready ? 2 : 1);
+    if (ready)
+      return groupnorm_apply_launch(x.p, x.C, nullptr, 0, B, HW, G, n.g, n.b, 1e-6f, silu, y.p, stats, x.C / G, x.C,
+                                    HW / GN_SLAB_ROWS, nullptr, 0, 0, s);
+    return groupnorm_launch(x.p, x.C, nullptr, 0, B, HW, G, n.g, n.b, 1e-6f, silu, y.p, stats, s);
   }
   int conv(const VTensor& x, const ConvW& w, int ups, const bf16_t* resid, const VTensor& y) {
     GemmArgs g;
@@ -320,7 +322,6 @@ struct VRun {
     m->arena.off = 0;
     m->gn_next = 0;
     if (!dry) {
-      GILL_TRY(zero_bytes_launch(m->gn_stats, sizeof(float) * (size_t)m->gn_slots * m->gn_slot_floats, s));   // (kernel, not a memset node: capturable)
       const int64_t total = (int64_t)B * c.latent_channels * L * L;
       int blocks = (int)((total + 255) / 256);
       hipLaunchKernelGGL(vae_latent_prep_kernel, dim3(blocks), dim3(256), 0, s, latents, m->pq_w, m->pq_b,
@@ -436,8 +437,8 @@ extern "C" int gill_vae_create(gill_vae** out, const gill_vae_config* cfg, const
   if ((rc = r.decode(nullptr, nullptr))) return fail(rc);
   if ((rc = m->pool.alloc(&m->arena_mem, m->arena.high + (1 << 20), true))) return fail(rc);
   m->arena.base = m->arena_mem; m->arena.dry = false;
-  m->gn_slots = m->gn_next + 1; m->gn_slot_floats = B * 64 * 2;
-  if ((rc = m->pool.alloc(&m->gn_stats, (size_t)m->gn_slots * m->gn_slot_floats))) return fail(rc);
+  m->gn_floats = m->gn_next + 64;
+  if ((rc = m->pool.alloc(&m->gn_stats, m->gn_floats))) return fail(rc);
   m->splitk_ws_floats = (size_t)16 << 20;
   if ((rc = m->pool.alloc(&m->splitk_ws, m->splitk_ws_floats, false))) return fail(rc);
   if ((rc = m->pool.alloc(&m->lat_prep, (size_t)B * cfg->latent_channels * Lz * Lz))) return fail(rc);

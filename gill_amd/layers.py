@@ -39,6 +39,9 @@ class TextFcLayer(nn.Module):
       raise NotImplementedError(mode)
     self._handle = None
     self._handle_key = None
+    # the native handle snapshots the weights: any state-dict load (also the recursive one of a parent module, which does not
+    # go through this class's load_state_dict) drops it
+    self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.release_native())
 
   # ---- native handle management -------------------------------------------------------------
   def _apply(self, fn, *a, **k):          # .cuda() / .bfloat16() / .to(): weights move -> rebuild lazily

@@ -12,8 +12,10 @@ Reference map (file:line in /root/reference/gill/models.py):
 New here (NOT in the reference): GILL.generate_images — the batched entry whose
 per-prompt semantics are the 'gen' branch of generate_for_images_and_texts([p], num_words=2, gen_scale_factor=1e5).
 
-Out of scope of this build (raise NotImplementedError): image prompts / CLIP vision tower, captioning and
-retrieval modes.
+Also built: image prompts through the native CLIP vision tower (get_visual_embs), KV-cached decoding in
+generate(), the retrieval / decision / CLIP-rerank branches of generate_for_images_and_texts, load_gill with the cc3m*.npy
+retrieval embeddings.  Out of scope (raise NotImplementedError): the captioning / retrieval TRAINING modes of
+GILLModel.forward.
 """
 from __future__ import annotations
 
@@ -161,6 +163,8 @@ class GILLModel(nn.Module):
     self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
     self._opt_handle = None
     self._opt_cap = (0, 0)
+    # native handles snapshot the weights: a state-dict load into this module (or, recursively, into a parent) drops them
+    self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.refresh_native())
 
   # ---- weights -------------------------------------------------------------------------------
   @staticmethod
@@ -264,8 +268,10 @@ class GILLModel(nn.Module):
   def refresh_native(self):
     """Call after mutating weights in place once a forward has already run (handles snapshot the weights)."""
     self.release_native()
-    for fc in self.gen_text_hidden_fcs:
-      fc.release_native()
+    for fcs in (self.gen_text_hidden_fcs, getattr(self, 'ret_text_hidden_fcs', [])):
+      for fc in fcs:
+        if hasattr(fc, 'release_native'):
+          fc.release_native()
 
   def __del__(self):
     try:
@@ -330,7 +336,12 @@ class GILLModel(nn.Module):
     """hidden_states[-1] rows of the tokens past_len .. past_len+T_new-1, computed against the handle's KV cache
     (gill_opt_forward_cached).  past_len == 0 starts a new sequence."""
     B, Tn, D = new_embeds.shape
-    h = self._opt_native(B, past_len + Tn)      # never grows mid-sequence: generate() sizes the handle up front
+    cb, ct = self._opt_cap
+    if past_len > 0 and (self._opt_handle is None or B > cb or past_len + Tn > ct):
+      # growing would rebuild the handle and lose the keys / values cached so far
+      raise N.GillNativeError(f'KV cache of the OPT handle holds {ct} tokens x {cb} sequences; step needs {past_len + Tn} x {B}. '
+                              f'generate() sizes it up front (max_positions = {self.opt_cfg.max_positions}).')
+    h = self._opt_native(B, past_len + Tn)
     x = new_embeds.to(torch.bfloat16).contiguous()
     out = torch.empty((B, Tn, D), device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
@@ -398,8 +409,12 @@ class GILLModel(nn.Module):
       dev = embeddings.device
       vocab = self.opt_cfg.vocab_size
       hidden = None
-      if use_kv_cache:   # the cache lives in the handle: size it for the longest sequence this call can produce
-        self._opt_native(embeddings.shape[0], embeddings.shape[1] + max_len + len(self.retrieval_token_idx))
+      if use_kv_cache:
+        # the cache lives in the handle: size it for the longest sequence this call can produce — every one of the max_len
+        # steps may emit [IMG0] and so append all len(retrieval_token_idx) forced tokens (:518-520) — capped at the LM's
+        # position table.  The handle is never rebuilt mid-sequence (_lm_forward_hidden_cached raises instead).
+        grow = max(1, len(self.retrieval_token_idx))
+        self._opt_native(embeddings.shape[0], min(embeddings.shape[1] + max_len * grow, self.opt_cfg.max_positions))
       for i in range(max_len):
         if use_kv_cache:
           past = 0 if hidden is None else hidden.shape[1]
@@ -477,8 +492,7 @@ class GILL(nn.Module):
         model_id = os.environ.get("GILL_SD_DIR", "runwayml/stable-diffusion-v1-5")
         self.sd_pipe = GillSDPipeline.from_pretrained(model_id).to("cuda")
     if decision_model_path is not None:
-      # the decision MLP belongs to the retrieval branch (models.py:553-561): parameters are loaded for
-      # state-dict compatibility, the branch itself is out of scope
+      # decision MLP of the gen-vs-ret choice (models.py:553-561); applied in generate_for_images_and_texts (:671-682)
       print('Loading decision model...')
       self.decision_model = nn.Sequential(*[nn.Dropout(0.5), nn.Linear(4096, 2)])
       mlp_checkpoint = torch.load(decision_model_path, map_location='cpu')
@@ -693,8 +707,13 @@ class GILL(nn.Module):
       full[b, :n] = ids[b, :n]
       full[b, n:n + k] = img
     last_idx = lens + k - 1
+    # a rank whose shard is empty (fewer prompts than ranks) still enters the collectives below with (0, ...) tensors
+    embs = torch.zeros((0, self.model.args.num_clip_tokens, self.model.args.gen_emb_dim), device=dev,
+                       dtype=self.model.logit_scale.dtype)
     local = None
-    embs = None
+    if self.load_sd:
+      local = torch.zeros((0, self.sd_pipe.cfg.in_channels, self.sd_pipe.cfg.sample_size, self.sd_pipe.cfg.sample_size),
+                          device=dev, dtype=torch.float32)
     if B > 0:
       raw, emb = self.model.img_hidden_states(full.to(dev), last_idx)
       embs = self.model.gen_text_hidden_fcs[0](raw, emb)          # (B,77,768)
@@ -714,9 +733,10 @@ class GILL(nn.Module):
     if decode:
       if not self.load_sd:
         raise ValueError('decode=True needs load_sd=True')
-      images = self.sd_pipe.decode_latents(local, as_uint8=True) if local is not None else None
+      images = self.sd_pipe.decode_latents(local, as_uint8=True) if B > 0 else \
+          torch.zeros((0, 8 * self.sd_pipe.cfg.sample_size, 8 * self.sd_pipe.cfg.sample_size, 3), device=dev, dtype=torch.uint8)
     if not self.load_sd:
-      return parallel.gather_rows(embs, B_total, distributed) if embs is not None else None
+      return parallel.gather_rows(embs, B_total, distributed)
     out = parallel.gather_rows(local, B_total, distributed)
     if decode:
       return out, images
@@ -728,7 +748,15 @@ class GILL(nn.Module):
     if isinstance(prompts, torch.Tensor):
       ids = prompts.to('cpu', torch.int64)
       pad = self.model.tokenizer.pad_token_id
-      lens = (ids != pad).sum(dim=1) if pad is not None else torch.full((ids.shape[0],), ids.shape[1])
+      # length = row length minus the TRAILING run of pad ids (a global count of non-pad ids miscounts when pad == eos/bos,
+      # which load_gill sets for tokenizers without a pad token)
+      if pad is None:
+        lens = torch.full((ids.shape[0],), ids.shape[1])
+      else:
+        not_pad = (ids != pad)
+        last = torch.where(not_pad.any(dim=1), ids.shape[1] - 1 - torch.argmax(not_pad.flip(1).to(torch.int64), dim=1),
+                           torch.full((ids.shape[0],), -1))
+        lens = last + 1
       return ids, lens.to(torch.int64)
     rows = [self.model.tokenizer(p, add_special_tokens=True, return_tensors="pt").input_ids[0] for p in prompts]
     lens = torch.tensor([len(r) for r in rows], dtype=torch.int64)
@@ -749,14 +777,15 @@ def load_gill(model_dir: str, load_ret_embs: bool = True, decision_model_fn: str
     raise ValueError(f'model_args.json does not exist in {model_dir}.')
   if not os.path.exists(model_ckpt_path):
     raise ValueError(f'pretrained_ckpt.pth.tar does not exist in {model_dir}.')
-  if not load_ret_embs or len(embs_paths) == 0:
-    if len(embs_paths) == 0:
+  path_array, emb_matrix = None, None
+  if load_ret_embs and embs_paths:
+    # models.py:826-838: every cc3m*.npy is a pickle {'paths': [...], 'embeddings': [...]} precomputed with
+    # get_visual_embs(image, mode='retrieval'); rows of all files are concatenated in glob order
+    path_array, emb_matrix = _read_retrieval_embeddings(embs_paths)
+  else:
+    if not embs_paths:
       print(f'cc3m.npy files do not exist in {model_dir}.')
     print('Running the model without retrieval.')
-    path_array, emb_matrix = None, None
-  else:
-    raise NotImplementedError('retrieval embeddings (cc3m*.npy) drive the retrieval branch, which is out of scope; '
-                              'call load_gill(..., load_ret_embs=False)')
   with open(model_args_path, 'r') as f:
     model_kwargs = json.load(f)
 
@@ -794,4 +823,23 @@ def load_gill(model_dir: str, load_ret_embs: bool = True, decision_model_fn: str
       assert model_kwargs['share_ret_gen'], 'Model loading only supports share_ret_gen=True for now.'
     model.model.input_embeddings.weight[-model_kwargs['num_tokens']:, :].copy_(img_token_embeddings)
   model.model.refresh_native()   # native handles snapshot the weights: rebuild after the in-place copy
+  if emb_matrix is not None:     # models.py:895-900: unit rows scaled by exp(logit_scale), in the model's dtype, on its device
+    scale = model.model.logit_scale.exp()
+    m = torch.as_tensor(emb_matrix).to(device=scale.device, dtype=scale.dtype)
+    model.emb_matrix = scale * (m / m.norm(dim=1, keepdim=True))
   return model
+
+
+def _read_retrieval_embeddings(paths: List[str]):
+  """cc3m*.npy files (pickles despite the suffix) -> (list of image paths / urls, float array (N, ret_emb_dim))."""
+  import pickle
+  names: List[str] = []
+  rows = []
+  for p in paths:
+    with open(p, 'rb') as f:
+      blob = pickle.load(f)
+    names.extend(blob['paths'])
+    rows.extend(blob['embeddings'])
+  mat = np.stack(rows, axis=0)
+  assert len(names) == mat.shape[0], (len(names), mat.shape)   # one embedding per path (models.py:841)
+  return names, mat

@@ -30,14 +30,20 @@ def shard_range(n: int, distributed: bool = True) -> Tuple[int, int]:
   return shard_bounds(n, r, w)
 
 
-def gather_rows(local: Optional[torch.Tensor], n_total: int, distributed: bool = True) -> torch.Tensor:
+def gather_rows(local: torch.Tensor, n_total: int, distributed: bool = True) -> torch.Tensor:
   """All-gather row-sharded results (rows = prompts) back into (n_total, ...) on every rank.
-  Uneven shards are padded to the largest shard for the collective and trimmed afterwards."""
+  Uneven shards are padded to the largest shard for the collective and trimmed afterwards.  EVERY rank must call this,
+  also one whose shard is empty (n_total < world): it passes a (0, ...) tensor of the right trailing shape / dtype /
+  device — entering the collective with nothing to contribute is what keeps the other ranks from hanging."""
   r, w = world(distributed)
+  if local is None:
+    raise ValueError("gather_rows: pass a (0, ...) tensor for an empty shard, not None (every rank enters the collective)")
   if w == 1:
     return local
   max_rows = (n_total + w - 1) // w
-  assert local is not None or n_total < w, "a rank with an empty shard must still pass a (0, ...) tensor"
+  lo, hi = shard_bounds(n_total, r, w)
+  if local.shape[0] != hi - lo:
+    raise ValueError(f"gather_rows: rank {r} holds {local.shape[0]} rows, its shard of {n_total} over {w} ranks is {hi - lo}")
   rest = tuple(local.shape[1:])
   buf = torch.zeros((max_rows,) + rest, device=local.device, dtype=local.dtype)
   buf[:local.shape[0]] = local

@@ -8,8 +8,9 @@ The reference builds `StableDiffusionPipeline.from_pretrained("runwayml/stable-d
 guidance_scale / num_inference_steps / output_type) and runs the UNet + PNDM loop in libgill_amd
 (gill_sd_denoise: csrc/unet.hip).
 
-Not built yet: the VAE decode + PIL conversion.  `output_type="latent"` (default
-here) returns the final latents (B,4,64,64) fp32 in `.images`; `output_type="pil"` raises.
+`output_type="latent"` (default here: the hot path hands latents to the all-gather) returns the final latents (B,4,64,64)
+fp32 in `.images`; "pil" / "np" / "pt" run the VAE decoder (gill_vae_decode: csrc/vae.hip, custom_sd.py:385-392, :654-661) and
+need the handle to have been built with VAE weights.
 """
 from __future__ import annotations
 
@@ -116,6 +117,11 @@ class GillSDPipeline:
                      heads_per_level=None if isinstance(ahd, int) else tuple(ahd), prediction_type=pred)
     wpath = os.path.join(model_dir, "unet", "diffusion_pytorch_model.safetensors")
     sd = load_file(wpath)
+    upath = os.path.join(model_dir, "uncond_embeds.safetensors")
+    if uncond_embeds is None and os.path.exists(upath):
+      # offline cache of CLIP-text("") (1,77,ctx_dim): what _encode_prompt computes for the empty negative prompt
+      # (custom_sd.py:319-357), for machines without the text encoder / tokenizer files
+      uncond_embeds = load_file(upath)["uncond_embeds"]
     if uncond_embeds is None:
       # CLIP-text("") — plumbing through transformers when its files are on disk
       from transformers import CLIPTextModel, CLIPTokenizer
@@ -204,13 +210,21 @@ class GillSDPipeline:
       cond = cond.repeat_interleave(num_images_per_prompt, dim=0)
     cond = cond.contiguous()
     B = cond.shape[0]
-    uncond = self.uncond_embeds if negative_prompt_embeds is None else \
-        negative_prompt_embeds.to(self.device, torch.bfloat16)[:1].contiguous()
+    if negative_prompt_embeds is None:
+      uncond = self.uncond_embeds
+    else:      # custom_sd.py:359-369: one negative embedding per prompt (or one for all), repeated per image
+      uncond = negative_prompt_embeds.to(self.device, torch.bfloat16)
+      if uncond.shape[0] != 1 and num_images_per_prompt != 1:
+        uncond = uncond.repeat_interleave(num_images_per_prompt, dim=0)
+      uncond = uncond.contiguous()
+      if uncond.shape[0] not in (1, B) or tuple(uncond.shape[1:]) != tuple(cond.shape[1:]):
+        raise ValueError(f"`negative_prompt_embeds` must have the shape of `prompt_embeds` (or batch 1): got "
+                         f"{tuple(negative_prompt_embeds.shape)} for prompt_embeds {tuple(prompt_embeds.shape)}")
     lat0 = self.prepare_latents(B, generator, latents)
     out = torch.empty_like(lat0)
     with torch.cuda.device(self.device):
-      N.check(N.lib().gill_sd_denoise(self._h, N.ptr(cond), N.ptr(uncond), N.ptr(lat0), B, int(num_inference_steps),
-                                      float(guidance_scale), N.ptr(out), N.current_stream()))
+      N.check(N.lib().gill_sd_denoise(self._h, N.ptr(cond), N.ptr(uncond), int(uncond.shape[0]), N.ptr(lat0), B,
+                                      int(num_inference_steps), float(guidance_scale), N.ptr(out), N.current_stream()))
     if output_type == "pil":      # custom_sd.py:654-661 (the safety checker is not part of this path)
       from PIL import Image
       u8 = self.decode_latents(out, as_uint8=True).cpu().numpy()

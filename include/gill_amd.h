@@ -166,10 +166,12 @@ int gill_unet_forward(gill_unet* h, const float* sample, const float* timesteps_
 
 /* The whole denoise loop (custom_sd.py:607-651 with PNDMScheduler(skip_prk_steps, steps_offset=1,
  * scaled_linear 0.00085..0.012, 1000 train steps)):
- *   cond (B,77,768) bf16, uncond (1,77,768) bf16, latents0 (B,4,L,L) fp32 (already * init_noise_sigma=1)
+ *   cond (B,77,768) bf16, uncond (n_uncond,77,768) bf16 with n_uncond == 1 (one negative embedding repeated over the batch,
+ *   custom_sd.py:365-369) or == B (per-sample negative_prompt_embeds), latents0 (B,4,L,L) fp32 (already * init_noise_sigma=1)
  *   -> latents_out (B,4,L,L) fp32.  num_steps "inference steps" = num_steps+1 UNet calls of batch 2B.
- *   guidance <= 1 disables CFG (batch B, uncond ignored) like do_classifier_free_guidance. */
-int gill_sd_denoise(gill_unet* h, const void* cond_bf16, const void* uncond_bf16, const float* latents0, int B,
+ *   guidance <= 1 disables CFG (batch B, uncond ignored) like do_classifier_free_guidance.
+ *   The loop is enqueued on a stream the handle owns, ordered after / before the caller's `stream` by events. */
+int gill_sd_denoise(gill_unet* h, const void* cond_bf16, const void* uncond_bf16, int n_uncond, const float* latents0, int B,
                     int num_steps, float guidance, float* latents_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------

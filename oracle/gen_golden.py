@@ -12,6 +12,12 @@ What is executed from the reference, unmodified:
   F5  gill.models.GILLModel.get_visual_embs(mode='captioning')                  (gill/models.py:129-146)
   F6  generate_for_images_and_texts([PIL image, text])                          (gill/models.py:606-613)
   F7  the retrieval branch of the same method (emb_matrix / path_array given)  (gill/models.py:671-696)
+  F8  gill.custom_sd.StableDiffusionPipeline.__call__ — the CFG / scheduler / decode DRIVER     (gill/custom_sd.py:567-666,
+      with _encode_prompt :224-373, prepare_latents :458-473, decode_latents :385-392) — run with the ORACLE's UNet, PNDM
+      scheduler and VAE decoder injected as self.unet / self.scheduler / self.vae.  This pins the order of operations of the
+      loop (negative|positive concat, scale_model_input, guidance combine, scheduler.step call pattern, 1/0.18215, /2+0.5 clamp,
+      NHWC float32) to the reference's own lines.  It does NOT pin the UNet / scheduler / VAE arithmetic, which stays a
+      restatement of diffusers==0.17.1 (absent): see oracle/__init__.py.
 Harness shim: `diffusers` / `torchvision` are absent here, so empty stand-in modules are placed in
 sys.modules BEFORE importing gill.models (its stage-3 code is never called: load_sd=False); random-init OPT / CLIP
 models are saved to local dirs whose paths contain 'facebook/opt' and 'clip' (string checks at models.py:56,78); a
@@ -248,8 +254,122 @@ def golden_visual(ref_models, tmp):
   print("F5", tuple(ve.shape), float(ve.abs().mean()), "F6", repr(ret[0]), ret[1]["decision"], tuple(gen.shape))
 
 
+def _import_reference_sd():
+  """gill/custom_sd.py imports diffusers names at module level (custom_sd.py:18-31); diffusers is not installed, so empty
+  modules carrying exactly those names are registered first.  None of them contributes behaviour to __call__ except the
+  two trivial ones written out here (DiffusionPipeline.device, the output dataclass)."""
+  import transformers
+  if not hasattr(transformers, "CLIPFeatureExtractor"):
+    transformers.CLIPFeatureExtractor = object
+  names = ["diffusers", "diffusers.configuration_utils", "diffusers.models", "diffusers.schedulers", "diffusers.utils",
+           "diffusers.pipeline_utils", "diffusers.pipelines", "diffusers.pipelines.stable_diffusion",
+           "diffusers.pipelines.stable_diffusion.safety_checker"]
+  for n in names:
+    sys.modules[n] = types.ModuleType(n)
+  d = sys.modules
+  d["diffusers"].StableDiffusionPipeline = object
+  d["diffusers.configuration_utils"].FrozenDict = dict
+  d["diffusers.models"].AutoencoderKL = object
+  d["diffusers.models"].UNet2DConditionModel = object
+  d["diffusers.schedulers"].KarrasDiffusionSchedulers = object
+  u = d["diffusers.utils"]
+  u.deprecate = lambda *a, **k: None
+  u.is_accelerate_available = lambda: False
+  u.logging = types.SimpleNamespace(get_logger=lambda name: types.SimpleNamespace(warning=print, info=print))
+  u.randn_tensor = lambda shape, generator=None, device=None, dtype=None: torch.randn(shape, generator=generator, dtype=dtype)
+  u.replace_example_docstring = lambda doc: (lambda fn: fn)
+
+  class DiffusionPipeline:
+    device = torch.device("cpu")
+  d["diffusers.pipeline_utils"].DiffusionPipeline = DiffusionPipeline
+
+  class StableDiffusionPipelineOutput:
+    def __init__(self, images, nsfw_content_detected):
+      self.images, self.nsfw_content_detected = images, nsfw_content_detected
+  d["diffusers.pipelines.stable_diffusion"].StableDiffusionPipelineOutput = StableDiffusionPipelineOutput
+  d["diffusers.pipelines.stable_diffusion.safety_checker"].StableDiffusionSafetyChecker = object
+  if REF not in sys.path:
+    sys.path.insert(0, REF)
+  sys.modules.pop("gill.custom_sd", None)
+  import gill.custom_sd as ref_sd
+  return ref_sd
+
+
+def golden_sd_driver():
+  """F8: reference pipeline driver over the oracle's tiny UNet / PNDM scheduler / VAE decoder, 2 prompts, 10 steps."""
+  from oracle import scheduler_ref, unet_ref, vae_ref
+  ref_sd = _import_reference_sd()
+  cfg = synth.UNetConfig.tiny(16)
+  vcfg = synth.VAEConfig.tiny(16)
+  bfw = lambda sd: {k: v.bfloat16().float() for k, v in sd.items()}  # noqa: E731
+  usd, vsd = bfw(synth.unet_state_dict(cfg, seed=21)), bfw(synth.vae_decoder_state_dict(vcfg, seed=22))
+  B, steps, guidance = 2, 10, 7.5
+  cond = synth.normal("f8_cond", (B, cfg.ctx_len, cfg.cross_attention_dim), 21).bfloat16().float()
+  neg = synth.normal("f8_neg", (B, cfg.ctx_len, cfg.cross_attention_dim), 22).bfloat16().float()   # per-sample negatives
+  lat0 = synth.initial_latents(B, 4, cfg.sample_size, seed=2024)
+
+  class _Out:
+    def __init__(self, **kw):
+      self.__dict__.update(kw)
+
+  class UNet:
+    config = types.SimpleNamespace(sample_size=cfg.sample_size)
+    in_channels = cfg.in_channels
+    calls = []
+
+    def __call__(self, x, t, encoder_hidden_states=None, cross_attention_kwargs=None):
+      UNet.calls.append((int(t), tuple(x.shape)))
+      return _Out(sample=unet_ref.unet_forward(usd, x, torch.full((x.shape[0],), float(t)), encoder_hidden_states,
+                                               cfg.block_out_channels, cfg.num_heads, cfg.norm_num_groups))
+
+  class Scheduler(scheduler_ref.PNDMSchedulerRef):
+    def set_timesteps(self, n, device=None):
+      return super().set_timesteps(n)
+
+    def step(self, model_output, timestep, sample):
+      return _Out(prev_sample=super().step(model_output, int(timestep), sample))
+
+  class VAE:
+    config = types.SimpleNamespace(scaling_factor=vcfg.scaling_factor, block_out_channels=vcfg.block_out_channels)
+
+    def decode(self, z):   # the pipeline has already divided by 0.18215 (custom_sd.py:387): undo the oracle's own scaling
+      return _Out(sample=vae_ref.vae_decode(vsd, z * vcfg.scaling_factor, vcfg.block_out_channels, vcfg.norm_num_groups,
+                                            vcfg.scaling_factor))
+
+  pipe = object.__new__(ref_sd.StableDiffusionPipeline)     # __init__ only registers modules / checks configs
+  pipe.unet, pipe.scheduler, pipe.vae = UNet(), Scheduler(), VAE()
+  pipe.text_encoder = types.SimpleNamespace(dtype=torch.float32)
+  pipe.safety_checker, pipe.feature_extractor, pipe.tokenizer = None, None, None
+  pipe.vae_scale_factor = 8
+  seen = {}
+  with torch.no_grad():
+    out = pipe(prompt_embeds=cond, negative_prompt_embeds=neg, latents=lat0.clone(), guidance_scale=guidance,
+               num_inference_steps=steps, output_type="np", callback=lambda i, t, lat: seen.__setitem__("lat", lat.clone()),
+               callback_steps=1)
+    # same call with ONE negative embedding for the whole batch is not expressible through the reference's check_inputs
+    # (shapes must match), which is how GILL calls it only when negative_prompt_embeds is None; so also record the
+    # num_images_per_prompt = 2 expansion order of a single prompt (custom_sd.py:313-316, :361-364)
+    seen2 = {}
+    pipe.unet.calls.clear()
+    out2 = pipe(prompt_embeds=cond[:1], negative_prompt_embeds=neg[:1], latents=lat0.clone(), guidance_scale=guidance,
+                num_inference_steps=3, num_images_per_prompt=2, output_type="np",
+                callback=lambda i, t, lat: seen2.__setitem__("lat", lat.clone()), callback_steps=1)
+  assert out.nsfw_content_detected is None and out.images.shape == (B, 128, 128, 3)
+  np.savez_compressed(os.path.join(OUT, "sd_driver_tiny.npz"), cond=cond.numpy(), neg=neg.numpy(), lat0=lat0.numpy(),
+                      steps=np.int64(steps), guidance=np.float32(guidance), unet_seed=np.int64(21), vae_seed=np.int64(22),
+                      latents=seen["lat"].numpy(), images=out.images.astype(np.float16),
+                      latents_n2=seen2["lat"].numpy(), images_n2=out2.images.astype(np.float16),
+                      unet_call_timesteps=np.array([c[0] for c in pipe.unet.calls], dtype=np.int64))
+  print("F8", tuple(seen["lat"].shape), float(seen["lat"].abs().mean()), tuple(out.images.shape), float(out.images.mean()),
+        "n2", tuple(seen2["lat"].shape), [c[0] for c in pipe.unet.calls])
+
+
 def main():
   os.makedirs(OUT, exist_ok=True)
+  if len(sys.argv) > 1 and sys.argv[1] == "sd":   # F8 only (does not need the OPT / CLIP temp models)
+    torch.set_num_threads(8)
+    golden_sd_driver()
+    return
   torch.manual_seed(0)
   torch.set_num_threads(8)
   ref_layers, ref_models = _import_reference()
@@ -258,6 +378,7 @@ def main():
   try:
     golden_gillmodel(ref_models, tmp)
     golden_visual(ref_models, tmp)
+    golden_sd_driver()
   finally:
     shutil.rmtree(tmp, ignore_errors=True)
   print("wrote", sorted(os.listdir(OUT)))

@@ -38,10 +38,13 @@ def denoise(unet_sd: Dict[str, torch.Tensor], cond: torch.Tensor, uncond: Option
             num_inference_steps: int = 50, guidance_scale: float = 7.5,
             block_out_channels: Sequence[int] = (320, 640, 1280, 1280), heads=8, groups: int = 32,
             return_eps: bool = False, prediction_type: str = "epsilon"):
-  """custom_sd.py:588-651 (without VAE decode): cond (B,77,768), uncond (1,77,768), latents (B,4,L,L) fp32."""
+  """custom_sd.py:588-651 (without VAE decode): cond (B,77,768), uncond (1,77,768) or per-sample (B,77,768), latents (B,4,L,L)
+  fp32.  Pinned to the reference's own driver lines by tests/golden/sd_driver_tiny.npz (oracle/gen_golden.py F8)."""
   B = cond.shape[0]
   do_cfg = guidance_scale > 1.0
-  ctx = torch.cat([uncond.expand(B, -1, -1), cond], 0) if do_cfg else cond     # custom_sd.py:371
+  if do_cfg and uncond.shape[0] != B:
+    uncond = uncond.expand(B, -1, -1)
+  ctx = torch.cat([uncond, cond], 0) if do_cfg else cond                        # custom_sd.py:371
   sched = scheduler_ref.PNDMSchedulerRef(prediction_type=prediction_type)
   sched.set_timesteps(num_inference_steps)                                      # :607
   lat = latents.float() * sched.init_noise_sigma                                # :472

@@ -37,7 +37,7 @@ def _gloo_worker(rank, world, port, n_total, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [8, 5])
+@pytest.mark.parametrize("n_total", [8, 5, 1])      # 1 < world: rank 1's shard is empty and it must still enter the collective
 def test_gather_rows_world2_gloo(n_total):
   ctx = mp.get_context("spawn")
   q = ctx.Queue()
@@ -50,6 +50,26 @@ def test_gather_rows_world2_gloo(n_total):
     p.join(timeout=60)
   assert all(ok for _, ok, _ in res), res
   assert all(shape == (n_total, 4, 3, 3) for _, _, shape in res)
+
+
+def test_gather_rows_rejects_none_and_wrong_shard():
+  with pytest.raises(ValueError, match="empty shard"):
+    parallel.gather_rows(None, 4, distributed=False)
+  x = torch.zeros(3, 2)
+  assert parallel.gather_rows(x, 3, distributed=False) is x           # single process: identity
+
+
+def test_prompt_ids_lengths_with_pad_equal_to_eos():
+  """load_gill sets pad_token_id = eos_token_id (= bos = 2 for OPT) for tokenizers without a pad token: the length of a tensor
+  prompt is the row minus its TRAILING pad run, not a count of non-pad ids (the leading BOS is a pad id too)."""
+  g = _tiny_gill()
+  g.model.tokenizer.pad_token_id = 2
+  ids = torch.tensor([[2, 11, 12, 13, 2, 2], [2, 21, 2, 23, 24, 25], [2, 2, 2, 2, 2, 2]])
+  _, lens = g._prompt_ids(ids)
+  assert lens.tolist() == [4, 6, 0]
+  g.model.tokenizer.pad_token_id = 1
+  _, lens = g._prompt_ids(torch.tensor([[2, 11, 12, 1, 1], [2, 21, 22, 23, 24]]))
+  assert lens.tolist() == [3, 5]
 
 
 def test_hash_tokenizer_contract():

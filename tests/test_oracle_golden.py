@@ -127,3 +127,29 @@ def test_clip_image_preprocessing_matches_transformers():
       img, return_tensors="pt").pixel_values
     got = ClipImageProcessor(size, size)(img).pixel_values
     assert got.shape == ref.shape and (got - ref).abs().max().item() < 1e-5
+
+
+def test_sd_driver_oracle_matches_reference_pipeline_call():
+  """F8: the reference's own StableDiffusionPipeline.__call__ (gill/custom_sd.py:567-666) drove the oracle's UNet / PNDM scheduler
+  / VAE; the oracle's restatement of that driver (pipeline_ref.denoise + vae_ref) must reproduce its latents and images
+  exactly (same fp32 arithmetic, same call order), incl. per-sample negative embeddings, the warm-up repeat of the second
+  timestep and the num_images_per_prompt expansion."""
+  from oracle import vae_ref
+  g = _load("sd_driver_tiny.npz")
+  cfg, vcfg = synth.UNetConfig.tiny(16), synth.VAEConfig.tiny(16)
+  usd = _bf16_weights(synth.unet_state_dict(cfg, seed=int(g["unet_seed"])))
+  vsd = _bf16_weights(synth.vae_decoder_state_dict(vcfg, seed=int(g["vae_seed"])))
+  cond, neg, lat0 = (torch.from_numpy(g[k]) for k in ("cond", "neg", "lat0"))
+  lat = pipeline_ref.denoise(usd, cond, neg, lat0, int(g["steps"]), float(g["guidance"]), cfg.block_out_channels, cfg.num_heads,
+                             cfg.norm_num_groups)
+  ref = torch.from_numpy(g["latents"])
+  assert (lat - ref).abs().max().item() <= 1e-4 * ref.abs().max().item(), (lat - ref).abs().max().item()
+  img = vae_ref.vae_decode(vsd, lat, vcfg.block_out_channels, vcfg.norm_num_groups, vcfg.scaling_factor)
+  img = (img / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1)
+  assert (img - torch.from_numpy(g["images"]).float()).abs().max().item() < 2e-3      # fixture stored as fp16
+  # num_images_per_prompt = 2 of ONE prompt: both images share the prompt, each has its own latent; 3 steps = timesteps 667, 334, 334, 1
+  assert g["unet_call_timesteps"].tolist() == scheduler_ref.PNDMSchedulerRef().set_timesteps(3)
+  lat2 = pipeline_ref.denoise(usd, cond[:1].repeat(2, 1, 1), neg[:1].repeat(2, 1, 1), lat0, 3, float(g["guidance"]),
+                              cfg.block_out_channels, cfg.num_heads, cfg.norm_num_groups)
+  ref2 = torch.from_numpy(g["latents_n2"])
+  assert (lat2 - ref2).abs().max().item() <= 1e-4 * ref2.abs().max().item()
