@@ -26,6 +26,7 @@
 #define BM_HOST 128       // rows of the 4-wave tile, for the host-side split-K heuristic; the kernel's BM is 32 * NWV
 #define BK 64
 #define GEMM_THREADS 256
+#define LN_MAX_PLANES 20   // row-sum planes a folded-LayerNorm consumer can add: 2 per N tile of the producer, or one per 64 columns of a split-K reducer (C <= 1280)
 
 // zeros read by padding taps; a row's pointer advances 128 B per K step within a (tap, source) segment, so the page
 // covers the longest segment (ZERO_PAGE_STEPS K steps) plus one 128-B row
@@ -125,14 +126,17 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0
 //         s_barrier) — for grids of ~one workgroup per CU where co-residency cannot do the hiding.
 // folded LayerNorm: rstd and mean*rstd of A's row m from the producer's {sum, sum of squares}
 __device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& rr, float& rm) {
-  // the producer's per-plane partial sums of this row, added in plane order (fixed order: bit-reproducible)
+  // the producer's per-plane partial sums of this row, added in plane order (fixed order: bit-reproducible); the loads are
+  // issued together (predicated up to LN_MAX_PLANES), not one L2 round trip per plane
   const int R = p.ln_rows ? p.ln_rows : p.M;
   if (m >= R) m -= R;
-  float2 st = *reinterpret_cast<const float2*>(p.ln_stats + (size_t)m * 2);
-  for (int pl = 1; pl < p.ln_planes; ++pl) {
-    const float2 v = *reinterpret_cast<const float2*>(p.ln_stats + ((size_t)pl * R + m) * 2);
-    st.x += v.x; st.y += v.y;
-  }
+  float2 v[LN_MAX_PLANES];
+#pragma unroll
+  for (int pl = 0; pl < LN_MAX_PLANES; ++pl)
+    v[pl] = (pl < p.ln_planes) ? *reinterpret_cast<const float2*>(p.ln_stats + ((size_t)pl * R + m) * 2) : make_float2(0.f, 0.f);
+  float2 st = v[0];
+#pragma unroll
+  for (int pl = 1; pl < LN_MAX_PLANES; ++pl) { st.x += v[pl].x; st.y += v[pl].y; }
   const float invk = 1.f / (float)p.K;
   const float mean = st.x * invk;
   const float var = fmaxf(st.y * invk - mean * mean, 0.f);
@@ -591,51 +595,55 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_kernel(const GemmDev d) {
 // Fused statistics are fixed-order like the in-kernel epilogue's: per-row / per-column cells in LDS written once each, then
 // one thread per output sum adds them in index order (row sums -> plane blockIdx.x of row_stats, bins -> this slab's
 // GroupNorm partial).
-template <int W>
+template <int W, int R>
 __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArgs p) {
   constexpr int QW = W / 4;                     // column quads per row
-  __shared__ float2 rowp[64][QW];               // per (row, quad) {sum, sum of squares} of the bf16-rounded outputs
+  constexpr int ROWS = 16 * R;                  // rows per block: 64 for large outputs, 16 when blocks would be too few
+  __shared__ float2 rowp[ROWS][QW];               // per (row, quad) {sum, sum of squares} of the bf16-rounded outputs
   __shared__ float2 colp[16][W];                // per (row lane, column) {sum, sum of squares} over the lane's 4 rows
   const int tx = threadIdx.x % QW, ty = threadIdx.x / QW;
   const int n = blockIdx.x * W + tx * 4;
-  const int mbase = blockIdx.y * 64;
+  const int mbase = blockIdx.y * ROWS;
   float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
-  float rsum[4] = {0.f, 0.f, 0.f, 0.f}, rsq[4] = {0.f, 0.f, 0.f, 0.f};
+  float rsum[R], rsq[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { rsum[r] = 0.f; rsq[r] = 0.f; }
   if (n < p.N) {
     // all partial loads of the thread's 4 rows are issued before any epilogue store (a store in between would fence the
     // next row's loads): 4 rows x 4 splits = 16 independent 16-B loads in flight per pass
-    float4 s[4];
-    const float* src[4];
+    float4 s[R];
+    const float* src[R];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < R; ++r) {
       int m = mbase + ty + 16 * r;
       if (m > p.M - 1) m = p.M - 1;
       s[r] = make_float4(0, 0, 0, 0);
       src[r] = p.ws + (size_t)m * p.N + n;
     }
     const size_t zstride = (size_t)p.M * p.N;
+    constexpr int U = 16 / R;        // slices per pass: 16 independent 16-B loads in flight per thread either way
     int z = 0;
-    for (; z + 4 <= p.splitk; z += 4) {
-      float4 v[4][4];
+    for (; z + U <= p.splitk; z += U) {
+      float4 v[R][U];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[r][u] = *reinterpret_cast<const float4*>(src[r] + (size_t)(z + u) * zstride);
+        for (int u = 0; u < U; ++u) v[r][u] = *reinterpret_cast<const float4*>(src[r] + (size_t)(z + u) * zstride);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { s[r].x += v[r][u].x; s[r].y += v[r][u].y; s[r].z += v[r][u].z; s[r].w += v[r][u].w; }
+        for (int u = 0; u < U; ++u) { s[r].x += v[r][u].x; s[r].y += v[r][u].y; s[r].z += v[r][u].z; s[r].w += v[r][u].w; }
     }
     for (; z < p.splitk; ++z) {
-      float4 v[4];
+      float4 v[R];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = *reinterpret_cast<const float4*>(src[r] + (size_t)z * zstride);
+      for (int r = 0; r < R; ++r) v[r] = *reinterpret_cast<const float4*>(src[r] + (size_t)z * zstride);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { s[r].x += v[r].x; s[r].y += v[r].y; s[r].z += v[r].z; s[r].w += v[r].w; }
+      for (int r = 0; r < R; ++r) { s[r].x += v[r].x; s[r].y += v[r].y; s[r].z += v[r].z; s[r].w += v[r].w; }
     }
     const float4 cs = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + n) : make_float4(0, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < R; ++r) {
       const int m = mbase + ty + 16 * r;
       if (m >= p.M) continue;
       if (p.ln_stats) {
@@ -654,9 +662,9 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
   }
   if (p.row_stats) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rowp[ty + 16 * r][tx] = make_float2(rsum[r], rsq[r]);
+    for (int r = 0; r < R; ++r) rowp[ty + 16 * r][tx] = make_float2(rsum[r], rsq[r]);
     __syncthreads();
-    if (threadIdx.x < 64 && mbase + (int)threadIdx.x < p.M) {
+    if ((int)threadIdx.x < ROWS && mbase + (int)threadIdx.x < p.M) {
       int nq = (p.N - blockIdx.x * W + 3) / 4;
       if (nq > QW) nq = QW;
       float a = 0.f, q = 0.f;
@@ -677,8 +685,8 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
         for (int r = 0; r < 16; ++r)
           for (int c = 0; c < p.gn_cg; ++c) { const float2 v = colp[r][lb * p.gn_cg + c]; a += which ? v.y : v.x; }
         const int b = mbase / p.rows_per_batch;
-        const int slab = (mbase - b * p.rows_per_batch) / GN_SLAB_ROWS;
-        const int nslab = p.rows_per_batch / GN_SLAB_ROWS;
+        const int slab = (mbase - b * p.rows_per_batch) / ROWS;
+        const int nslab = p.rows_per_batch / ROWS;
         p.gn_stats[(((size_t)b * nslab + slab) * p.gn_groups + bin) * 2 + which] = a;
       }
     }
@@ -687,6 +695,10 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
 
 // width of the split-K reducer's blocks: 80 when the fused GroupNorm bins do not divide 64 (UNet: 5 / 10 / 20 / 40 channels)
 static inline int reduce_width(const GemmArgs& a) { return (a.gn_stats && 64 % a.gn_cg != 0) ? 80 : 64; }
+// rows per block of the reducer: 64 for large outputs, 16 when there would be too few blocks to pull the partials
+static inline int reduce_rows(const GemmArgs& a) {
+  return ((int64_t)cdiv(a.N, reduce_width(a)) * cdiv(a.M, 64) >= 1024) ? 64 : 16;
+}
 static inline int tile_width(const GemmArgs& a) {
   if (a.act == ACT_GEGLU) return 128;
   static const int forced_bn = [] { const char* v = getenv("GILL_GEMM_BN"); return v ? atoi(v) : 0; }();
@@ -701,6 +713,7 @@ int gemm_row_planes(const GemmArgs& a) {
   if (a.splitk > 1) return cdiv(a.N, reduce_width(a));
   return 2 * cdiv(a.N, tile_width(a));
 }
+int gemm_gn_slab_rows(const GemmArgs& a) { return a.splitk > 1 ? reduce_rows(a) : GN_SLAB_ROWS; }
 bool gemm_fused_gn_ok(int N, int cg) {
   if (cg < 1 || N % cg != 0 || N / cg > 64) return false;
   const int bn = (N % 160 == 0) ? 160 : 128;
@@ -805,10 +818,12 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     else GILL_TRY((gemm_launch_stages<BN, 0, 0>(d, grid, stages, s)));
   }
   if (sk > 1) {
-    if (reduce_width(a) == 80)
-      hipLaunchKernelGGL(gemm_splitk_reduce_kernel<80>, dim3(cdiv(a.N, 80), cdiv(a.M, 64)), dim3(320), 0, s, d.a);
-    else
-      hipLaunchKernelGGL(gemm_splitk_reduce_kernel<64>, dim3(cdiv(a.N, 64), cdiv(a.M, 64)), dim3(256), 0, s, d.a);
+    const int rw = reduce_width(a), rr = reduce_rows(a);
+    const dim3 rg(cdiv(a.N, rw), cdiv(a.M, rr));
+    if (rw == 80 && rr == 64) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<80, 4>), rg, dim3(320), 0, s, d.a);
+    else if (rw == 80) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<80, 1>), rg, dim3(320), 0, s, d.a);
+    else if (rr == 64) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<64, 4>), rg, dim3(256), 0, s, d.a);
+    else hipLaunchKernelGGL((gemm_splitk_reduce_kernel<64, 1>), rg, dim3(256), 0, s, d.a);
     GILL_CHECK_HIP(hipGetLastError());
   }
   return 0;
@@ -839,7 +854,7 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   }
   if (a.gn_stats) {
     GILL_REQUIRE(a.out_mode != OUT_QKV && a.act != ACT_GEGLU, "fused GroupNorm statistics need the row-major epilogue");
-    GILL_REQUIRE(a.rows_per_batch % GN_SLAB_ROWS == 0 && a.gn_groups > 0 && a.gn_groups <= 64 && a.gn_cg * a.gn_groups == a.N,
+    GILL_REQUIRE(a.rows_per_batch % 64 == 0 && a.gn_groups > 0 && a.gn_groups <= 64 && a.gn_cg * a.gn_groups == a.N,
                  "fused GroupNorm statistics: rows per sample must be a multiple of 64 and bins must tile N");
     GILL_REQUIRE(gemm_fused_gn_ok(a.N, a.gn_cg) && tile_width(a) % a.gn_cg == 0,
                  "fused GroupNorm statistics: bins must not straddle output tiles");
@@ -847,7 +862,7 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   if (a.row_stats)
     GILL_REQUIRE(a.out_mode == OUT_BF16 && a.act != ACT_GEGLU, "row statistics need the bf16 row-major epilogue");
   if (a.ln_stats) {
-    GILL_REQUIRE(a.ln_planes >= 1, "folded LayerNorm: ln_planes must be >= 1");
+    GILL_REQUIRE(a.ln_planes >= 1 && a.ln_planes <= LN_MAX_PLANES, "folded LayerNorm: 1 <= ln_planes <= 20");
     GILL_REQUIRE(a.ln_colsum != nullptr && !a.conv && a.K1 == a.K, "folded LayerNorm: column sums missing / single-source plain GEMM only");
     GILL_REQUIRE(a.act == ACT_GEGLU || a.out_mode == OUT_QKV, "folded LayerNorm is implemented in the GEGLU and QKV epilogues");
     GILL_REQUIRE(a.alpha == 1.f, "folded LayerNorm: alpha must be 1");

@@ -244,8 +244,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ x2, int C2, int HW, int groups,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, int silu,
-                                                              const float* __restrict__ stats1, int nb1, int r1, int ns1,
-                                                              const float* __restrict__ stats2, int nb2, int r2, int o2, int ns2,
+                                                              const float* __restrict__ stats1, int nb1, int r1, int ns1, int bs1,
+                                                              const float* __restrict__ stats2, int nb2, int r2, int o2, int ns2, int bs2,
                                                               bf16_t* __restrict__ y, int rows, int cc) {
   // block = (slab of `rows` pixels, sample b, chunk of cc <= 256 channels).  Phase 1: fold statistics and affine into
   // per-channel (scale, shift) in LDS — one channel per thread, so the dependent loads of the prologue are paid once,
@@ -263,28 +263,29 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
   // wrote once each: stats[(b * ns + slab) * nb + bin] = {sum, sum of squares}.  stats1 covers channels [0, sc1) of the
   // (concatenated) input, stats2 the rest.  Producers use bins finer than a group so that the same sums serve this tensor's
   // own GroupNorm and the wider groups of a later skip concatenation.
-  // Phase 0: the block's bins are totalled over the slabs in slab order (fixed order: bit-reproducible), one (bin, moment)
-  // per thread with four interleaved accumulators combined in a fixed tree; totals land in LDS.
-  __shared__ float gn_tot[2][128][2];   // [statistics block][bin][moment]
-  {
-    const int t = threadIdx.x;
-    const int blk = t >> 7, bin = (t >> 1) & 63, which = t & 1;
+  // Phase 0: every (statistics block, bin, moment) of this sample is totalled over its <= GN_MAX_PARTIALS partials in a fixed
+  // order (bit-reproducible): 4 threads per total take 16 consecutive partials each (independent loads, fixed summation
+  // tree), then one of them adds the 4 segment sums in segment order.  Totals land in LDS.
+  __shared__ float gn_seg[2][128][2][4];   // [statistics block][bin][moment][segment]
+  __shared__ float gn_tot[2][128][2];      // [statistics block][bin][moment]
+  for (int item = threadIdx.x; item < 2 * 128 * 2 * 4; item += blockDim.x) {
+    const int seg = item & 3, which = (item >> 2) & 1, bin = (item >> 3) & 127, blk = item >> 10;
     const float* st = blk ? stats2 : stats1;
-    const int nb = blk ? nb2 : nb1, ns = blk ? ns2 : ns1;
-    for (int bb = bin; bb < nb; bb += 64) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      if (st) {
-        const float* src = st + ((size_t)b * ns * nb + bb) * 2 + which;
-        const size_t step = (size_t)nb * 2;
-        int sl = 0;
-        for (; sl + 4 <= ns; sl += 4) {
-          a0 += src[(size_t)sl * step]; a1 += src[(size_t)(sl + 1) * step];
-          a2 += src[(size_t)(sl + 2) * step]; a3 += src[(size_t)(sl + 3) * step];
-        }
-        for (; sl < ns; ++sl) a0 += src[(size_t)sl * step];
-      }
-      gn_tot[blk][bb][which] = (a0 + a1) + (a2 + a3);
-    }
+    const int nb = blk ? nb2 : nb1, ns = blk ? ns2 : ns1, bs = blk ? bs2 : bs1;   // bs: partials per sample in memory (>= ns)
+    if (st == nullptr || bin >= nb) continue;
+    const float* src = st + (((size_t)b * bs + seg * 16) * nb + bin) * 2 + which;
+    const size_t step = (size_t)nb * 2;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = (seg * 16 + i < ns) ? src[(size_t)i * step] : 0.f;
+    gn_seg[blk][bin][which][seg] = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+                                   (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+  }
+  __syncthreads();
+  for (int item = threadIdx.x; item < 2 * 128 * 2; item += blockDim.x) {
+    const int which = item & 1, bin = (item >> 1) & 127, blk = item >> 8;
+    const float* g4 = gn_seg[blk][bin][which];
+    if ((blk ? stats2 : stats1) != nullptr && bin < (blk ? nb2 : nb1)) gn_tot[blk][bin][which] = (g4[0] + g4[1]) + (g4[2] + g4[3]);
   }
   __syncthreads();
   for (int ch = c0 + threadIdx.x; ch < c0 + cc; ch += blockDim.x) {
@@ -355,6 +356,27 @@ int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, 
   return groupnorm_apply_launch(x1, C1, x2, C2, B, HW, groups, gamma, beta, eps, silu, y, stats, C / groups, C, nslab, nullptr, 0, 0, s);
 }
 
+// Partial counts beyond GN_MAX_PARTIALS (the VAE's 128^2 .. 512^2 maps): total them once, in slab order, IN PLACE — the sum
+// of (sample, bin, moment) replaces its slab-0 partial, which only the thread that owns that sum ever touches — and let
+// the apply kernel read one "partial" per (sample, bin).
+#define GN_MAX_PARTIALS 64
+__global__ __launch_bounds__(256) void groupnorm_total_kernel(float* __restrict__ stats, int ns, int nb) {
+  const int b = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;      // (bin, moment)
+  if (idx >= nb * 2) return;
+  float* base = stats + (size_t)b * ns * nb * 2 + idx;
+  const size_t step = (size_t)nb * 2;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+  int sl = 0;
+  for (; sl + 8 <= ns; sl += 8) {
+    a0 += base[(size_t)sl * step]; a1 += base[(size_t)(sl + 1) * step]; a2 += base[(size_t)(sl + 2) * step];
+    a3 += base[(size_t)(sl + 3) * step]; a4 += base[(size_t)(sl + 4) * step]; a5 += base[(size_t)(sl + 5) * step];
+    a6 += base[(size_t)(sl + 6) * step]; a7 += base[(size_t)(sl + 7) * step];
+  }
+  for (; sl < ns; ++sl) a0 += base[(size_t)sl * step];
+  base[0] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+}
+
 static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
 
 // Normalise from sums accumulated elsewhere (GEMM / conv epilogues): stats1 = [B][sc1 / bin1][2] over the first sc1 channels,
@@ -371,6 +393,16 @@ int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, i
                "groupnorm: group boundaries must fall on statistics bin boundaries");
   GILL_REQUIRE(sc1 == C || (stats2 != nullptr && bin2 > 0 && (C - sc1) % bin2 == 0), "groupnorm: second statistics block missing");
   GILL_REQUIRE(nslab1 >= 1 && (stats2 == nullptr || nslab2 >= 1), "groupnorm: partial counts missing");
+  int ns1 = nslab1, ns2 = nslab2;
+  if (nslab1 > GN_MAX_PARTIALS) {     // (the statistics buffers are scratch of this forward: totalling in place is fine)
+    hipLaunchKernelGGL(groupnorm_total_kernel, dim3(cdiv(2 * (sc1 / bin1), 256), B), dim3(256), 0, s, const_cast<float*>(stats1), nslab1, sc1 / bin1);
+    ns1 = 1;
+  }
+  if (stats2 && nslab2 > GN_MAX_PARTIALS) {
+    hipLaunchKernelGGL(groupnorm_total_kernel, dim3(cdiv(2 * ((C - sc1) / bin2), 256), B), dim3(256), 0, s, const_cast<float*>(stats2), nslab2, (C - sc1) / bin2);
+    ns2 = 1;
+  }
+  GILL_CHECK_HIP(hipGetLastError());
   GILL_REQUIRE(sc1 / bin1 <= 128 && (stats2 == nullptr || (C - sc1) / bin2 <= 128), "groupnorm: more than 128 statistics bins per block");
   const int cg = C / groups;   // bins_align() guarantees cg, sc1 (and the block-2 offsets) are whole numbers of bins
   // channel chunks of <= 256 (whole 8-channel vectors); slabs of 32 rows, fewer while the grid is short of ~4 blocks per CU
@@ -383,8 +415,8 @@ int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, i
   while (rows > 4 && (int64_t)cdiv(HW, rows) * B * nch < 1024) rows >>= 1;
   dim3 g2(cdiv(HW, rows), B, nch);
   hipLaunchKernelGGL(groupnorm_apply_kernel, g2, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, gamma, beta,
-                     eps, silu, stats1, sc1 / bin1, cg / bin1, nslab1, stats2, stats2 ? (C - sc1) / bin2 : 0, stats2 ? cg / bin2 : 0,
-                     stats2 ? sc1 / bin2 : 0, stats2 ? nslab2 : 0, y, rows, cc);
+                     eps, silu, stats1, sc1 / bin1, cg / bin1, ns1, nslab1, stats2, stats2 ? (C - sc1) / bin2 : 0,
+                     stats2 ? cg / bin2 : 0, stats2 ? sc1 / bin2 : 0, stats2 ? ns2 : 0, stats2 ? nslab2 : 0, y, rows, cc);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }

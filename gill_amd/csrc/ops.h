@@ -40,8 +40,9 @@ struct GemmArgs {
   // Both kinds of fused statistics are FIXED-ORDER: a producer writes each partial sum exactly once (no atomics, nothing to
   // zero), the consumer adds the partials in index order, so two runs of the same launch sequence are bit-identical.
   // fused GroupNorm statistics of the output: gn_stats[(b * nslab + slab) * gn_groups + g][2] = {sum, sum of squares} of the
-  // gn_cg channels of bin g over the 64 output rows of slab `slab` of sample b = m / rows_per_batch (nslab = rows_per_batch
-  // / GN_SLAB_ROWS; row-major epilogue only; the tile width must be a multiple of gn_cg: gemm_fused_gn_ok())
+  // gn_cg channels of bin g over the output rows of slab `slab` of sample b = m / rows_per_batch; rows per slab =
+  // gemm_gn_slab_rows() (64, or 16 when a split-K reducer with small blocks produces them), nslab = rows_per_batch / that
+  // (row-major epilogue only; the tile width must be a multiple of gn_cg: gemm_fused_gn_ok())
   float* gn_stats = nullptr; int gn_groups = 0; int gn_cg = 0;
   // LayerNorm folded into the NEXT GEMM: LN(x) W^T + b = rstd (x (g*W)^T - mean * colsum(g*W)) + (beta W^T + b).
   //  producer: row_stats[(plane * M + m)][2] = {sum, sum of squares} of the bf16-rounded outputs of row m in the columns of
@@ -57,7 +58,9 @@ struct GemmArgs {
   int stages = 0; int bn = 0;
 };
 int gemm_launch(const GemmArgs& a, hipStream_t s);
-#define GN_SLAB_ROWS 64        // rows per fused GroupNorm-statistics partial
+#define GN_SLAB_ROWS 64        // rows per fused GroupNorm-statistics partial of the in-kernel epilogue
+#define GN_SLAB_ROWS_MIN 16    // ... of the smallest producer (size statistics buffers for rows / GN_SLAB_ROWS_MIN partials)
+int gemm_gn_slab_rows(const GemmArgs& a);
 #define GEMM_MAX_ROW_PLANES(N) (((N) + 63) / 64 > 2 * (((N) + 127) / 128) ? ((N) + 63) / 64 : 2 * (((N) + 127) / 128))
 // planes of row_stats this launch writes (depends on the tile width and on split-K, both fixed by the arguments)
 int gemm_row_planes(const GemmArgs& a);

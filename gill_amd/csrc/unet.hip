@@ -60,7 +60,8 @@ struct XfW {  // Transformer2DModel with one BasicTransformerBlock
 // stats: optional slot [Bx][H*W/64][C/sbin][2] that the PRODUCING GEMM epilogue fills with this tensor's per-slab GroupNorm
 // partial sums (GemmArgs::gn_stats: written once each, added in slab order by the consumer)
 // sbin: channels per statistics bin (C/64: finer than a group, so the sums also serve the wider groups of a skip concat)
-struct Tensor { bf16_t* p = nullptr; int H = 0, W = 0, C = 0; float* stats = nullptr; int sbin = 0; };
+// nslab: partials per (sample, bin) the producer actually wrote (set when the producing GEMM is launched)
+struct Tensor { bf16_t* p = nullptr; int H = 0, W = 0, C = 0; float* stats = nullptr; int sbin = 0; int nslab = 1; };
 // row sums feeding a folded LayerNorm: [planes][rows][2], planes fixed by the producing GEMM's tiling (gemm_row_planes)
 struct RowStats { float* p = nullptr; int planes = 1; };
 
@@ -461,7 +462,7 @@ struct UNetRun {
       const int sbin = (C % 64 == 0 && C / 64 >= 2) ? C / 64 : C / m->cfg.norm_num_groups;
       if (gemm_fused_gn_ok(C, sbin)) {
         t.sbin = sbin;
-        t.stats = stats_slot((size_t)Bx * (H * W / GN_SLAB_ROWS) * (C / sbin) * 2);
+        t.stats = stats_slot((size_t)Bx * (H * W / GN_SLAB_ROWS_MIN) * (C / sbin) * 2);
       }
     }
     return t;
@@ -477,10 +478,11 @@ struct UNetRun {
     g.ws = m->splitk_ws;
     return 0;
   }
-  int gemm(GemmArgs& g, RowStats* rs = nullptr) {
+  int gemm(GemmArgs& g, RowStats* rs = nullptr, Tensor* ys = nullptr) {
     if (dry) return 0;
     pick_sk(g);
     if (rs) { g.row_stats = rs->p; rs->planes = gemm_row_planes(g); }
+    if (ys && ys->stats) ys->nslab = ys->H * ys->W / gemm_gn_slab_rows(g);
     return gemm_launch(g, s);
   }
   int gnorm(const Tensor& x1, const Tensor* x2, const NormW& n, float eps, int silu, const Tensor& y) {
@@ -494,14 +496,14 @@ struct UNetRun {
     GILL_REQUIRE(m->gn_next <= m->gn_floats, "internal: GroupNorm stats pool exhausted");
     if (ready)
       return groupnorm_apply_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, HW, m->cfg.norm_num_groups,
-                                    n.g, n.b, eps, silu, y.p, x1.stats, x1.sbin, x1.C, HW / GN_SLAB_ROWS,
-                                    x2 ? x2->stats : nullptr, x2 ? x2->sbin : 0, x2 ? HW / GN_SLAB_ROWS : 0, s);
+                                    n.g, n.b, eps, silu, y.p, x1.stats, x1.sbin, x1.C, x1.nslab,
+                                    x2 ? x2->stats : nullptr, x2 ? x2->sbin : 0, x2 ? x2->nslab : 0, s);
     return groupnorm_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, HW, m->cfg.norm_num_groups, n.g,
                             n.b, eps, silu, y.p, stats, s);
   }
   // 3x3 conv (pad 1) over x1 (++ x2): stride 1|2, optional fused nearest-2x upsample
   int conv(const Tensor& x1, const Tensor* x2, const ConvW& w, int stride, int ups, const float* rowvec, int rv_bstride,
-           const bf16_t* resid, const Tensor& y) {
+           const bf16_t* resid, Tensor& y) {
     GemmArgs g;
     g.conv = 1; g.IH = x1.H; g.IW = x1.W; g.OH = y.H; g.OW = y.W; g.Cin = w.cin; g.stride = stride; g.ups = ups;
     g.M = Bx * y.H * y.W; g.N = w.cout; g.K = 9 * w.cin;
@@ -511,16 +513,16 @@ struct UNetRun {
     g.resid = resid; g.ldr = w.cout;
     g.C = y.p; g.ldc = w.cout;
     fuse_stats(g, y);
-    return gemm(g);
+    return gemm(g, nullptr, &y);
   }
   int linear(const bf16_t* A, int lda, const bf16_t* A2, int lda2, int K1, int M, const bf16_t* W, const float* b, int N,
-             int K, const bf16_t* resid, int act, bf16_t* out, int ldc, const Tensor* ystats = nullptr,
+             int K, const bf16_t* resid, int act, bf16_t* out, int ldc, Tensor* ystats = nullptr,
              RowStats* row_stats = nullptr) {
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.K1 = K1; g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.W = W; g.bias = b;
     g.resid = resid; g.ldr = N; g.act = act; g.C = out; g.ldc = ldc;
     if (ystats) fuse_stats(g, *ystats);
-    return gemm(g, row_stats);
+    return gemm(g, row_stats, ystats);
   }
 
   // out_stats: the output feeds a single-source GroupNorm next (accumulate its sums in conv2's epilogue)
@@ -546,7 +548,7 @@ struct UNetRun {
       g.rows_per_batch = H * Wd;
       g.C = out->p; g.ldc = w.cout;
       fuse_stats(g, *out);
-      GILL_TRY(gemm(g));
+      GILL_TRY(gemm(g, nullptr, out));
     } else {
       GILL_TRY(conv(n2, nullptr, w.c2, 1, 0, nullptr, 0, x1.p, *out));
     }

@@ -27,7 +27,7 @@ struct VResW {
   bf16_t* c2f_w = nullptr; float* c2f_b = nullptr;   // conv2 with the 1x1 shortcut fused (see unet.hip)
   int cin = 0, cout = 0;
 };
-struct VTensor { bf16_t* p = nullptr; int H = 0, W = 0, C = 0; float* stats = nullptr; };
+struct VTensor { bf16_t* p = nullptr; int H = 0, W = 0, C = 0; float* stats = nullptr; int nslab = 1; };
 
 struct VArena {
   unsigned char* base = nullptr;
@@ -207,7 +207,7 @@ struct VRun {
     t.p = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)B * H * W * C);
     const int G = m->cfg.norm_num_groups;
     if (want_stats && (H * W) % GN_SLAB_ROWS == 0 && C % G == 0 && gemm_fused_gn_ok(C, C / G))
-      t.stats = stats_slot((size_t)B * (H * W / GN_SLAB_ROWS) * G * 2);
+      t.stats = stats_slot((size_t)B * (H * W / GN_SLAB_ROWS_MIN) * G * 2);
     return t;
   }
   void fuse_stats(GemmArgs& g, const VTensor& y) {
@@ -215,11 +215,12 @@ struct VRun {
     g.gn_stats = y.stats; g.gn_groups = m->cfg.norm_num_groups; g.gn_cg = y.C / m->cfg.norm_num_groups;
     g.rows_per_batch = y.H * y.W;
   }
-  int gemm(GemmArgs& g) {
+  int gemm(GemmArgs& g, VTensor* ys = nullptr) {
     if (dry) return 0;
     g.splitk = gemm_pick_splitk(g.M, g.N, g.K, g.act);
     while (g.splitk > 1 && (size_t)g.splitk * g.M * g.N > m->splitk_ws_floats) --g.splitk;
     g.ws = m->splitk_ws;
+    if (ys && ys->stats) ys->nslab = ys->H * ys->W / gemm_gn_slab_rows(g);
     return gemm_launch(g, s);
   }
   int gnorm(const VTensor& x, const NormW& n, int silu, const VTensor& y) {
@@ -229,10 +230,10 @@ struct VRun {
     if (dry) return 0;
     if (ready)
       return groupnorm_apply_launch(x.p, x.C, nullptr, 0, B, HW, G, n.g, n.b, 1e-6f, silu, y.p, stats, x.C / G, x.C,
-                                    HW / GN_SLAB_ROWS, nullptr, 0, 0, s);
+                                    x.nslab, nullptr, 0, 0, s);
     return groupnorm_launch(x.p, x.C, nullptr, 0, B, HW, G, n.g, n.b, 1e-6f, silu, y.p, stats, s);
   }
-  int conv(const VTensor& x, const ConvW& w, int ups, const bf16_t* resid, const VTensor& y) {
+  int conv(const VTensor& x, const ConvW& w, int ups, const bf16_t* resid, VTensor& y) {
     GemmArgs g;
     g.conv = 1; g.IH = x.H; g.IW = x.W; g.OH = y.H; g.OW = y.W; g.Cin = w.cin; g.stride = 1; g.ups = ups;
     g.M = B * y.H * y.W; g.N = w.cout; g.K = 9 * w.cin;
@@ -241,7 +242,7 @@ struct VRun {
     g.resid = resid; g.ldr = w.cout;
     g.C = y.p; g.ldc = w.cout;
     fuse_stats(g, y);
-    return gemm(g);
+    return gemm(g, &y);
   }
   int resnet(const VTensor& x, const VResW& w, VTensor* out, bool out_stats) {
     const int H = x.H, Wd = x.W;
@@ -263,7 +264,7 @@ struct VRun {
       g.rows_per_batch = H * Wd;
       g.C = out->p; g.ldc = w.cout;
       fuse_stats(g, *out);
-      GILL_TRY(gemm(g));
+      GILL_TRY(gemm(g, out));
     } else {
       GILL_TRY(conv(n2, w.c2, 0, x.p, *out));
     }
@@ -309,7 +310,7 @@ struct VRun {
     g3.M = M; g3.N = C; g3.K = C; g3.K1 = C; g3.A = o; g3.lda = C; g3.W = m->attn_wo; g3.bias = m->attn_bo;
     g3.resid = x.p; g3.ldr = C; g3.C = out->p; g3.ldc = C;
     fuse_stats(g3, *out);
-    GILL_TRY(gemm(g3));
+    GILL_TRY(gemm(g3, out));
     m->arena.off = mk;
     return 0;
   }
@@ -336,7 +337,7 @@ struct VRun {
       g.M = B * L * L; g.N = ctop; g.K = 64; g.K1 = 64; g.A = col; g.lda = 64; g.W = m->conv_in_w; g.bias = m->conv_in_b;
       g.C = x.p; g.ldc = ctop;
       fuse_stats(g, x);
-      GILL_TRY(gemm(g));
+      GILL_TRY(gemm(g, &x));
     }
     { VTensor y; GILL_TRY(resnet(x, m->mid_res[0], &y, true)); x = y; }
     { VTensor y; GILL_TRY(attention(x, &y, true)); x = y; }
