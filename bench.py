@@ -230,6 +230,9 @@ def main():
   ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
   ap.add_argument("--pmc-timeout", type=int, default=300)
   ap.add_argument("--child-pmc", action="store_true", help=argparse.SUPPRESS)   # the profiled child of pmc_traffic_live
+  ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, the product path) | gloo (test rigs "
+                  "where several ranks share one GPU; with --share-gpu every rank uses cuda:0)")
+  ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
   a = ap.parse_args()
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,7 +242,12 @@ def main():
     respawn_under_torchrun(a)
   if world > 1:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if a.share_gpu:
+      local = 0
+    if a.backend == "nccl":
+      dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+      dist.init_process_group(a.backend, rank=rank, world_size=world)
   assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
   if a.prompts_per_gpu <= 0:
     a.prompts_per_gpu = 4 if a.gpus == 1 else 8

@@ -146,8 +146,11 @@ __device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& 
 
 // NWV: waves per workgroup.  4 -> 128-row tile (waves 2 x 2).  2 -> 64-row tile (waves 1 x 2) for problems with so few
 // 128-row tiles that half the CUs would idle (UNet level 2-3 projections: M = 2048 / 512).
+// 8 -> 256-row tile (waves 4 x 2, one workgroup per CU): with BN = 256 a K step fetches 64 KiB for 8.4 MFLOP — half the
+// bytes per FLOP of the 128 x 160 tile, whose 36.8 KiB per 2.6 MFLOP is 89 % of the 64 B/clk a CU can pull from L2 at the
+// MFMA peak — for the wide plain GEMMs (GEGLU, QKV) with enough 256 x 256 tiles to fill the chip.
 template <int NWV, int BN, int CONV, int EPI, int STAGES>
-__global__ __launch_bounds__(NWV * 64, 2) void gemm_kernel(const GemmDev d) {
+__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const GemmDev d) {
   constexpr int BM = NWV * 32;
   constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -699,7 +702,20 @@ static inline int reduce_width(const GemmArgs& a) { return (a.gn_stats && 64 % a
 static inline int reduce_rows(const GemmArgs& a) {
   return ((int64_t)cdiv(a.N, reduce_width(a)) * cdiv(a.M, 64) >= 1024) ? 64 : 16;
 }
+// 256 x 256 tiles (8 waves, one workgroup per CU) for plain GEMMs without split-K / fused GroupNorm statistics.  OFF by
+// default: measured on the UNet's wide GEMMs (profiles/r02_big_tile.md) the level-0 GEGLU went 94 -> 100 us and the level-0 QKV
+// 46.6 -> 48.3 us — those kernels are bound by their epilogues (GELU / head scatter: VALU and stores), not by operand
+// fetch, and one workgroup per CU has nothing to hide an epilogue behind.  GILL_GEMM_BIG = 1 turns it on where legal
+// (2 = only where the output holds >= 256 such tiles and N wastes < 15 %).
+static inline bool big_tile(const GemmArgs& a) {
+  static const int forced = [] { const char* v = getenv("GILL_GEMM_BIG"); return v ? atoi(v) : 0; }();
+  if (forced <= 0 || a.conv || a.splitk > 1 || a.gn_stats || a.N < 256 || a.M < 256 || (a.stages == 3)) return false;
+  const int tn = cdiv(a.N, 256);
+  if (forced == 1) return true;
+  return (int64_t)cdiv(a.M, 256) * tn >= 256 && tn * 256 * 100 <= a.N * 115;
+}
 static inline int tile_width(const GemmArgs& a) {
+  if (big_tile(a)) return 256;
   if (a.act == ACT_GEGLU) return 128;
   static const int forced_bn = [] { const char* v = getenv("GILL_GEMM_BN"); return v ? atoi(v) : 0; }();
   int bn = a.bn;
@@ -755,11 +771,15 @@ static int gemm_launch_inst(const GemmDev& d, dim3 grid, hipStream_t s) {
 // d.nwv = 2 selects the 64-row tile (plain GEMMs, 2-deep ring, no split-K)
 template <int BN, int CONV, int EPI>
 static int gemm_launch_stages(const GemmDev& d, dim3 grid, int stages, hipStream_t s) {
-  if constexpr (CONV == 0 && EPI != 2) {
-    if (d.nwv == 2) return gemm_launch_inst<2, BN, CONV, EPI, 2>(d, grid, s);
+  if constexpr (BN == 256) {
+    return gemm_launch_inst<8, BN, CONV, EPI, 2>(d, grid, s);
+  } else {
+    if constexpr (CONV == 0 && EPI != 2) {
+      if (d.nwv == 2) return gemm_launch_inst<2, BN, CONV, EPI, 2>(d, grid, s);
+    }
+    if (stages == 3) return gemm_launch_inst<4, BN, CONV, EPI, 3>(d, grid, s);
+    return gemm_launch_inst<4, BN, CONV, EPI, 2>(d, grid, s);
   }
-  if (stages == 3) return gemm_launch_inst<4, BN, CONV, EPI, 3>(d, grid, s);
-  return gemm_launch_inst<4, BN, CONV, EPI, 2>(d, grid, s);
 }
 
 // tuning knobs (tests / tools): GILL_GEMM_STAGES = 2|3 forces the ring depth, GILL_GEMM_BN = 128|160 the tile width
@@ -789,6 +809,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   if (!a.conv && sk == 1 && stages == 2 && (int64_t)cdiv(a.M, 128) * d.tiles_n < 300 && a.M > 64) d.nwv = 2;   // measured: < 300 +0.3 %, < 520 -3 % end to end
   if (forced_bm == 128) d.nwv = 4;
   if (forced_bm == 64 && !a.conv && sk == 1 && stages == 2) d.nwv = 2;
+  if (BN == 256) d.nwv = 8;
   const int tiles_m = cdiv(a.M, d.nwv * 32);
   // Short-K GEMMs with many N tiles (GEGLU, QKV: K = 320..1280, 6..80 N tiles) spend most of a tile's life in the first-load
   // latency and the epilogue.  Let one workgroup walk `npw` N tiles back to back instead: the ring is staged across tile
@@ -796,14 +817,19 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   d.npw = 1;
   static const int npw_off = env_int("GILL_GEMM_NPW_OFF");
   if (!a.conv && sk == 1 && stages == 2 && !a.gn_stats && d.tiles_n >= 2 && !npw_off) {
-    int groups = cdiv(512, tiles_m);
+    int groups = cdiv(BN == 256 ? 256 : 512, tiles_m);   // ~2 workgroups per CU (one for the 8-wave tile)
     if (groups < 1) groups = 1;
     if (groups > d.tiles_n) groups = d.tiles_n;
     d.npw = cdiv(d.tiles_n, groups);
   }
   d.groups_n = cdiv(d.tiles_n, d.npw);
   dim3 grid(tiles_m * d.groups_n, sk, 1);
-  if (a.conv) {
+  if constexpr (BN == 256) {   // plain, unsplit GEMMs only (big_tile())
+    if (a.act == ACT_GEGLU) GILL_TRY((gemm_launch_stages<BN, 0, 1>(d, grid, stages, s)));
+    else if (a.out_mode == OUT_QKV) GILL_TRY((gemm_launch_stages<BN, 0, 3>(d, grid, stages, s)));
+    else GILL_TRY((gemm_launch_stages<BN, 0, 0>(d, grid, stages, s)));
+    return 0;
+  } else if (a.conv) {
     if (a.ups) {
       if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 2, 2>(d, grid, stages, s)));
       else GILL_TRY((gemm_launch_stages<BN, 2, 0>(d, grid, stages, s)));
@@ -873,10 +899,12 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   }
   if (a.act == ACT_GEGLU) {
     GILL_REQUIRE(a.N % 128 == 0 && a.out_mode == OUT_BF16, "GEGLU needs N % 128 == 0 and bf16 row-major output");
+    if (tile_width(a) == 256) return gemm_launch_bn<256>(a, s);
     return gemm_launch_bn<128>(a, s);
   }
   if (a.out_mode == OUT_QKV) GILL_REQUIRE(a.dp % 4 == 0 && a.heads > 0 && a.ntok > 0, "bad QKV scatter geometry");
   const int bn = tile_width(a);
+  if (bn == 256) return gemm_launch_bn<256>(a, s);
   if (bn == 160) return gemm_launch_bn<160>(a, s);
   return gemm_launch_bn<128>(a, s);
 }

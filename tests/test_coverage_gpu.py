@@ -385,3 +385,22 @@ def test_gather_rows_rccl(n_total):
     p.join(60)
   for _, rows in res:
     assert rows == [float(i) for i in range(n_total)]
+
+
+def test_bench_two_ranks_share_one_gpu_gloo(cuda):
+  """bench.py's multi-rank path end to end with real kernels: `python bench.py --gpus 2` self-spawns two ranks under
+  torch.distributed.run (127.0.0.1); they shard 2 x 2 prompts, run the whole hot path, all-gather the latents and print ONE json
+  line.  Both ranks share cuda:0 here and talk gloo (RCCL refuses two ranks on one device); on an N-GPU node the same code runs
+  with backend nccl, one rank per GPU."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--small",
+                      "--prompts-per-gpu", "2", "--infer-steps", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pmc"],
+                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
+  assert r.returncode == 0, r.stderr.decode()[-2000:]
+  lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+  assert len(lines) == 1, r.stdout.decode()[-2000:]
+  rec = json.loads(lines[0])
+  assert rec["n_gpus"] == 2 and rec["config"]["prompts_per_gpu"] == 2 and rec["scaling"] == "weak"
+  assert rec["output_check"]["max_rel_l2_vs_first_step"] == 0.0 and rec["value"] > 0
