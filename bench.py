@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 UNET_TFLOP_PER_SAMPLE_FORWARD = 0.8032   # 401.6 GMAC, SD-1.5, 64x64 latents
+UNET_TFLOP_SD21_768 = 2.149              # 1074.6 GMAC, SD-2.1-768, 96x96 latents (--config c4)
 PEAK_BF16_TFLOPS = 2500.0                # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 REL_STEP_TOL = 1e-6                      # rel-L2 of a step's final latents vs the first timed step's: same inputs every step and
                                          # fixed-order reductions everywhere, so the steps are bit-identical (0 expected)
@@ -81,7 +82,7 @@ def shapes_of(builder_name, cfg):
   return shapes
 
 
-def build_model(dev, opt_cfg, unet_cfg, max_prompts):
+def build_model(dev, opt_cfg, unet_cfg, max_prompts, vae_cfg=None):
   from types import SimpleNamespace
   from gill_amd import synth
   from gill_amd.models import GILL
@@ -90,17 +91,18 @@ def build_model(dev, opt_cfg, unet_cfg, max_prompts):
   opt_sd = gpu_state_dict(lambda c, meta: shapes_of("opt_state_dict", c), opt_cfg, dev, 0)
   unet_sd = gpu_state_dict(lambda c, meta: shapes_of("unet_state_dict", c), unet_cfg, dev, 1)
   uncond = synth.uncond_context(unet_cfg.ctx_len, unet_cfg.cross_attention_dim, 0)
-  vae_cfg = synth.VAEConfig.sd15()
+  vae_cfg = vae_cfg or synth.VAEConfig.sd15()
   vae_sd = gpu_state_dict(lambda c, meta: shapes_of("vae_decoder_state_dict", c), vae_cfg, dev, 3)
   pipe = GillSDPipeline(unet_sd, unet_cfg, uncond, dev, max_batch=2 * min(8, max_prompts), vae_state=vae_sd, vae_cfg=vae_cfg)
   del unet_sd, vae_sd
   name = "facebook/opt-6.7b" if opt_cfg.hidden_size == 4096 else "facebook/opt-125m"
   args = SimpleNamespace(freeze_lm=True, freeze_vm=True, opt_version=name, visual_encoder="openai/clip-vit-large-patch14",
-                         n_visual_tokens=4, ret_emb_dim=256, gen_emb_dim=768, text_emb_layers=[-1], text_fc_mode="gill_mapper",
+                         n_visual_tokens=4, ret_emb_dim=256, gen_emb_dim=unet_cfg.cross_attention_dim, text_emb_layers=[-1], text_fc_mode="gill_mapper",
                          ret_text_fc_mode="linear", num_tokens=8, num_clip_tokens=77, retrieval_token_idx=synth.IMG_TOKEN_IDS,
                          gen_token_idx=synth.IMG_TOKEN_IDS, opt_state_dict=opt_sd)
   g = GILL(tok, args, load_sd=True, sd_pipe=pipe)
-  msd = gpu_state_dict(lambda c, meta: shapes_of("mapper_state_dict", c), synth.MapperConfig(in_dim=opt_cfg.hidden_size), dev, 2)
+  msd = gpu_state_dict(lambda c, meta: shapes_of("mapper_state_dict", c),
+                       synth.MapperConfig(in_dim=opt_cfg.hidden_size, out_dim=unet_cfg.cross_attention_dim), dev, 2)
   g.model.gen_text_hidden_fcs[0].load_state_dict({k: v.float().cpu() for k, v in msd.items()}, strict=True)
   g = g.eval().bfloat16().cuda(dev)
   return g
@@ -226,6 +228,8 @@ def main():
   ap.add_argument("--infer-steps", type=int, default=50)
   ap.add_argument("--prompt-len", type=int, default=24)
   ap.add_argument("--small", action="store_true", help="opt-125m shapes (debug only; not the benchmark config)")
+  ap.add_argument("--config", default="c2", choices=["c2", "c4"], help="c2 (default): BASELINE configs[1]/[2], SD-1.5 UNet 512x512; "
+                  "c4: configs[3], SD-2.1-768 UNet (1024-d context, head dim 64, v-prediction, 96x96 latents) + gen_emb_dim=1024 mapper")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
   ap.add_argument("--pmc-timeout", type=int, default=300)
@@ -256,9 +260,12 @@ def main():
 
   from gill_amd import synth
   opt_cfg = synth.OptConfig.opt_125m() if a.small else synth.OptConfig.opt_6_7b()
-  unet_cfg = synth.UNetConfig.sd15()
+  unet_cfg = synth.UNetConfig.sd21_768() if a.config == "c4" else synth.UNetConfig.sd15()
+  vae_cfg = synth.VAEConfig(latent_size=unet_cfg.sample_size)
+  tflop_fwd = UNET_TFLOP_SD21_768 if a.config == "c4" else UNET_TFLOP_PER_SAMPLE_FORWARD
+  side = 8 * unet_cfg.sample_size
   P = a.prompts_per_gpu
-  g = build_model(dev, opt_cfg, unet_cfg, P)
+  g = build_model(dev, opt_cfg, unet_cfg, P, vae_cfg)
   ids = synth.synthetic_prompt_ids(P * world, a.prompt_len, seed=0)[:, :a.prompt_len]   # [IMG] ids are appended by generate_images
   lat0 = synth.initial_latents(P * world, 4, unet_cfg.sample_size, seed=1337).to(dev)
 
@@ -318,7 +325,7 @@ def main():
   table, ok = [], True
   for i, (lat, img) in enumerate(kept):
     shape_ok = tuple(lat.shape) == (P * world, 4, unet_cfg.sample_size, unet_cfg.sample_size) and \
-        tuple(img.shape) == (P, 512, 512, 3) and img.dtype == torch.uint8
+        tuple(img.shape) == (P, side, side, 3) and img.dtype == torch.uint8
     lat = lat.float()
     n_bad = int((~torch.isfinite(lat)).sum().item())
     rel = float(((lat - ref_lat).norm() / ref_lat.norm()).item()) if n_bad == 0 else float("nan")
@@ -347,33 +354,38 @@ def main():
     unet_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev["t"]) / max(1, len(ev["t"]))   # per sd_pipe call (<= 8 prompts)
     vae_ms = sum(e0.elapsed_time(e1) for e0, e1 in vae_ev) / max(1, len(vae_ev))
     per_call = min(P, 8)                                                               # gen_max_bs = 8 chunks (models.py:726)
-    flop_per_call = UNET_TFLOP_PER_SAMPLE_FORWARD * 2 * (a.infer_steps + 1) * per_call
+    flop_per_call = tflop_fwd * 2 * (a.infer_steps + 1) * per_call
     achieved = flop_per_call / (unet_ms * 1e-3)
     traffic, traffic_detail = (None, "skipped (--no-pmc or N > 1)")
-    if world == 1 and not a.no_pmc and not a.small:
+    if world == 1 and not a.no_pmc and not a.small and a.config == "c2":
       del kept
       traffic, traffic_detail = pmc_traffic_live(a)
     cfg_name = "configs[1]" if (world == 1 and P == 4) else ("configs[2]" if P == 8 else "custom")
+    unet_name = "SD-1.5 UNet"
+    metric = "512x512 images/sec/node, OPT-6.7B+SD1.5 50-step"
+    if a.config == "c4":
+      cfg_name, unet_name = "configs[3]", "SD-2.1-768 UNet (outside the reference: needs the gen_emb_dim=1024 mapper variant)"
+      metric = "768x768 images/sec/node, OPT-6.7B+SD2.1-768 50-step (BASELINE configs[3]; not the headline metric)"
     rec = {
-      "metric": "512x512 images/sec/node, OPT-6.7B+SD1.5 50-step", "value": value, "unit": "images/s",
+      "metric": metric, "value": value, "unit": "images/s",
       "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-      "config": {"workload": f"BASELINE {cfg_name}: {'opt-125m' if a.small else 'opt-6.7b'} + GILLMapper + SD-1.5 UNet + VAE decoder "
+      "config": {"workload": f"BASELINE {cfg_name}: {'opt-125m' if a.small else 'opt-6.7b'} + GILLMapper + {unet_name} + VAE decoder "
                              f"(random-init weights of the exact shapes), {P} prompts/GPU x {world} GPU = batch {P * world}, prompt "
                              f"{a.prompt_len}+8 [IMG] tokens, {a.infer_steps} PLMS steps ({a.infer_steps + 1} UNet calls, CFG 7.5, UNet batch "
-                             f"{2 * per_call}), final latents all-gathered, then VAE decode of the local shard to uint8 512x512 "
+                             f"{2 * per_call}), final latents all-gathered, then VAE decode of the local shard to uint8 {side}x{side} "
                              f"({vae_ms:.1f} ms per {P} images)", "parallelism": f"dp{world}", "prompts_per_gpu": P},
       "output_check": {"steps_checked": len(table), "max_rel_l2_vs_first_step": max_rel, "tolerance": REL_STEP_TOL, "all_finite": True},
       "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                    "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                    "traffic_unit": "GB of HBM traffic per step (all hot-path kernels of the step; live rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes)",
                    "traffic_detail": traffic_detail,
-                   "kernel": "SD-1.5 UNet denoise loop (gill_sd_denoise: MFMA GEMM/implicit-conv + flash attention kernels)",
+                   "kernel": f"{unet_name.split(' (')[0]} denoise loop (gill_sd_denoise: MFMA GEMM/implicit-conv + flash attention kernels)",
                    "algorithmic_tflop_per_launch": flop_per_call, "avg_launch_ms": unet_ms},
     }
-    if world == 1 and not a.small:
+    if world == 1 and not a.small and a.config == "c2":
       rec["roofline_kernels"] = kernel_rooflines(dev)
-    if not a.no_cpu_baseline and world == 1:
+    if not a.no_cpu_baseline and world == 1 and a.config == "c2":
       rec["cpu_baseline"] = cpu_baseline(a.infer_steps)
     else:
       rec["cpu_baseline"] = None

@@ -115,5 +115,8 @@ class TextFcLayer(nn.Module):
       outputs = y.to(x.dtype) if x.dtype != torch.float32 else y
     else:
       raise NotImplementedError(f"TextFcLayer mode {self.mode!r}")
-    assert outputs.shape[1] == 1 or (outputs.shape[1] * outputs.shape[2] == self.num_output_tokens * 768), (outputs.shape, self.num_output_tokens)
+    # layers.py:52 hard-codes the SD-1.x width 768; a mapper built with another out_dim (gen_emb_dim = 1024: the SD-2.x variant
+    # main.py:253 anticipates, BASELINE configs[3]) is checked against its own width
+    width = 768 if self.out_dim in (256, 768) else self.out_dim
+    assert outputs.shape[1] == 1 or (outputs.shape[1] * outputs.shape[2] == self.num_output_tokens * width), (outputs.shape, self.num_output_tokens)
     return outputs  # (N, T, D)
