@@ -58,6 +58,7 @@ class GillSDPipeline:
     self._h = h
     self._vae = None
     self.vae_cfg = None
+    self.safety_checker = None          # GillSafetyChecker (custom_sd.py:375-383), loaded by from_pretrained when its files exist
     if vae_state is not None:
       self.load_vae(vae_state, vae_cfg or VAEConfig(latent_size=cfg.sample_size))
 
@@ -139,7 +140,18 @@ class GillSDPipeline:
                           block_out_channels=tuple(vc["block_out_channels"]), layers_per_block=vc["layers_per_block"],
                           norm_num_groups=vc["norm_num_groups"], latent_size=cfg.sample_size)   # scaling 0.18215: custom_sd.py:387
       vae_sd = load_file(os.path.join(vdir, "diffusion_pytorch_model.safetensors"))
-    return cls(sd, cfg, uncond_embeds, device, max_batch, vae_state=vae_sd, vae_cfg=vae_cfg)
+    pipe = cls(sd, cfg, uncond_embeds, device, max_batch, vae_state=vae_sd, vae_cfg=vae_cfg)
+    sdir = os.path.join(model_dir, "safety_checker")
+    if os.path.exists(os.path.join(sdir, "model.safetensors")):     # the reference's from_pretrained loads it by default
+      from .safety import GillSafetyChecker
+      from .synth import ClipConfig
+      with open(os.path.join(sdir, "config.json")) as f:
+        vc = json.load(f).get("vision_config", {})
+      ccfg = ClipConfig(image_size=vc.get("image_size", 224), patch_size=vc.get("patch_size", 14), hidden_size=vc.get("hidden_size", 1024),
+                        num_layers=vc.get("num_hidden_layers", 24), num_heads=vc.get("num_attention_heads", 16),
+                        intermediate_size=vc.get("intermediate_size", 4096))
+      pipe.safety_checker = GillSafetyChecker(load_file(os.path.join(sdir, "model.safetensors")), ccfg, pipe.device, max_batch=max(1, max_batch // 2))
+    return pipe
 
   def to(self, device):   # the reference chains .to("cuda")
     assert torch.device(device).type == "cuda"
@@ -225,14 +237,16 @@ class GillSDPipeline:
     with torch.cuda.device(self.device):
       N.check(N.lib().gill_sd_denoise(self._h, N.ptr(cond), N.ptr(uncond), int(uncond.shape[0]), N.ptr(lat0), B,
                                       int(num_inference_steps), float(guidance_scale), N.ptr(out), N.current_stream()))
-    if output_type == "pil":      # custom_sd.py:654-661 (the safety checker is not part of this path)
+    has_nsfw = None
+    if output_type in ("pil", "np"):      # custom_sd.py:654-661: decode_latents -> run_safety_checker -> numpy_to_pil
       from PIL import Image
       u8 = self.decode_latents(out, as_uint8=True).cpu().numpy()
-      out = [Image.fromarray(im) for im in u8]
-    elif output_type == "np":
-      out = self.decode_latents(out, as_uint8=True).cpu().numpy().astype("float32") / 255.0
+      if self.safety_checker is not None:
+        img01, has_nsfw = self.safety_checker(u8.astype("float32") / 255.0, [Image.fromarray(im) for im in u8])
+        u8 = (img01 * 255).round().astype("uint8")
+      out = [Image.fromarray(im) for im in u8] if output_type == "pil" else u8.astype("float32") / 255.0
     elif output_type == "pt":
       out = self.decode_latents(out, as_uint8=False)
     if not return_dict:
-      return (out, None)
-    return PipelineOutput(images=out)
+      return (out, has_nsfw)
+    return PipelineOutput(images=out, nsfw_content_detected=has_nsfw)

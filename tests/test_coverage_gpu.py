@@ -266,6 +266,16 @@ def _make_model_dir(root, D=128):
   with open(os.path.join(sd_dir, "scheduler", "scheduler_config.json"), "w") as f:
     json.dump(dict(prediction_type="epsilon"), f)
   save_file({"uncond_embeds": synth.uncond_context(77, 768, seed=73).contiguous()}, os.path.join(sd_dir, "uncond_embeds.safetensors"))
+  # safety_checker/ (the reference's from_pretrained loads it by default): tiny CLIP tower, thresholds no cosine can reach
+  os.makedirs(os.path.join(sd_dir, "safety_checker"))
+  tiny = synth.ClipConfig.tiny()
+  sc = _safety_state(tiny)
+  sc["concept_embeds_weights"], sc["special_care_embeds_weights"] = torch.full((17,), 2.0), torch.full((3,), 2.0)
+  save_file({k: v.contiguous() for k, v in sc.items()}, os.path.join(sd_dir, "safety_checker", "model.safetensors"))
+  with open(os.path.join(sd_dir, "safety_checker", "config.json"), "w") as f:
+    json.dump({"vision_config": dict(image_size=tiny.image_size, patch_size=tiny.patch_size, hidden_size=tiny.hidden_size,
+                                     num_hidden_layers=tiny.num_layers, num_attention_heads=tiny.num_heads,
+                                     intermediate_size=tiny.intermediate_size)}, f)
 
   mdir = os.path.join(root, "gill_opt")
   os.makedirs(mdir)
@@ -315,6 +325,7 @@ def test_load_gill_synthetic_model_dir_end_to_end(cuda, tmp_path, monkeypatch):
 
   g = models.load_gill(mdir, decision_model_fn=None)
   m = g.model
+  assert g.sd_pipe.safety_checker is not None and g.sd_pipe._vae is not None
   assert len(m.tokenizer) == 50274 and m.retrieval_token_idx == list(range(50266, 50274)) == m.gen_token_idx
   assert m.tokenizer.pad_token_id == m.tokenizer.eos_token_id
   w = m.input_embeddings.weight
@@ -404,3 +415,69 @@ def test_bench_two_ranks_share_one_gpu_gloo(cuda):
   rec = json.loads(lines[0])
   assert rec["n_gpus"] == 2 and rec["config"]["prompts_per_gpu"] == 2 and rec["scaling"] == "weak"
   assert rec["output_check"]["max_rel_l2_vs_first_step"] == 0.0 and rec["value"] > 0
+
+
+# ------------------------------------------------------------------------------------------------ safety checker
+def _safety_state(ccfg, proj_dim=64, seed=81):
+  sd = {"vision_model." + k: v for k, v in _bfw(synth.clip_state_dict(ccfg, seed=seed)).items()}
+  sd["visual_projection.weight"] = synth.normal("sc_proj", (proj_dim, ccfg.hidden_size), seed, std=0.1).bfloat16().float()
+  sd["concept_embeds"] = synth.normal("sc_concepts", (17, proj_dim), seed).bfloat16().float()
+  sd["special_care_embeds"] = synth.normal("sc_special", (3, proj_dim), seed).bfloat16().float()
+  return sd
+
+
+def test_safety_checker_vs_oracle(cuda):
+  """custom_sd.py:375-383 / :657: CLIP tower -> visual_projection -> cosines against 3 special-care + 17 concept embeddings ->
+  thresholds with the 0.01 special-care adjustment -> flagged images come back black.  Tiny CLIP geometry, synthetic
+  concept embeddings; thresholds are placed half way between the oracle's sorted cosines so that flags are mixed and no
+  decision sits within rounding distance of its threshold."""
+  from PIL import Image
+  from gill_amd.safety import GillSafetyChecker
+  from gill_amd.sd import GillSDPipeline
+  from oracle import safety_ref
+  ccfg = synth.ClipConfig.tiny()
+  sd = _safety_state(ccfg)
+  rng = np.random.RandomState(5)
+  pils = [Image.fromarray(rng.randint(0, 256, (48, 40, 3), dtype=np.uint8)) for _ in range(6)]
+  proc = GillSafetyChecker.__new__(GillSafetyChecker)          # (only for the pre-processing object)
+  from gill_amd.utils import ClipImageProcessor
+  fe = ClipImageProcessor(ccfg.image_size, ccfg.image_size)
+  px = torch.cat([fe(im).pixel_values for im in pils], 0)
+  _, special, cos = safety_ref.safety_check({**sd, "concept_embeds_weights": torch.zeros(17), "special_care_embeds_weights": torch.zeros(3)},
+                                            px, ccfg.num_heads, ccfg.patch_size)
+  # thresholds: per concept the midpoint between the 3rd and 4th largest cosine over the 6 images (=> 3 of 6 exceed each
+  # concept's threshold before the adjustment); special-care thresholds at the median likewise
+  def mid(col):
+    v = torch.sort(col, descending=True).values
+    return float((v[2] + v[3]) / 2)
+  sd["concept_embeds_weights"] = torch.tensor([mid(cos[:, c]) + 0.25 for c in range(17)])     # +0.25: most concepts quiet ...
+  sd["concept_embeds_weights"][4] = mid(cos[:, 4])                                            # ... one concept live
+  sd["special_care_embeds_weights"] = torch.tensor([mid(special[:, c]) for c in range(3)])
+  want, special, cos = safety_ref.safety_check(sd, px, ccfg.num_heads, ccfg.patch_size)
+  margin = min((cos[:, 4] - sd["concept_embeds_weights"][4]).abs().min().item(), 1.0)
+  assert any(want) and not all(want) and margin > 2e-3, (want, margin)
+  chk = GillSafetyChecker(sd, ccfg, cuda, max_batch=4)        # 6 images through a 4-image handle: two chunks
+  got_cos = chk.cosines(px)
+  ref_cos = torch.cat([special, cos], 1).numpy()
+  assert np.abs(got_cos - ref_cos).max() < 2e-2, np.abs(got_cos - ref_cos).max()             # bf16 tower vs fp32 oracle
+  imgs = np.stack([np.asarray(im.resize((32, 32)), dtype=np.float32) / 255.0 for im in pils])
+  out, flags = chk(imgs, pils)
+  assert flags == want
+  for i, bad in enumerate(flags):
+    assert (out[i] == 0).all() if bad else np.array_equal(out[i], imgs[i])
+  # inside the pipeline: output_type="pil" / "np" run decode -> checker; "latent" does not
+  cfg, usd, uncond, pipe = _tiny_pipe(cuda)
+  vcfg = synth.VAEConfig.tiny(16)
+  pipe.load_vae(_bfw(synth.vae_decoder_state_dict(vcfg, seed=5)), vcfg)
+  always = dict(sd)
+  always["concept_embeds_weights"] = torch.full((17,), -2.0)   # every cosine exceeds -2: everything is flagged
+  pipe.safety_checker = GillSafetyChecker(always, ccfg, cuda, max_batch=4)
+  cond = synth.normal("sc_cond", (2, 77, cfg.cross_attention_dim), 4).bfloat16().float()
+  lat0 = synth.initial_latents(2, 4, 16, seed=7)
+  r = pipe(prompt_embeds=cond, latents=lat0, num_inference_steps=3, output_type="np")
+  assert r.nsfw_content_detected == [True, True] and float(np.abs(r.images).max()) == 0.0
+  r = pipe(prompt_embeds=cond, latents=lat0, num_inference_steps=3, output_type="latent")
+  assert r.nsfw_content_detected is None and float(r.images.abs().max()) > 0
+  pipe.safety_checker = None
+  r = pipe(prompt_embeds=cond, latents=lat0, num_inference_steps=3, output_type="np")
+  assert r.nsfw_content_detected is None and float(np.abs(r.images).max()) > 0
