@@ -74,7 +74,11 @@ extern "C" int gill_op_conv3x3(const void* x1, int C1, const void* x2, int C2, c
   const int Cin = C1 + C2;
   DevBuf wr, ws;
   GILL_TRY(wr.alloc(sizeof(bf16_t) * (size_t)Cout * 9 * Cin));
-  GILL_TRY(conv_weight_relayout_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wr.p, s));
+  // K order as the engines choose it (GILL_CONV_KORDER = 0 | 1 forces tap-major / chunk-major for tests and tools)
+  static const int korder = [] { const char* v = getenv("GILL_CONV_KORDER"); return v ? atoi(v) : -1; }();
+  const int chunked = korder >= 0 ? korder : (conv_k_chunked(IH * IW, Cin) ? 1 : 0);
+  if (chunked) GILL_TRY(conv_weight_relayout_chunked_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wr.p, s));
+  else GILL_TRY(conv_weight_relayout_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wr.p, s));
   GemmArgs g;
   g.conv = 1;
   g.IH = IH; g.IW = IW; g.Cin = Cin; g.stride = stride; g.ups = ups;
@@ -82,7 +86,7 @@ extern "C" int gill_op_conv3x3(const void* x1, int C1, const void* x2, int C2, c
   else { g.OH = (IH + 2 - 3) / stride + 1; g.OW = (IW + 2 - 3) / stride + 1; }
   g.M = B * g.OH * g.OW; g.N = Cout; g.K = 9 * Cin;
   g.A = (const bf16_t*)x1; g.A2 = (const bf16_t*)x2; g.K1 = C1;
-  g.W = (const bf16_t*)wr.p;
+  g.W = (const bf16_t*)wr.p; g.k_chunked = chunked;
   g.bias = bias;
   g.rowvec = rowvec; g.rows_per_batch = g.OH * g.OW; g.rowvec_bstride = Cout;
   g.resid = resid; g.ldr = Cout;

@@ -434,6 +434,27 @@ __global__ __launch_bounds__(256) void conv_w_relayout_kernel(const void* w, int
     out[i] = f2bf(load_as_f32(w, dtype, ((int64_t)o * Cin + c) * 9 + tap));
   }
 }
+// OIHW (3x3) -> [O][chunk][tap][64]: the K order of the implicit-GEMM convolution (gemm.hip, CONV != 0).  K walks the input
+// channels in 64-wide chunks and, inside a chunk, the 9 taps: the 9 shifted reads of one chunk's input patch are 9
+// consecutive K steps, so they hit a patch that is still in L2 (tap-major order re-streamed the whole input 9 times from the
+// fabric once a sample's activations outgrew the 4 MiB L2: 398 MB fetched for a 42 MB input at level 0, Cin = 640).
+__global__ __launch_bounds__(256) void conv_w_relayout_chunked_kernel(const void* w, int dtype, int Cout, int Cin, bf16_t* out) {
+  const int64_t n = (int64_t)Cout * Cin * 9;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % ((int64_t)Cin * 9));
+    const int o = (int)(i / ((int64_t)Cin * 9));
+    const int chunk = k / 576, r = k - chunk * 576;
+    const int tap = r >> 6, c = chunk * 64 + (r & 63);
+    out[i] = f2bf(load_as_f32(w, dtype, ((int64_t)o * Cin + c) * 9 + tap));
+  }
+}
+int conv_weight_relayout_chunked_launch(const void* w, int dtype, int Cout, int Cin, bf16_t* out, hipStream_t s) {
+  GILL_REQUIRE(dtype >= 0 && dtype <= 2, "unsupported source dtype");
+  GILL_REQUIRE(Cin % 64 == 0, "implicit-GEMM conv: input channels must be a multiple of 64");
+  hipLaunchKernelGGL(conv_w_relayout_chunked_kernel, dim3(grid_for((int64_t)Cout * Cin * 9)), dim3(256), 0, s, w, dtype, Cout, Cin, out);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 int conv_weight_relayout_launch(const void* w, int dtype, int Cout, int Cin, bf16_t* out, hipStream_t s) {
   GILL_REQUIRE(dtype >= 0 && dtype <= 2, "unsupported source dtype");
   hipLaunchKernelGGL(conv_w_relayout_kernel, dim3(grid_for((int64_t)Cout * Cin * 9)), dim3(256), 0, s, w, dtype, Cout, Cin, out);

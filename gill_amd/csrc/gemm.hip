@@ -54,6 +54,8 @@ struct GemmDev {
   int npw;           // N tiles one workgroup walks back to back (plain GEMM, no split-K): the LDS ring keeps flowing
   int groups_n;      // cdiv(tiles_n, npw)
   int nwv;           // waves per workgroup: 4 (128-row tile) or 2 (64-row tile)
+  int n_major;       // 1: consecutive tile ids walk M first (an XCD's contiguous id range = a range of N tiles over every M tile)
+  int tiles_m;
 };
 
 __device__ __noinline__ float gelu_erf_call(float v) { return gelu_erf(v); }  // keeps erff out of the unrolled epilogue
@@ -172,8 +174,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
     const int xcd = bid & 7, idx = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int gn = tile % d.groups_n;
-  const int tm = tile / d.groups_n;
+  // weight-heavy problems (N*K > the activation matrix: UNet levels 2-3, the LM) give each XCD a range of N tiles, so every
+  // weight is fetched into one L2 only; activation-heavy ones a range of M tiles (N tiles and 3x3 halo rows share the L2)
+  const int gn = d.n_major ? tile / d.tiles_m : tile % d.groups_n;
+  const int tm = d.n_major ? tile % d.tiles_m : tile / d.groups_n;
   const int m0 = tm * BM;
   const int tn_first = gn * d.npw;
   const int ntl = (d.tiles_n - tn_first < d.npw) ? d.tiles_n - tn_first : d.npw;   // N tiles of this workgroup
@@ -267,9 +271,17 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
         for (int i = 0; i < 4; ++i) a_ptr[i] = xs + (size_t)a_pc[i] * cx + kc;
         seg_left = ((fx ? p.KX1 : p.KX) - ke) / BK;
       } else {
-        // all wave-uniform: tap, source tensor, channel offset, tap displacement
-        const int tap = k0 / p.Cin;
-        const int c0 = k0 - tap * p.Cin;
+        // all wave-uniform: chunk, tap, source tensor, channel offset, tap displacement.  K order: 64-channel chunks, the 9
+        // taps inside a chunk (see conv_weight_relayout_chunked_launch): one (chunk, tap) per K step
+        int tap, c0;
+        if (p.k_chunked) {
+          const int chunk = k0 / (9 * BK);
+          tap = (k0 - chunk * (9 * BK)) / BK;
+          c0 = chunk * BK;
+        } else {
+          tap = k0 / p.Cin;
+          c0 = k0 - tap * p.Cin;
+        }
         const int ty = tap / 3;
         const int dy = ty - 1, dx = tap - ty * 3 - 1;
         const int need = (dy < 0 ? 1 : (dy > 0 ? 2 : 0)) | (dx < 0 ? 4 : (dx > 0 ? 8 : 0));
@@ -290,7 +302,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
           const bool ok = (a_fl[i] & need) == need;
           a_ptr[i] = ok ? src + off : zero_lane;
         }
-        seg_left = ((first ? p.K1 : p.Cin) - c0) / BK;
+        seg_left = p.k_chunked ? 1 : ((first ? p.K1 : p.Cin) - c0) / BK;
       }
     }
   };
@@ -823,6 +835,13 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     d.npw = cdiv(d.tiles_n, groups);
   }
   d.groups_n = cdiv(d.tiles_n, d.npw);
+  d.tiles_m = tiles_m;
+  {
+    static const int forced_nm = [] { const char* v = getenv("GILL_GEMM_NMAJOR"); return v ? atoi(v) : -1; }();
+    const int64_t wel = (int64_t)a.N * a.K;
+    const int64_t ael = (int64_t)a.M * (a.conv ? a.Cin + a.KX : a.K);
+    d.n_major = (forced_nm >= 0) ? forced_nm : (wel > ael && d.groups_n >= 8 ? 1 : 0);
+  }
   dim3 grid(tiles_m * d.groups_n, sk, 1);
   if constexpr (BN == 256) {   // plain, unsplit GEMMs only (big_tile())
     if (a.act == ACT_GEGLU) GILL_TRY((gemm_launch_stages<BN, 0, 1>(d, grid, stages, s)));

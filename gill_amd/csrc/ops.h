@@ -21,7 +21,13 @@ struct GemmArgs {
   // conv only: extra plain K segment appended after the 9 taps (a fused 1x1 conv of the tensor X1 ++ X2 at the same
   // pixel, i.e. ResnetBlock2D's conv_shortcut): KX channels in total, the first KX1 from X1
   const bf16_t* X1 = nullptr; const bf16_t* X2 = nullptr; int KX = 0, KX1 = 0;
-  const bf16_t* W = nullptr;  // [N][K], K contiguous (conv: k = tap*Cin + c, then the KX shortcut channels)
+  const bf16_t* W = nullptr;  // [N][K], K contiguous.  conv: k = tap*Cin + c (conv_weight_relayout_launch), or with k_chunked
+                              // k = (c / 64) * 576 + tap * 64 + c % 64 — 64-channel chunks, the 9 taps inside a chunk
+                              // (conv_weight_relayout_chunked_launch) — then the KX shortcut channels
+  int k_chunked = 0;          // conv: the chunk-major K order.  The 9 shifted reads of a chunk's input patch are then 9
+                              // consecutive K steps and hit L2; worth it (conv_k_chunked()) once a sample's input no longer
+                              // fits the 4 MiB L2 next to the weights: tap-major re-streams it from the fabric 9 times
+                              // (398 MB fetched for a 42 MB input at 64x64x640), but pays one address set-up per K step
   float alpha = 1.f;
   const float* bias = nullptr;
   const float* rowvec = nullptr; int rows_per_batch = 1; int rowvec_bstride = 0;  // + rowvec[(m/rows_per_batch)*bstride + n]
@@ -78,6 +84,7 @@ struct AttnArgs {
   float scale = 1.f;    // informative only: Q must arrive pre-multiplied by scale * log2(e) (GemmArgs::qscale)
   int causal = 0;
   int kv_bstride_zero = 0;  // 1: K/Vt have a single batch entry shared by every b (learned queries etc.)
+  int xcd_map = 1;          // 1: all query tiles of a (sample, head) on one XCD (set by the launcher; GILL_ATT_XCD=0 turns it off)
 };
 int attention_launch(const AttnArgs& a, hipStream_t s);
 
@@ -161,7 +168,11 @@ int sd_stage_launch(const SdLoopArgs& a, hipStream_t s);
 int plms_step_launch(const SdLoopArgs& a, hipStream_t s);
 
 // weight re-layout helpers (run once at engine creation)
-int conv_weight_relayout_launch(const void* w, int dtype, int Cout, int Cin, bf16_t* out /*[Cout][9][Cin]*/, hipStream_t s);
+int conv_weight_relayout_launch(const void* w, int dtype, int Cout, int Cin, bf16_t* out /*[Cout][9][Cin]*/, hipStream_t s);   // conv_in / conv_out
+// measured (tools/one_op.py, 8 samples): 64x64x640 -> 320: 150.9 -> 145.4 us, 64x64x960: 207.6 -> 193.7 us; but 64x64x320: 75.9 ->
+// 77.8 us and the split-K level-1 convs lose 14-18 % (32x32x1280 -> 640: 166.8 -> 193.2 us)
+static inline bool conv_k_chunked(int HW, int Cin) { return HW >= 4096 && (int64_t)HW * Cin * 2 > (int64_t)4 << 20; }
+int conv_weight_relayout_chunked_launch(const void* w, int dtype, int Cout, int Cin, bf16_t* out /*[Cout][Cin/64][9][64]*/, hipStream_t s);   // GemmArgs::conv
 int convert_to_bf16_launch(const void* src, int dtype, int64_t n, bf16_t* dst, hipStream_t s);
 int convert_to_f32_launch(const void* src, int dtype, int64_t n, float* dst, hipStream_t s);
 // copy rows of a [rows][cols] matrix into a (possibly wider/padded/permuted) destination:

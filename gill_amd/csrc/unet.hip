@@ -27,7 +27,7 @@
 
 namespace {
 
-struct ConvW { bf16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; };
+struct ConvW { bf16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; int chunked = 0; /* K order: GemmArgs::k_chunked */ };
 struct LinW { bf16_t* w = nullptr; float* b = nullptr; int out = 0, in = 0; };
 struct NormW { float* g = nullptr; float* b = nullptr; int c = 0; };
 
@@ -193,12 +193,14 @@ struct Loader {
     GILL_TRY(load_f32(wt, pool, p + ".weight", c, &n->g, s));
     return load_f32(wt, pool, p + ".bias", c, &n->b, s);
   }
-  int conv3(const std::string& p, int cin, int cout, ConvW* c) {
-    c->cin = cin; c->cout = cout;
+  // hw: pixels per sample of the conv's INPUT (decides the K order, see GemmArgs::k_chunked)
+  int conv3(const std::string& p, int cin, int cout, int hw, ConvW* c) {
+    c->cin = cin; c->cout = cout; c->chunked = conv_k_chunked(hw, cin) ? 1 : 0;
     const gill_tensor* t;
     GILL_TRY(wt.get(p + ".weight", (int64_t)cout * cin * 9, &t));
     GILL_TRY(pool.alloc(&c->w, (size_t)cout * cin * 9, false));
-    GILL_TRY(conv_weight_relayout_launch(t->data, t->dtype, cout, cin, c->w, s));
+    if (c->chunked) GILL_TRY(conv_weight_relayout_chunked_launch(t->data, t->dtype, cout, cin, c->w, s));
+    else GILL_TRY(conv_weight_relayout_launch(t->data, t->dtype, cout, cin, c->w, s));
     return load_f32(wt, pool, p + ".bias", cout, &c->b, s);
   }
   int lin(const std::string& p, int out, int in, LinW* l, bool bias = true) {
@@ -215,13 +217,13 @@ struct Loader {
     GILL_CHECK_HIP(hipGetLastError());
     return 0;
   }
-  int resnet(const std::string& p, int cin, int cout, int temb_dim, int* temb_off, bf16_t* temb_w, float* temb_b,
+  int resnet(const std::string& p, int cin, int cout, int hw, int temb_dim, int* temb_off, bf16_t* temb_w, float* temb_b,
              ResnetW* r) {
     r->cin = cin; r->cout = cout;
     GILL_TRY(norm(p + ".norm1", cin, &r->n1));
-    GILL_TRY(conv3(p + ".conv1", cin, cout, &r->c1));
+    GILL_TRY(conv3(p + ".conv1", cin, cout, hw, &r->c1));
     GILL_TRY(norm(p + ".norm2", cout, &r->n2));
-    GILL_TRY(conv3(p + ".conv2", cout, cout, &r->c2));
+    GILL_TRY(conv3(p + ".conv2", cout, cout, hw, &r->c2));
     r->has_sc = (cin != cout);
     if (r->has_sc) {
       GILL_TRY(lin(p + ".conv_shortcut", cout, cin, &r->sc));
@@ -376,26 +378,27 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
   if ((rc = L.lin("time_embedding.linear_2", temb_dim, temb_dim, &m->te2))) return fail(rc);
 
   int layer_id = 0;
+  auto hw_of = [&](int level) { const int side = cfg->sample_size >> level; return side * side; };   // pixels per sample
   // down blocks: CrossAttnDownBlock2D x3, DownBlock2D
   for (int i = 0; i < 4; ++i) {
     const int cin = (i == 0) ? ch[0] : ch[i - 1];
     const std::string p = "down_blocks." + std::to_string(i);
     m->down_res[i].resize(2);
     for (int j = 0; j < 2; ++j)
-      if ((rc = L.resnet(p + ".resnets." + std::to_string(j), j == 0 ? cin : ch[i], ch[i], temb_dim, &temb_off,
+      if ((rc = L.resnet(p + ".resnets." + std::to_string(j), j == 0 ? cin : ch[i], ch[i], hw_of(i), temb_dim, &temb_off,
                          m->temb_proj_w, m->temb_proj_b, &m->down_res[i][j]))) return fail(rc);
     if (i < 3) {
       m->down_xf[i].resize(2);
       for (int j = 0; j < 2; ++j)
         if ((rc = L.xf(p + ".attentions." + std::to_string(j), ch[i], Hl[i], ctxd, layer_id++, &m->down_xf[i][j]))) return fail(rc);
-      if ((rc = L.conv3(p + ".downsamplers.0.conv", ch[i], ch[i], &m->down_ds[i]))) return fail(rc);
+      if ((rc = L.conv3(p + ".downsamplers.0.conv", ch[i], ch[i], hw_of(i), &m->down_ds[i]))) return fail(rc);
     }
   }
   // mid
-  if ((rc = L.resnet("mid_block.resnets.0", ch[3], ch[3], temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[0])))
+  if ((rc = L.resnet("mid_block.resnets.0", ch[3], ch[3], hw_of(3), temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[0])))
     return fail(rc);
   if ((rc = L.xf("mid_block.attentions.0", ch[3], Hl[3], ctxd, layer_id++, &m->mid_xf))) return fail(rc);
-  if ((rc = L.resnet("mid_block.resnets.1", ch[3], ch[3], temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[1])))
+  if ((rc = L.resnet("mid_block.resnets.1", ch[3], ch[3], hw_of(3), temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[1])))
     return fail(rc);
   // up blocks: UpBlock2D, CrossAttnUpBlock2D x3
   const int rev[4] = {ch[3], ch[2], ch[1], ch[0]};
@@ -408,7 +411,7 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
     for (int j = 0; j < 3; ++j) {
       const int skip = (j == 2) ? inc : outc;
       const int rin = (j == 0) ? prev : outc;
-      if ((rc = L.resnet(p + ".resnets." + std::to_string(j), rin + skip, outc, temb_dim, &temb_off, m->temb_proj_w,
+      if ((rc = L.resnet(p + ".resnets." + std::to_string(j), rin + skip, outc, hw_of(3 - i), temb_dim, &temb_off, m->temb_proj_w,
                          m->temb_proj_b, &m->up_res[i][j]))) return fail(rc);
     }
     if (i > 0) {
@@ -417,7 +420,7 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
         if ((rc = L.xf(p + ".attentions." + std::to_string(j), outc, Hl[3 - i], ctxd, layer_id++, &m->up_xf[i][j]))) return fail(rc);
     }
     if (i < 3)
-      if ((rc = L.conv3(p + ".upsamplers.0.conv", outc, outc, &m->up_us[i]))) return fail(rc);
+      if ((rc = L.conv3(p + ".upsamplers.0.conv", outc, outc, hw_of(3 - i), &m->up_us[i]))) return fail(rc);
   }
   m->n_xf = layer_id;
   if (temb_off != temb_total) { gill_set_error("internal: temb table width mismatch"); return fail(-4); }
@@ -508,7 +511,7 @@ struct UNetRun {
     g.conv = 1; g.IH = x1.H; g.IW = x1.W; g.OH = y.H; g.OW = y.W; g.Cin = w.cin; g.stride = stride; g.ups = ups;
     g.M = Bx * y.H * y.W; g.N = w.cout; g.K = 9 * w.cin;
     g.A = x1.p; g.A2 = x2 ? x2->p : nullptr; g.K1 = x1.C;
-    g.W = w.w; g.bias = w.b;
+    g.W = w.w; g.bias = w.b; g.k_chunked = w.chunked;
     g.rowvec = rowvec; g.rows_per_batch = y.H * y.W; g.rowvec_bstride = rv_bstride;
     g.resid = resid; g.ldr = w.cout;
     g.C = y.p; g.ldc = w.cout;
@@ -544,7 +547,7 @@ struct UNetRun {
       g.M = Bx * H * Wd; g.N = w.cout; g.K = 9 * w.cout + w.cin;
       g.A = n2.p; g.K1 = w.cout;
       g.X1 = x1.p; g.X2 = x2 ? x2->p : nullptr; g.KX = w.cin; g.KX1 = x1.C;
-      g.W = w.c2f_w; g.bias = w.c2f_b;
+      g.W = w.c2f_w; g.bias = w.c2f_b; g.k_chunked = w.c2.chunked;
       g.rows_per_batch = H * Wd;
       g.C = out->p; g.ldc = w.cout;
       fuse_stats(g, *out);

@@ -150,7 +150,7 @@ struct VLoader {
     const gill_tensor* t;
     GILL_TRY(wt.get(p + ".weight", (int64_t)cout * cin * 9, &t));
     GILL_TRY(pool.alloc(&c->w, (size_t)cout * cin * 9, false));
-    GILL_TRY(conv_weight_relayout_launch(t->data, t->dtype, cout, cin, c->w, s));
+    GILL_TRY(conv_weight_relayout_launch(t->data, t->dtype, cout, cin, c->w, s));   // tap-major K order (k_chunked = 0)
     return load_f32(wt, pool, p + ".bias", cout, &c->b, s);
   }
   int resnet(const std::string& p, int cin, int cout, VResW* r) {

@@ -47,10 +47,29 @@ __global__ __launch_bounds__(256, OCC) void k_gemm(const bf16_t* __restrict__ A,
     w_ptr[i] = W + (size_t)(n0 + row) * K + ((lane & 7) ^ sw) * 8;
   }
   int kcol = 0;
+  int patch_step = 0;
   auto issue = [&](int buf) {
     if (!LOADS) return;
     bf16_t* As = smem + buf * BUF;
-    bf16_t* Bs = As + A_ELEMS;
+    bf16_t* Bs = LOADS == 2 ? smem + buf * B_ELEMS : As + A_ELEMS;     // patch mode: LDS = [W ring 2 x 20 KiB | patch 36 KiB]
+    if (LOADS == 2) {
+      // LDS-resident input patch: the A side is fetched once per 9 K steps (one 64-channel chunk of a (2+2) x (64+2) pixel
+      // patch = 264 pixels = 33 KiB: 9 wave-instructions per wave), the W side every step
+      if (patch_step == 0) {
+        bf16_t* P = smem + 2 * B_ELEMS;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[i & 3] + (i >> 2) * 8 * KW),
+                                           (__attribute__((address_space(3))) void*)(P + (i * 4 + w) * 8 * BK), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_ptr[i] += BK;
+        if (++kcol == KW / BK) { kcol = 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a_ptr[i] -= KW; }
+      }
+      if (++patch_step == 9) patch_step = 0;
+    } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[i],
@@ -60,6 +79,7 @@ __global__ __launch_bounds__(256, OCC) void k_gemm(const bf16_t* __restrict__ A,
     if (++kcol == KW / BK) { kcol = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) a_ptr[i] -= KW; }
+    }
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
@@ -81,8 +101,8 @@ __global__ __launch_bounds__(256, OCC) void k_gemm(const bf16_t* __restrict__ A,
     for (int it = 0; it < nsteps; ++it) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (BARR) __builtin_amdgcn_s_barrier();
-      const bf16_t* As = smem + buf * BUF;
-      const bf16_t* Bs = As + A_ELEMS;
+      const bf16_t* As = LOADS == 2 ? smem + 2 * B_ELEMS + ((it % 9) / 3) * 66 * BK + ((it % 9) % 3) * BK : smem + buf * BUF;
+      const bf16_t* Bs = LOADS == 2 ? smem + buf * B_ELEMS : As + A_ELEMS;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         if (LDSR) {
@@ -381,7 +401,7 @@ template <int MODE, int LOADS, int LDSR, int BARR, int OCC>
 void run(const bf16_t* A, const bf16_t* W, float* C, int M, int N, int K, const char* what) {
   constexpr int smem = 2 * (BM * BK + BN * BK) * 2;
   hipFuncSetAttribute((const void*)k_gemm<MODE, LOADS, LDSR, BARR, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-  int lds = OCC == 1 ? 100 * 1024 : smem;
+  int lds = OCC == 1 ? 100 * 1024 : (LOADS == 2 ? 2 * BN * BK * 2 + 36 * 1024 : smem);
   int grid = (M / BM) * (N / BN);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) k_gemm<MODE, LOADS, LDSR, BARR, OCC><<<grid, 256, lds>>>(A, W, C, M, N, K);
@@ -414,6 +434,7 @@ int main(int argc, char** argv) {
   }
   printf("M=%d N=%d K=%d, %d tiles\n", M, N, K, (M / BM) * (N / BN));
   run<0, 1, 1, 1, 2>(A, W, C, M, N, K, "16x16x32 full");
+  run<0, 2, 1, 1, 2>(A, W, C, M, N, K, "16x16x32 A patch once per 9 steps");
   run<0, 0, 1, 1, 2>(A, W, C, M, N, K, "16x16x32 no global loads");
   run<0, 0, 1, 0, 2>(A, W, C, M, N, K, "16x16x32 no loads, no barrier");
   run<0, 0, 0, 0, 2>(A, W, C, M, N, K, "16x16x32 pure MFMA");
