@@ -13,7 +13,7 @@ from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgill_amd.so")
+LIB_PATH = os.environ.get("GILL_AMD_LIB") or os.path.join(_HERE, "libgill_amd.so")   # GILL_AMD_LIB: A/B runs of two builds
 
 
 class GillNativeError(RuntimeError):

@@ -268,11 +268,18 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
   // tree), then one of them adds the 4 segment sums in segment order.  Totals land in LDS.
   __shared__ float gn_seg[2][128][2][4];   // [statistics block][bin][moment][segment]
   __shared__ float gn_tot[2][128][2];      // [statistics block][bin][moment]
+  // (only the bins this block's channel chunk [c0, c0 + cc) needs: groups g_lo .. g_hi - 1)
+  const int g_lo = c0 / cg, g_hi = (c0 + cc - 1) / cg + 1;
+  int lo1 = g_lo * r1, hi1 = g_hi * r1;
+  if (hi1 > nb1) hi1 = nb1;
+  int lo2 = g_lo * r2 - o2, hi2 = g_hi * r2 - o2;
+  if (lo2 < 0) lo2 = 0;
+  if (hi2 > nb2) hi2 = nb2;
   for (int item = threadIdx.x; item < 2 * 128 * 2 * 4; item += blockDim.x) {
     const int seg = item & 3, which = (item >> 2) & 1, bin = (item >> 3) & 127, blk = item >> 10;
     const float* st = blk ? stats2 : stats1;
     const int nb = blk ? nb2 : nb1, ns = blk ? ns2 : ns1, bs = blk ? bs2 : bs1;   // bs: partials per sample in memory (>= ns)
-    if (st == nullptr || bin >= nb) continue;
+    if (st == nullptr || bin < (blk ? lo2 : lo1) || bin >= (blk ? hi2 : hi1)) continue;
     const float* src = st + (((size_t)b * bs + seg * 16) * nb + bin) * 2 + which;
     const size_t step = (size_t)nb * 2;
     float v[16];
@@ -285,7 +292,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
   for (int item = threadIdx.x; item < 2 * 128 * 2; item += blockDim.x) {
     const int which = item & 1, bin = (item >> 1) & 127, blk = item >> 8;
     const float* g4 = gn_seg[blk][bin][which];
-    if ((blk ? stats2 : stats1) != nullptr && bin < (blk ? nb2 : nb1)) gn_tot[blk][bin][which] = (g4[0] + g4[1]) + (g4[2] + g4[3]);
+    if ((blk ? stats2 : stats1) != nullptr && bin >= (blk ? lo2 : lo1) && bin < (blk ? hi2 : hi1))
+      gn_tot[blk][bin][which] = (g4[0] + g4[1]) + (g4[2] + g4[3]);
   }
   __syncthreads();
   for (int ch = c0 + threadIdx.x; ch < c0 + cc; ch += blockDim.x) {
