@@ -54,6 +54,7 @@ struct GemmDev {
   int npw;           // N tiles one workgroup walks back to back (plain GEMM, no split-K): the LDS ring keeps flowing
   int groups_n;      // cdiv(tiles_n, npw)
   int nwv;           // waves per workgroup: 4 (128-row tile) or 2 (64-row tile)
+  int kt;            // K elements per ring stage: 64 (2-deep ring) or 32 (4-deep ring, 128-row tiles only)
   int n_major;       // 1: consecutive tile ids walk M first (an XCD's contiguous id range = a range of N tiles over every M tile)
   int tiles_m;
 };
@@ -151,15 +152,27 @@ __device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& 
 // 8 -> 256-row tile (waves 4 x 2, one workgroup per CU): with BN = 256 a K step fetches 64 KiB for 8.4 MFLOP — half the
 // bytes per FLOP of the 128 x 160 tile, whose 36.8 KiB per 2.6 MFLOP is 89 % of the 64 B/clk a CU can pull from L2 at the
 // MFMA peak — for the wide plain GEMMs (GEGLU, QKV) with enough 256 x 256 tiles to fill the chip.
-template <int NWV, int BN, int CONV, int EPI, int STAGES>
+// KT: K elements per ring stage (64 | 32).  With a 2-deep ring the loads of stage t+1 can only be issued after the barrier of
+// stage t (their buffer is free from there): prefetch distance = one stage.  KT = 32 cuts the SAME 73.7 KiB of LDS into a
+// 4-deep ring of half-size stages: loads are issued three stages (1.5 K steps of 64) ahead and waited for with counted
+// s_waitcnt vmcnt(N), at the price of a barrier per 32-wide stage.  Measured: that price is higher than the gain (the
+// launcher keeps KT = 64 unless GILL_GEMM_KT = 32).
+template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const GemmDev d) {
   constexpr int BM = NWV * 32;
   constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
+  static_assert(KT == 64 || KT == 32, "stage depth");
+  constexpr int LPR = KT / 8;          // lanes (16-B chunks) per tile row
+  constexpr int RPI = 64 / LPR;        // tile rows one 1-KiB LDS-DMA wave-instruction covers (8 | 16)
+  constexpr int KK = KT / 32;          // 32-wide MFMA k steps per stage
+  // XOR swizzle of the 16-B chunk index by the row: conflict-free ds_read_b128 of 16 consecutive rows
+  // (KT = 64: rows are 128 B, chunk ^= row & 7; KT = 32: rows are 64 B, chunk ^= (row >> 2) & 3)
+#define SWZ(row) (KT == 64 ? ((row) & 7) : (((row) >> 2) & 3))
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
-  // layout: [buf][A tile BM*64 | B tile BN*64]
-  constexpr int A_ELEMS = BM * BK;
-  constexpr int B_ELEMS = BN * BK;
+  // layout: [buf][A tile BM*KT | B tile BN*KT]
+  constexpr int A_ELEMS = BM * KT;
+  constexpr int B_ELEMS = BN * KT;
   constexpr int BUF_ELEMS = A_ELEMS + B_ELEMS;
 
   const GemmArgs& p = d.a;
@@ -188,16 +201,18 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
   if (kt_end > d.ksteps) kt_end = d.ksteps;
   const int nsteps = kt_end - kt_beg;
 
-  // ---- per-lane staging geometry: instruction i of wave w fills tile rows (i*4+w)*8 .. +8
-  const int srow = lane >> 3;                 // row within the 8-row group == (tile row & 7)
-  const int schunk = (lane & 7) ^ srow;       // logical 16-B chunk this lane fetches (source-side swizzle)
+  // ---- per-lane staging geometry: instruction i of wave w fills tile rows (i*NWV+w)*RPI .. +RPI
+  const int srow = lane / LPR;                            // row within the instruction's row group
+  const int schunk = (lane % LPR) ^ SWZ(srow);            // logical 16-B chunk this lane fetches (source-side swizzle;
+                                                          // group bases are multiples of RPI, so SWZ(row) == SWZ(srow))
 
   // A rows (4 per lane): element offset of the row start (plain) / of the centre input pixel (conv) in each source,
   // plus conv flag bits {1: dy=-1 in range, 2: dy=+1, 4: dx=-1, 8: dx=+1, 16: oy odd, 32: ox odd}
-  int a_off1[4], a_off2[4], a_fl[4], a_pc[4];
+  constexpr int AI = BM / (RPI * NWV);                    // A instructions per wave per stage (4 | 2)
+  int a_off1[AI], a_off2[AI], a_fl[AI], a_pc[AI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int row = (i * NWV + w) * 8 + srow;
+  for (int i = 0; i < AI; ++i) {
+    int row = (i * NWV + w) * RPI + srow;
     int m = m0 + row;
     if (m > p.M - 1) m = p.M - 1;
     a_fl[i] = 0; a_pc[i] = 0;
@@ -228,19 +243,22 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
       a_off2[i] = pc * (p.Cin - p.K1) + schunk * 8;
     }
   }
-  // W rows: BN/32 instructions per wave (BN rows / 8 rows per instr / 4 waves)
-  constexpr int WG = BN / 8;                    // 8-row groups of the W tile
-  static_assert(WG % NWV == 0, "every wave stages the same number of W row groups");
-  constexpr int WI = WG / NWV;
+  // W rows: groups of RPI rows dealt to the waves round robin; a wave's last instruction may have no group (KT = 32, BN = 160:
+  // 10 groups over 4 waves)
+  constexpr int WG = BN / RPI;                  // row groups of the W tile
+  constexpr int WI = (WG + NWV - 1) / NWV;      // W instructions per wave per stage (the last one predicated)
+  static_assert(BN % RPI == 0, "whole row groups");
+  const bool w_last_ok = ((WI - 1) * NWV + w) < WG;       // wave-uniform
+  const int lw = AI + (w_last_ok ? WI : WI - 1);           // LDS-DMA instructions this wave issues per stage
   const bf16_t* w_ptr[WI];
   int n_issue = n0;        // first column of the N tile being staged
   auto w_setup = [&]() {
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      int row = (i * NWV + w) * 8 + srow;
+      int row = (i * NWV + w) * RPI + srow;
       int n = n_issue + row;
       if (n > p.N - 1) n = p.N - 1;
-      w_ptr[i] = p.W + (size_t)n * p.K + schunk * 8 + kt_beg * BK;
+      w_ptr[i] = p.W + (size_t)n * p.K + schunk * 8 + kt_beg * KT;
     }
   };
   w_setup();
@@ -248,7 +266,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
 
   // ---- K-step addressing is incremental: K is walked in (tap, source) segments inside which every row pointer just
   // advances by 64 elements; seg_setup() (wave-uniform control flow, once per segment) recomputes the 4 A row pointers
-  const bf16_t* a_ptr[4];
+  const bf16_t* a_ptr[AI];
   int seg_left = 0;
   auto seg_setup = [&](int k0) {
     if constexpr (CONV == 0) {
@@ -256,8 +274,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
       const bf16_t* src = first ? p.A : p.A2;
       const int kk = first ? k0 : k0 - p.K1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a_ptr[i] = src + (first ? a_off1[i] : a_off2[i]) + kk;
-      seg_left = ((first ? p.K1 : p.K) - k0) / BK;
+      for (int i = 0; i < AI; ++i) a_ptr[i] = src + (first ? a_off1[i] : a_off2[i]) + kk;
+      seg_left = ((first ? p.K1 : p.K) - k0) / KT;
     } else {
       if (CONV == 1 && k0 >= 9 * p.Cin) {
         // fused 1x1 "conv_shortcut" segment: K continues over the channels of the raw block input X1 (++ X2) at the
@@ -268,16 +286,17 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
         const int cx = fx ? p.KX1 : (p.KX - p.KX1);
         const int kc = (fx ? ke : ke - p.KX1) + schunk * 8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a_ptr[i] = xs + (size_t)a_pc[i] * cx + kc;
-        seg_left = ((fx ? p.KX1 : p.KX) - ke) / BK;
+        for (int i = 0; i < AI; ++i) a_ptr[i] = xs + (size_t)a_pc[i] * cx + kc;
+        seg_left = ((fx ? p.KX1 : p.KX) - ke) / KT;
       } else {
         // all wave-uniform: chunk, tap, source tensor, channel offset, tap displacement.  K order: 64-channel chunks, the 9
         // taps inside a chunk (see conv_weight_relayout_chunked_launch): one (chunk, tap) per K step
         int tap, c0;
         if (p.k_chunked) {
           const int chunk = k0 / (9 * BK);
-          tap = (k0 - chunk * (9 * BK)) / BK;
-          c0 = chunk * BK;
+          const int r = k0 - chunk * (9 * BK);
+          tap = r / BK;
+          c0 = chunk * BK + (r - tap * BK);
         } else {
           tap = k0 / p.Cin;
           c0 = k0 - tap * p.Cin;
@@ -291,7 +310,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
         const int cc = first ? c0 : c0 - p.K1;
         const int delta = (dy * p.IW + dx) * cs + cc;   // used when CONV == 1
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AI; ++i) {
           int off = (first ? a_off1[i] : a_off2[i]);
           if constexpr (CONV == 2) {
             const int ddy = (dy + ((a_fl[i] >> 4) & 1)) >> 1, ddx = (dx + ((a_fl[i] >> 5) & 1)) >> 1;
@@ -302,16 +321,16 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
           const bool ok = (a_fl[i] & need) == need;
           a_ptr[i] = ok ? src + off : zero_lane;
         }
-        seg_left = p.k_chunked ? 1 : ((first ? p.K1 : p.Cin) - c0) / BK;
+        seg_left = p.k_chunked ? 1 : ((first ? p.K1 : p.Cin) - c0) / KT;
       }
     }
   };
-  int k_issue = kt_beg * BK;     // K coordinate of the next step to stage
+  int k_issue = kt_beg * KT;     // K coordinate of the next step to stage
   int steps_in_tile = 0;
   auto issue = [&](int buf) {
     if (steps_in_tile == nsteps) {   // next N tile of this workgroup: same A rows from the top, next BN weight rows
       steps_in_tile = 0;
-      k_issue = kt_beg * BK;
+      k_issue = kt_beg * KT;
       seg_left = 0;
       n_issue += BN;
       w_setup();
@@ -322,20 +341,21 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
     bf16_t* As = smem + buf * BUF_ELEMS;
     bf16_t* Bs = As + A_ELEMS;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      bf16_t* l = As + (i * NWV + w) * 8 * BK;
+    for (int i = 0; i < AI; ++i) {
+      bf16_t* l = As + (i * NWV + w) * RPI * KT;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[i],
                                        (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-      a_ptr[i] += BK;
+      a_ptr[i] += KT;
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      bf16_t* l = Bs + (i * NWV + w) * 8 * BK;
+      if (i == WI - 1 && !w_last_ok) break;
+      bf16_t* l = Bs + (i * NWV + w) * RPI * KT;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
                                        (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-      w_ptr[i] += BK;
+      w_ptr[i] += KT;
     }
-    k_issue += BK;
+    k_issue += KT;
   };
 
   f32x4 acc[4][NT];
@@ -344,8 +364,22 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
   const int frow = lane & 15;       // fragment row within a 16-row sub-tile
   const int fkc = lane >> 4;        // 16-B k chunk within the 32-wide MFMA k step
 
-  constexpr int LOADS = 4 + WI;     // LDS-DMA instructions one wave issues per K step
-  static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+  static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+  // s_waitcnt vmcnt(n) with a run-time n (its operand is an immediate): n = (stages still allowed in flight) * lw <= 15
+  auto wait_vm = [](int n) {
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // (waiting for more than needed is always correct)
+    }
+  };
   const int total_steps = ntl * nsteps;
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
@@ -369,39 +403,54 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int it = 0; it < nsteps; ++it, ++flat) {
-    // wait for stage `flat` only: with a 3-deep ring the next stage (the youngest LOADS instructions) stays in flight
-    if (STAGES == 3 && flat + 1 < total_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // wait for stage `flat` only: the up to STAGES - 2 younger stages (lw instructions each) stay in flight
+    if constexpr (STAGES == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      int ahead = total_steps - 1 - flat;
+      if (ahead > STAGES - 2) ahead = STAGES - 2;
+      wait_vm(ahead * lw);
+    }
     __builtin_amdgcn_s_barrier();
     const bf16_t* As = smem + buf * BUF_ELEMS;
     const bf16_t* Bs = As + A_ELEMS;
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[4];
-      bf16x8 bfr[NT];
+    // Fragment reads are software-pipelined by hand: the reads of k step kk+1 are ISSUED before the MFMAs of k step kk (two
+    // fragment sets live), and sched_barriers pin that order.  Left alone, the compiler recycles one 4-register A fragment
+    // for the second k step (read -> s_waitcnt lgkmcnt(0) -> 5 MFMAs, three times over): every one of those waits exposes a
+    // full LDS round trip.
+    bf16x8 af[KK][4];
+    bf16x8 bfr[KK][NT];
+    auto frag_load = [&](int kk) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = wm * 64 + i * 16 + frow;
-        const int slot = (kk * 4 + fkc) ^ (row & 7);
-        af[i] = *reinterpret_cast<const bf16x8*>(As + row * BK + slot * 8);
+        const int slot = (kk * 4 + fkc) ^ SWZ(row);
+        af[kk][i] = *reinterpret_cast<const bf16x8*>(As + row * KT + slot * 8);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int row = wn * (BN / 2) + j * 16 + frow;
-        const int slot = (kk * 4 + fkc) ^ (row & 7);
-        bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * BK + slot * 8);
+        const int slot = (kk * 4 + fkc) ^ SWZ(row);
+        bfr[kk][j] = *reinterpret_cast<const bf16x8*>(Bs + row * KT + slot * 8);
       }
-      if (kk == 0) {
-        // stage the next tile while the first fragments are in flight from LDS (its ~30 instructions cover that latency)
-        if (flat + STAGES - 1 < total_steps) issue(buf_issue);
-        buf_issue = (buf_issue + 1 == STAGES) ? 0 : buf_issue + 1;
+    };
+    frag_load(0);
+    // stage the next tile while the first fragments are in flight from LDS (its ~30 instructions cover that latency)
+    if (flat + STAGES - 1 < total_steps) issue(buf_issue);
+    buf_issue = (buf_issue + 1 == STAGES) ? 0 : buf_issue + 1;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      if (kk + 1 < KK) {
+        __builtin_amdgcn_sched_barrier(0);
+        frag_load(kk + 1);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
     }
   }
 
@@ -602,6 +651,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
     }
   }
   }   // N tiles of this workgroup
+#undef SWZ
 }
 
 // split-K reduction + epilogue
@@ -766,16 +816,16 @@ int gemm_pick_splitk(int M, int N, int K, int act) {
   return s;
 }
 
-template <int NWV, int BN, int CONV, int EPI, int STAGES>
+template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT = BK>
 static int gemm_launch_inst(const GemmDev& d, dim3 grid, hipStream_t s) {
   static bool attr_set = false;
-  constexpr int smem = STAGES * (NWV * 32 * BK + BN * BK) * (int)sizeof(bf16_t);
+  constexpr int smem = STAGES * (NWV * 32 * KT + BN * KT) * (int)sizeof(bf16_t);
   if (!attr_set) {
-    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<NWV, BN, CONV, EPI, STAGES>,
+    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<NWV, BN, CONV, EPI, STAGES, KT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<NWV, BN, CONV, EPI, STAGES>), grid, dim3(NWV * 64), smem, s, d);
+  hipLaunchKernelGGL((gemm_kernel<NWV, BN, CONV, EPI, STAGES, KT>), grid, dim3(NWV * 64), smem, s, d);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -790,6 +840,7 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, int stages, hipStream
       if (d.nwv == 2) return gemm_launch_inst<2, BN, CONV, EPI, 2>(d, grid, s);
     }
     if (stages == 3) return gemm_launch_inst<4, BN, CONV, EPI, 3>(d, grid, s);
+    if (d.kt == 32) return gemm_launch_inst<4, BN, CONV, EPI, 4, 32>(d, grid, s);
     return gemm_launch_inst<4, BN, CONV, EPI, 2>(d, grid, s);
   }
 }
@@ -806,10 +857,8 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   d.a = a;
   d.zero = gill_zero_page();
   GILL_REQUIRE(d.zero != nullptr, "zero page unavailable");
-  d.ksteps = a.K / BK;
   const int sk = a.splitk > 1 ? a.splitk : 1;
   d.a.splitk = sk;
-  d.ksteps_per_split = cdiv(d.ksteps, sk);
   d.tiles_n = cdiv(a.N, BN);
   static const int forced = env_int("GILL_GEMM_STAGES");
   int stages = a.stages;
@@ -822,6 +871,12 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   if (forced_bm == 128) d.nwv = 4;
   if (forced_bm == 64 && !a.conv && sk == 1 && stages == 2) d.nwv = 2;
   if (BN == 256) d.nwv = 8;
+  // GILL_GEMM_KT = 32: 4-deep ring of 32-wide stages on the 128-row tiles (see the kernel's KT note).  Off by default: measured
+  // 7 % SLOWER on the denoise loop (608 -> 652 ms): the deeper prefetch does not pay for a barrier per 32-wide stage
+  static const int forced_kt = env_int("GILL_GEMM_KT");
+  d.kt = (forced_kt == 32 && d.nwv == 4 && stages == 2) ? 32 : 64;
+  d.ksteps = a.K / d.kt;
+  d.ksteps_per_split = cdiv(d.ksteps, sk);
   const int tiles_m = cdiv(a.M, d.nwv * 32);
   // Short-K GEMMs with many N tiles (GEGLU, QKV: K = 320..1280, 6..80 N tiles) spend most of a tile's life in the first-load
   // latency and the epilogue.  Let one workgroup walk `npw` N tiles back to back instead: the ring is staged across tile
