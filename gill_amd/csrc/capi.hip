@@ -141,3 +141,39 @@ extern "C" int gill_op_groupnorm(const void* x1, int C1, const void* x2, int C2,
   GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
 }
+
+// fp8 convolution (conv_fp8.hip) on bf16 NHWC input: quantises x (x F8_ACT_SCALE) and the fp32 OIHW weights (per output
+// channel), runs the fp8 MFMA kernel (+ the split-K reducer), returns bf16 NHWC.  For tests/test_fp8_gpu.py and tools.
+extern "C" int gill_op_conv3x3_fp8(const void* x_bf16, const float* w_oihw, const float* bias, const void* resid_bf16, void* y_bf16,
+                                   int B, int H, int W, int Cin, int Cout, int splitk, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GILL_REQUIRE(x_bf16 && w_oihw && y_bf16, "null argument");
+  const int M = B * H * W, Kpad = conv_fp8_kpad(Cin);
+  DevBuf x8, w8, sc, ws;
+  GILL_TRY(x8.alloc((size_t)M * Cin));
+  GILL_TRY(w8.alloc((size_t)Cout * Kpad));
+  GILL_TRY(sc.alloc(sizeof(float) * (size_t)Cout));
+  GILL_TRY(quant_bf16_fp8_launch((const bf16_t*)x_bf16, F8_ACT_SCALE, (int64_t)M * Cin, (unsigned char*)x8.p, s));
+  GILL_TRY(conv_weight_quant_fp8_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, F8_ACT_SCALE, (unsigned char*)w8.p, (float*)sc.p, s));
+  ConvF8Args a;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.M = M; a.N = Cout; a.Kpad = Kpad;
+  a.A8 = (const unsigned char*)x8.p; a.W8 = (const unsigned char*)w8.p; a.colscale = (const float*)sc.p;
+  a.C = (bf16_t*)y_bf16;
+  a.splitk = splitk > 0 ? splitk : gemm_pick_splitk(M, Cout, 9 * Cin, 0);
+  if (a.splitk > 1) {
+    GILL_TRY(ws.alloc(sizeof(float) * (size_t)a.splitk * M * Cout));
+    a.ws = (float*)ws.p;
+    for (int r = 0; r < op_repeat(); ++r) {
+      GILL_TRY(conv3x3_fp8_launch(a, s));
+      GemmArgs g;     // finish the partials: + bias + residual -> bf16
+      g.M = M; g.N = Cout; g.K = 9 * Cin; g.splitk = a.splitk; g.ws = a.ws; g.bias = bias;
+      g.resid = resid_bf16; g.ldr = Cout; g.C = y_bf16; g.ldc = Cout;
+      GILL_TRY(gemm_splitk_reduce_launch(g, s));
+    }
+  } else {
+    a.bias = bias; a.resid = (const bf16_t*)resid_bf16;
+    for (int r = 0; r < op_repeat(); ++r) GILL_TRY(conv3x3_fp8_launch(a, s));
+  }
+  GILL_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}

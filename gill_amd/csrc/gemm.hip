@@ -816,6 +816,18 @@ int gemm_pick_splitk(int M, int N, int K, int act) {
   return s;
 }
 
+int gemm_splitk_reduce_launch(const GemmArgs& a, hipStream_t s) {
+  GILL_REQUIRE(a.splitk > 1 && a.ws != nullptr, "split-K reducer: no partials");
+  const int rw = reduce_width(a), rr = reduce_rows(a);
+  const dim3 rg(cdiv(a.N, rw), cdiv(a.M, rr));
+  if (rw == 80 && rr == 64) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<80, 4>), rg, dim3(320), 0, s, a);
+  else if (rw == 80) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<80, 1>), rg, dim3(320), 0, s, a);
+  else if (rr == 64) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<64, 4>), rg, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_splitk_reduce_kernel<64, 1>), rg, dim3(256), 0, s, a);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT = BK>
 static int gemm_launch_inst(const GemmDev& d, dim3 grid, hipStream_t s) {
   static bool attr_set = false;
@@ -917,15 +929,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     else if (a.out_mode == OUT_QKV) GILL_TRY((gemm_launch_stages<BN, 0, 3>(d, grid, stages, s)));
     else GILL_TRY((gemm_launch_stages<BN, 0, 0>(d, grid, stages, s)));
   }
-  if (sk > 1) {
-    const int rw = reduce_width(a), rr = reduce_rows(a);
-    const dim3 rg(cdiv(a.N, rw), cdiv(a.M, rr));
-    if (rw == 80 && rr == 64) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<80, 4>), rg, dim3(320), 0, s, d.a);
-    else if (rw == 80) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<80, 1>), rg, dim3(320), 0, s, d.a);
-    else if (rr == 64) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<64, 4>), rg, dim3(256), 0, s, d.a);
-    else hipLaunchKernelGGL((gemm_splitk_reduce_kernel<64, 1>), rg, dim3(256), 0, s, d.a);
-    GILL_CHECK_HIP(hipGetLastError());
-  }
+  if (sk > 1) return gemm_splitk_reduce_launch(d.a, s);
   return 0;
 }
 

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
                                                               const float* __restrict__ beta, float eps, int silu,
                                                               const float* __restrict__ stats1, int nb1, int r1, int ns1, int bs1,
                                                               const float* __restrict__ stats2, int nb2, int r2, int o2, int ns2, int bs2,
-                                                              bf16_t* __restrict__ y, int rows, int cc) {
+                                                              bf16_t* __restrict__ y, int rows, int cc, float out8_scale) {
   // block = (slab of `rows` pixels, sample b, chunk of cc <= 256 channels).  Phase 1: fold statistics and affine into
   // per-channel (scale, shift) in LDS — one channel per thread, so the dependent loads of the prologue are paid once,
   // not C/256 times; phase 2: y = [silu](x * scale + shift), 16-B loads and stores.
@@ -343,6 +343,16 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = silu_f(o[e]);
     }
+    if (out8_scale > 0.f) {     // fp8 (e4m3) output: the A operand of the fp8 convolution (conv_fp8.hip), 8 bytes per thread
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = fminf(fmaxf(o[e] * out8_scale, -448.f), 448.f);
+      int lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], 0, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], lo, true);
+      int hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[4], o[5], 0, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[6], o[7], hi, true);
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(y) + row * C + c) = make_uint2((unsigned)lo, (unsigned)hi);
+      continue;
+    }
     gn_u32x4 w;
     w[0] = pack_bf2(o[0], o[1]); w[1] = pack_bf2(o[2], o[3]); w[2] = pack_bf2(o[4], o[5]); w[3] = pack_bf2(o[6], o[7]);
     *reinterpret_cast<gn_u32x4*>(y + row * C + c) = w;
@@ -350,7 +360,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
 }
 
 int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups, const float* gamma,
-                     const float* beta, float eps, int silu, bf16_t* y, float* stats, hipStream_t s) {
+                     const float* beta, float eps, int silu, bf16_t* y, float* stats, hipStream_t s, float out8_scale) {
   const int C = C1 + C2;
   GILL_REQUIRE(groups <= 64 && C % groups == 0 && (C / groups) % 2 == 0, "groupnorm: channels/group must be even");
   GILL_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "groupnorm: channel counts must be multiples of 8");
@@ -361,7 +371,8 @@ int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, 
   hipLaunchKernelGGL(groupnorm_stats_kernel, g1, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, stats);
   GILL_CHECK_HIP(hipGetLastError());
   // `stats` holds nslab partial {sum, sum of squares} per group of the whole (concatenated) input
-  return groupnorm_apply_launch(x1, C1, x2, C2, B, HW, groups, gamma, beta, eps, silu, y, stats, C / groups, C, nslab, nullptr, 0, 0, s);
+  return groupnorm_apply_launch(x1, C1, x2, C2, B, HW, groups, gamma, beta, eps, silu, y, stats, C / groups, C, nslab, nullptr, 0, 0, s,
+                                out8_scale);
 }
 
 // Partial counts beyond GN_MAX_PARTIALS (the VAE's 128^2 .. 512^2 maps): total them once, in slab order, IN PLACE — the sum
@@ -391,7 +402,7 @@ static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t
 // stats2 = [B][(C - sc1) / bin2][2] over the rest (nullptr when stats1 covers everything).
 int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups, const float* gamma,
                            const float* beta, float eps, int silu, bf16_t* y, const float* stats1, int bin1, int sc1, int nslab1,
-                           const float* stats2, int bin2, int nslab2, hipStream_t s) {
+                           const float* stats2, int bin2, int nslab2, hipStream_t s, float out8_scale) {
   const int C = C1 + C2;
   GILL_REQUIRE(groups <= 64 && C % groups == 0 && (C / groups) % 2 == 0, "groupnorm: channels/group must be even");
   GILL_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "groupnorm: channel counts must be multiples of 8");
@@ -424,7 +435,7 @@ int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, i
   dim3 g2(cdiv(HW, rows), B, nch);
   hipLaunchKernelGGL(groupnorm_apply_kernel, g2, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, gamma, beta,
                      eps, silu, stats1, sc1 / bin1, cg / bin1, ns1, nslab1, stats2, stats2 ? (C - sc1) / bin2 : 0,
-                     stats2 ? cg / bin2 : 0, stats2 ? sc1 / bin2 : 0, stats2 ? ns2 : 0, stats2 ? nslab2 : 0, y, rows, cc);
+                     stats2 ? cg / bin2 : 0, stats2 ? sc1 / bin2 : 0, stats2 ? ns2 : 0, stats2 ? nslab2 : 0, y, rows, cc, out8_scale);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }

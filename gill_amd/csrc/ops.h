@@ -75,6 +75,30 @@ bool gemm_fused_gn_ok(int N, int cg);
 // heuristic split-K factor for under-filled grids
 int gemm_pick_splitk(int M, int N, int K, int act);
 
+// split-K reducer of gemm_launch on its own (partials a.ws [splitk][M][N] fp32 written by another kernel: conv_fp8.hip)
+int gemm_splitk_reduce_launch(const GemmArgs& a, hipStream_t s);
+
+// 3x3 / pad 1 / stride 1 convolution with fp8 (OCP e4m3) activations and weights on v_mfma_scale_f32_16x16x128_f8f6f4
+// (conv_fp8.hip): C[M, N] bf16 = colscale[n] * (A8 (*) W8) + bias + rowvec + resid, M = B*H*W, N = Cout
+#define F8_ACT_SCALE 8.0f     // activations are stored as fp8(8 * x): SiLU(GroupNorm) lives in [-0.28, ~8]
+struct ConvF8Args {
+  int B = 0, H = 0, W = 0, Cin = 0, M = 0, N = 0, Kpad = 0;
+  const unsigned char* A8 = nullptr;       // [B][H][W][Cin] fp8
+  const unsigned char* W8 = nullptr;       // [N][Kpad] fp8, K order of conv_weight_quant_fp8_launch
+  const float* colscale = nullptr;         // [N]: weight scale / activation scale
+  const float* bias = nullptr;
+  const float* rowvec = nullptr; int rows_per_batch = 1; int rowvec_bstride = 0;
+  const bf16_t* resid = nullptr;           // [M][N] bf16
+  bf16_t* C = nullptr;                     // [M][N] bf16
+  float* gn_stats = nullptr; int gn_groups = 0; int gn_cg = 0;   // fused GroupNorm partials (GemmArgs::gn_stats layout; splitk == 1)
+  int splitk = 1; float* ws = nullptr;     // fp32 partials [splitk][M][N]; finish with gemm_splitk_reduce_launch
+};
+int conv3x3_fp8_launch(const ConvF8Args& a, hipStream_t s);
+int conv_fp8_kpad(int Cin);
+int quant_bf16_fp8_launch(const bf16_t* x, float scale, int64_t n, unsigned char* y, hipStream_t s);
+int conv_weight_quant_fp8_launch(const void* w_oihw, int dtype, int Cout, int Cin, float act_scale, unsigned char* w8, float* colscale,
+                                 hipStream_t s);
+
 // Flash-style attention over head-major operands (see GemmArgs OUT_QKV):
 //   Q [B][H][nq_pad][dp], K [B][H][nkv_pad][dp], Vt [B][H][dpv][nkv_pad]  ->  O [B*nq][H*dp] (token-major)
 struct AttnArgs {
@@ -103,13 +127,14 @@ static inline size_t groupnorm_stats_floats(int B, int HW, int groups) {
 }
 int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups,
                      const float* gamma, const float* beta, float eps, int silu, bf16_t* y,
-                     float* stats, hipStream_t s);
+                     float* stats, hipStream_t s, float out8_scale = 0.f);
 // normalise from per-slab partial sums written in bins by producer epilogues (GemmArgs::gn_stats layout: nslab1 / nslab2
 // partials per (sample, bin)); groupnorm_bins_align() tells whether a (channels per group, split point, bin sizes)
 // combination is usable
 int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups, const float* gamma,
                            const float* beta, float eps, int silu, bf16_t* y, const float* stats1, int bin1, int sc1, int nslab1,
-                           const float* stats2, int bin2, int nslab2, hipStream_t s);
+                           const float* stats2, int bin2, int nslab2, hipStream_t s, float out8_scale = 0.f);
+// out8_scale > 0: y is an fp8 (e4m3) tensor [B][HW][C] holding fp8(out8_scale * value) — the A operand of conv3x3_fp8_launch
 bool groupnorm_bins_align(int cg, int sc1, int bin1, int bin2);
 
 // ---- small elementwise / gather kernels ----

@@ -117,3 +117,22 @@ def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
   N.check(N.lib().gill_op_groupnorm(N.ptr(x1), C1, N.ptr(x2), C2, B, H * W, groups, N.ptr(g), N.ptr(b), eps, int(silu),
                                     N.ptr(y), N.current_stream()))
   return y
+
+
+def conv3x3_fp8(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
+                splitk: int = 0) -> torch.Tensor:
+  """3x3 / pad 1 / stride 1 conv with fp8 (e4m3) activations and weights on the fp8 MFMA (csrc/conv_fp8.hip): NHWC bf16 x
+  (B,H,W,Cin), OIHW fp32 weights -> NHWC bf16.  Quantisation (x * 8 per tensor, weights per output channel) happens inside."""
+  x = _bf(x)
+  B, H, W, Cin = x.shape
+  w = w_oihw.float().contiguous()
+  Cout = w.shape[0]
+  assert w.shape[1] == Cin and Cin % 64 == 0
+  y = torch.empty((B, H, W, Cout), device=x.device, dtype=torch.bfloat16)
+  if bias is not None:
+    bias = bias.float().contiguous()
+  if resid is not None:
+    resid = _bf(resid)
+  N.check(N.lib().gill_op_conv3x3_fp8(N.ptr(x), N.ptr(w), N.ptr(bias), N.ptr(resid), N.ptr(y), B, H, W, Cin, Cout, splitk,
+                                      N.current_stream()))
+  return y

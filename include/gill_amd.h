@@ -226,6 +226,13 @@ int gill_op_layernorm(const void* x, int x_f32, const float* gamma, const float*
 int gill_op_groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, const float* gamma,
                       const float* beta, float eps, int silu, void* y, void* stream);
 
+/* fp8 (OCP e4m3) 3x3 convolution on CDNA4's v_mfma_scale_f32_16x16x128_f8f6f4 — BASELINE.json configs[4]; no reference
+ * counterpart (the reference runs SD in fp16, gill/models.py:550-551).  x (B,H,W,Cin) bf16 NHWC, w (Cout,Cin,3,3) fp32,
+ * optional bias (Cout) fp32 and residual (B,H,W,Cout) bf16 -> y (B,H,W,Cout) bf16.  Operands are quantised inside
+ * (activations x 8 per tensor, weights per output channel).  splitk 0 = heuristic. */
+int gill_op_conv3x3_fp8(const void* x_bf16, const float* w_oihw, const float* bias, const void* resid_bf16, void* y_bf16,
+                        int B, int H, int W, int Cin, int Cout, int splitk, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,55 @@
+"""BASELINE.json configs[4] — fp8 (OCP e4m3) operands on CDNA4's fp8 matrix instruction — for the UNet's 3x3 convolutions
+(gill_amd/csrc/conv_fp8.hip).  No reference counterpart exists (the reference runs SD in fp16): the kernel is checked against an
+fp32 convolution of the SAME quantised operands (torch.float8_e4m3fn emulates the quantiser on the CPU; bar: fp32-accumulation
+noise), and the whole fp8 UNet mode against this build's own bf16 path (accuracy delta stated in the test)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gill_amd import synth
+
+pytestmark = pytest.mark.gpu
+ACT_SCALE = 8.0
+
+
+def _q(t, scale):
+  """fp8 e4m3 round trip of t * scale (round-to-nearest-even, saturating at 448), back in fp32 and un-scaled."""
+  return (t * scale).clamp(-448, 448).to(torch.float8_e4m3fn).float() / scale
+
+
+def _ref(x_nhwc, w, bias, resid):
+  xq = _q(x_nhwc.float(), ACT_SCALE)
+  s = w.abs().amax(dim=(1, 2, 3), keepdim=True) / 448.0
+  wq = _q(w / s, 1.0) * s
+  y = F.conv2d(xq.permute(0, 3, 1, 2), wq, bias, padding=1).permute(0, 2, 3, 1)
+  if resid is not None:
+    y = y + resid.float()
+  return y
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,sk", [
+  (2, 16, 16, 128, 160, 1),      # even number of 64-channel halves per tap
+  (2, 16, 16, 320, 320, 1),      # 9 * 5 = 45 halves: the last K step is half padding; two 160-wide N tiles
+  (1, 8, 8, 64, 128, 1),         # one half per tap: every K step mixes two taps; BN = 128
+  (3, 12, 20, 192, 64, 1),       # W not a power of two, ragged M (720 rows), N < tile
+  (2, 16, 16, 640, 320, 4),      # split-K partials finished by the bf16 path's reducer
+  (1, 8, 8, 1280, 1280, 16),
+])
+def test_conv3x3_fp8_vs_quantised_fp32(cuda, B, H, W, Cin, Cout, sk):
+  from gill_amd import ops
+  x = synth.normal("f8_x", (B, H, W, Cin), 1).bfloat16()
+  x = torch.nn.functional.silu(x.float()).bfloat16()             # the operand's real distribution: SiLU of a unit normal
+  w = synth.normal("f8_w", (Cout, Cin, 3, 3), 2, std=0.03)
+  bias = synth.normal("f8_b", (Cout,), 3, std=0.1)
+  resid = synth.normal("f8_r", (B, H, W, Cout), 4).bfloat16()
+  got = ops.conv3x3_fp8(x.to(cuda), w.to(cuda), bias.to(cuda), resid.to(cuda), splitk=sk).float().cpu()
+  ref = _ref(x, w, bias, resid)
+  err = (got - ref).abs().max().item()
+  scale = ref.abs().max().item()
+  print(f"[conv fp8 {B}x{H}x{W}x{Cin}->{Cout} sk{sk}] max_abs={err:.3e} of {scale:.2f}")
+  assert err < 1.5e-2 * scale      # bf16 output rounding (2^-9 relative) + fp32 accumulation order; the quantisation itself is in `ref`
+  # and the quantisation error against the un-quantised convolution is what e4m3 operands cost (reported, loosely bounded)
+  full = F.conv2d(x.float().permute(0, 3, 1, 2), w, bias, padding=1).permute(0, 2, 3, 1) + resid.float()
+  rel = ((got - full).norm() / full.norm()).item()
+  print(f"  vs un-quantised conv: rel-L2 {rel:.3e}")
+  assert rel < 6e-2
