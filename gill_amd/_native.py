@@ -39,7 +39,8 @@ class gill_unet_config(C.Structure):
   _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("block_out_channels", C.c_int32 * 4),
               ("layers_per_block", C.c_int32), ("cross_attention_dim", C.c_int32), ("num_heads", C.c_int32),
               ("norm_num_groups", C.c_int32), ("sample_size", C.c_int32), ("ctx_len", C.c_int32),
-              ("max_batch", C.c_int32), ("heads_per_level", C.c_int32 * 4), ("v_prediction", C.c_int32)]
+              ("max_batch", C.c_int32), ("heads_per_level", C.c_int32 * 4), ("v_prediction", C.c_int32),
+              ("fp8_convs", C.c_int32)]
 
 
 class gill_clip_config(C.Structure):

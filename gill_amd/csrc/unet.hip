@@ -27,7 +27,11 @@
 
 namespace {
 
-struct ConvW { bf16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; int chunked = 0; /* K order: GemmArgs::k_chunked */ };
+struct ConvW {
+  bf16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; int chunked = 0; /* K order: GemmArgs::k_chunked */
+  // gill_unet_config.fp8_convs: e4m3 weights [cout][kpad] in conv_fp8.hip's K order + per-output-channel de-quantisation scale
+  unsigned char* w8 = nullptr; float* cs = nullptr; int kpad = 0;
+};
 struct LinW { bf16_t* w = nullptr; float* b = nullptr; int out = 0, in = 0; };
 struct NormW { float* g = nullptr; float* b = nullptr; int c = 0; };
 
@@ -194,10 +198,17 @@ struct Loader {
     return load_f32(wt, pool, p + ".bias", c, &n->b, s);
   }
   // hw: pixels per sample of the conv's INPUT (decides the K order, see GemmArgs::k_chunked)
-  int conv3(const std::string& p, int cin, int cout, int hw, ConvW* c) {
+  int conv3(const std::string& p, int cin, int cout, int hw, ConvW* c, bool f8 = false) {
     c->cin = cin; c->cout = cout; c->chunked = conv_k_chunked(hw, cin) ? 1 : 0;
     const gill_tensor* t;
     GILL_TRY(wt.get(p + ".weight", (int64_t)cout * cin * 9, &t));
+    if (f8) {
+      c->kpad = conv_fp8_kpad(cin);
+      GILL_TRY(pool.alloc(&c->w8, (size_t)cout * c->kpad, false));
+      GILL_TRY(pool.alloc(&c->cs, (size_t)cout, false));
+      GILL_TRY(conv_weight_quant_fp8_launch(t->data, t->dtype, cout, cin, F8_ACT_SCALE, c->w8, c->cs, s));
+      return load_f32(wt, pool, p + ".bias", cout, &c->b, s);
+    }
     GILL_TRY(pool.alloc(&c->w, (size_t)cout * cin * 9, false));
     if (c->chunked) GILL_TRY(conv_weight_relayout_chunked_launch(t->data, t->dtype, cout, cin, c->w, s));
     else GILL_TRY(conv_weight_relayout_launch(t->data, t->dtype, cout, cin, c->w, s));
@@ -218,15 +229,16 @@ struct Loader {
     return 0;
   }
   int resnet(const std::string& p, int cin, int cout, int hw, int temb_dim, int* temb_off, bf16_t* temb_w, float* temb_b,
-             ResnetW* r) {
+             ResnetW* r, bool f8) {
     r->cin = cin; r->cout = cout;
+    f8 = f8 && cin % 64 == 0 && cout % 64 == 0;
     GILL_TRY(norm(p + ".norm1", cin, &r->n1));
-    GILL_TRY(conv3(p + ".conv1", cin, cout, hw, &r->c1));
+    GILL_TRY(conv3(p + ".conv1", cin, cout, hw, &r->c1, f8));
     GILL_TRY(norm(p + ".norm2", cout, &r->n2));
-    GILL_TRY(conv3(p + ".conv2", cout, cout, hw, &r->c2));
+    GILL_TRY(conv3(p + ".conv2", cout, cout, hw, &r->c2, f8));
     r->has_sc = (cin != cout);
-    if (r->has_sc) {
-      GILL_TRY(lin(p + ".conv_shortcut", cout, cin, &r->sc));
+    if (r->has_sc) GILL_TRY(lin(p + ".conv_shortcut", cout, cin, &r->sc));
+    if (r->has_sc && !f8) {   // (fp8 mode: the 1x1 shortcut stays a bf16 GEMM of its own whose output is conv2's residual)
       // fused weight rows: [conv2 taps (9*cout) | shortcut (cin)]
       const int kf = 9 * cout + cin;
       std::vector<int32_t> ident(cout);
@@ -378,6 +390,7 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
   if ((rc = L.lin("time_embedding.linear_2", temb_dim, temb_dim, &m->te2))) return fail(rc);
 
   int layer_id = 0;
+  const bool f8 = cfg->fp8_convs != 0;   // ResnetBlock2D convolutions on the fp8 matrix instruction (conv_fp8.hip)
   auto hw_of = [&](int level) { const int side = cfg->sample_size >> level; return side * side; };   // pixels per sample
   // down blocks: CrossAttnDownBlock2D x3, DownBlock2D
   for (int i = 0; i < 4; ++i) {
@@ -386,7 +399,7 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
     m->down_res[i].resize(2);
     for (int j = 0; j < 2; ++j)
       if ((rc = L.resnet(p + ".resnets." + std::to_string(j), j == 0 ? cin : ch[i], ch[i], hw_of(i), temb_dim, &temb_off,
-                         m->temb_proj_w, m->temb_proj_b, &m->down_res[i][j]))) return fail(rc);
+                         m->temb_proj_w, m->temb_proj_b, &m->down_res[i][j], f8))) return fail(rc);
     if (i < 3) {
       m->down_xf[i].resize(2);
       for (int j = 0; j < 2; ++j)
@@ -395,10 +408,10 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
     }
   }
   // mid
-  if ((rc = L.resnet("mid_block.resnets.0", ch[3], ch[3], hw_of(3), temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[0])))
+  if ((rc = L.resnet("mid_block.resnets.0", ch[3], ch[3], hw_of(3), temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[0], f8)))
     return fail(rc);
   if ((rc = L.xf("mid_block.attentions.0", ch[3], Hl[3], ctxd, layer_id++, &m->mid_xf))) return fail(rc);
-  if ((rc = L.resnet("mid_block.resnets.1", ch[3], ch[3], hw_of(3), temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[1])))
+  if ((rc = L.resnet("mid_block.resnets.1", ch[3], ch[3], hw_of(3), temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[1], f8)))
     return fail(rc);
   // up blocks: UpBlock2D, CrossAttnUpBlock2D x3
   const int rev[4] = {ch[3], ch[2], ch[1], ch[0]};
@@ -412,7 +425,7 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
       const int skip = (j == 2) ? inc : outc;
       const int rin = (j == 0) ? prev : outc;
       if ((rc = L.resnet(p + ".resnets." + std::to_string(j), rin + skip, outc, hw_of(3 - i), temb_dim, &temb_off, m->temb_proj_w,
-                         m->temb_proj_b, &m->up_res[i][j]))) return fail(rc);
+                         m->temb_proj_b, &m->up_res[i][j], f8))) return fail(rc);
     }
     if (i > 0) {
       m->up_xf[i].resize(3);
@@ -470,6 +483,11 @@ struct UNetRun {
     }
     return t;
   }
+  Tensor talloc8(int H, int W, int C) {   // fp8 activation tensor (one byte per element)
+    Tensor t; t.H = H; t.W = W; t.C = C;
+    t.p = (bf16_t*)m->arena.alloc((size_t)Bx * H * W * C);
+    return t;
+  }
   void fuse_stats(GemmArgs& g, const Tensor& y) {
     if (!y.stats) return;
     g.gn_stats = y.stats; g.gn_groups = y.C / y.sbin; g.gn_cg = y.sbin;
@@ -488,7 +506,8 @@ struct UNetRun {
     if (ys && ys->stats) ys->nslab = ys->H * ys->W / gemm_gn_slab_rows(g);
     return gemm_launch(g, s);
   }
-  int gnorm(const Tensor& x1, const Tensor* x2, const NormW& n, float eps, int silu, const Tensor& y) {
+  // y8_scale > 0: y holds fp8(y8_scale * value) instead of bf16 (same shape; the A operand of conv8())
+  int gnorm(const Tensor& x1, const Tensor* x2, const NormW& n, float eps, int silu, const Tensor& y, float y8_scale = 0.f) {
     // single-source input whose producer already accumulated the sums: no statistics pass
     const int C = x1.C + (x2 ? x2->C : 0);
     const bool ready = x1.stats != nullptr && (x2 == nullptr || x2->stats != nullptr) &&
@@ -500,9 +519,34 @@ struct UNetRun {
     if (ready)
       return groupnorm_apply_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, HW, m->cfg.norm_num_groups,
                                     n.g, n.b, eps, silu, y.p, x1.stats, x1.sbin, x1.C, x1.nslab,
-                                    x2 ? x2->stats : nullptr, x2 ? x2->sbin : 0, x2 ? x2->nslab : 0, s);
+                                    x2 ? x2->stats : nullptr, x2 ? x2->sbin : 0, x2 ? x2->nslab : 0, s, y8_scale);
     return groupnorm_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, HW, m->cfg.norm_num_groups, n.g,
-                            n.b, eps, silu, y.p, stats, s);
+                            n.b, eps, silu, y.p, stats, s, y8_scale);
+  }
+  // 3x3 conv (pad 1, stride 1) of an fp8 activation tensor x8 (gnorm(..., F8_ACT_SCALE)) with fp8 weights:
+  // y = conv + bias + rowvec + resid (resid may alias y.p), GroupNorm partials of y fused like conv()
+  int conv8(const Tensor& x8, const ConvW& w, const float* rowvec, int rv_bstride, const bf16_t* resid, Tensor& y) {
+    if (dry) return 0;
+    ConvF8Args a;
+    a.B = Bx; a.H = x8.H; a.W = x8.W; a.Cin = w.cin; a.M = Bx * x8.H * x8.W; a.N = w.cout; a.Kpad = w.kpad;
+    a.A8 = reinterpret_cast<const unsigned char*>(x8.p); a.W8 = w.w8; a.colscale = w.cs; a.C = y.p;
+    a.rows_per_batch = x8.H * x8.W;
+    GemmArgs g;      // split-K geometry + the reducer's epilogue
+    g.M = a.M; g.N = a.N; g.K = 9 * w.cin;
+    pick_sk(g);
+    a.splitk = g.splitk;
+    if (a.splitk > 1) {
+      a.ws = g.ws;
+      GILL_TRY(conv3x3_fp8_launch(a, s));
+      g.bias = w.b; g.rowvec = rowvec; g.rows_per_batch = a.rows_per_batch; g.rowvec_bstride = rv_bstride;
+      g.resid = resid; g.ldr = w.cout; g.C = y.p; g.ldc = w.cout;
+      fuse_stats(g, y);
+      if (y.stats) y.nslab = y.H * y.W / gemm_gn_slab_rows(g);
+      return gemm_splitk_reduce_launch(g, s);
+    }
+    a.bias = w.b; a.rowvec = rowvec; a.rowvec_bstride = rv_bstride; a.resid = resid;
+    if (y.stats) { a.gn_stats = y.stats; a.gn_groups = y.C / y.sbin; a.gn_cg = y.sbin; y.nslab = y.H * y.W / GN_SLAB_ROWS; }
+    return conv3x3_fp8_launch(a, s);
   }
   // 3x3 conv (pad 1) over x1 (++ x2): stride 1|2, optional fused nearest-2x upsample
   int conv(const Tensor& x1, const Tensor* x2, const ConvW& w, int stride, int ups, const float* rowvec, int rv_bstride,
@@ -533,6 +577,25 @@ struct UNetRun {
     const int H = x1.H, Wd = x1.W;
     *out = talloc(H, Wd, w.cout, out_stats);
     const size_t mk = m->arena.mark();
+    if (w.c1.w8) {
+      // fp8 mode: both GroupNorm-apply passes write e4m3 (half the bytes of the bf16 tensors they replace) and both convs run on
+      // the fp8 matrix instruction; the 1x1 shortcut (bf16 GEMM over the raw input) lands in `out` first and conv2 adds onto it
+      Tensor n1 = talloc8(H, Wd, w.cin);
+      GILL_TRY(gnorm(x1, x2, w.n1, 1e-5f, 1, n1, F8_ACT_SCALE));
+      Tensor h = talloc(H, Wd, w.cout, true);   // -> norm2
+      GILL_TRY(conv8(n1, w.c1, temb_rows ? temb_rows + w.temb_off : nullptr, temb_bstride, nullptr, h));
+      Tensor n2 = talloc8(H, Wd, w.cout);
+      GILL_TRY(gnorm(h, nullptr, w.n2, 1e-5f, 1, n2, F8_ACT_SCALE));
+      const bf16_t* resid = x1.p;
+      if (w.has_sc) {
+        GILL_TRY(linear(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, x1.C, Bx * H * Wd, w.sc.w, w.sc.b, w.cout, w.cin, nullptr, 0,
+                        out->p, w.cout));
+        resid = out->p;
+      }
+      GILL_TRY(conv8(n2, w.c2, nullptr, 0, resid, *out));
+      m->arena.release(mk);
+      return 0;
+    }
     Tensor n1 = talloc(H, Wd, w.cin);
     GILL_TRY(gnorm(x1, x2, w.n1, 1e-5f, 1, n1));
     Tensor h = talloc(H, Wd, w.cout, true);   // -> norm2

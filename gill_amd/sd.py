@@ -45,7 +45,7 @@ class GillSDPipeline:
     ccfg = N.gill_unet_config(in_channels=cfg.in_channels, out_channels=cfg.out_channels,
                               layers_per_block=cfg.layers_per_block, cross_attention_dim=cfg.cross_attention_dim,
                               num_heads=cfg.num_heads, norm_num_groups=cfg.norm_num_groups,
-                              v_prediction=int(cfg.prediction_type == "v_prediction"),
+                              v_prediction=int(cfg.prediction_type == "v_prediction"), fp8_convs=int(cfg.fp8_convs),
                               sample_size=cfg.sample_size, ctx_len=cfg.ctx_len, max_batch=max_batch)
     for i in range(4):
       ccfg.block_out_channels[i] = cfg.block_out_channels[i]

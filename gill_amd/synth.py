@@ -195,6 +195,7 @@ class UNetConfig:
   ctx_len: int = 77
   heads_per_level: Optional[Tuple[int, int, int, int]] = None   # SD-2.x: fixed head dim 64 -> (5, 10, 20, 20) heads
   prediction_type: str = "epsilon"                              # "v_prediction" for SD-2.1-768
+  fp8_convs: bool = False      # BASELINE.json configs[4]: resnet convolutions in fp8 e4m3 (csrc/conv_fp8.hip); not a parity mode
 
   def heads(self, level: int) -> int:
     return self.heads_per_level[level] if self.heads_per_level else self.num_heads

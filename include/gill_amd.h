@@ -154,6 +154,8 @@ typedef struct {
   int32_t max_batch;            /* largest UNet batch (2 x prompts with CFG) */
   int32_t heads_per_level[4];   /* all 0: num_heads at every level (SD-1.x); SD-2.x: 5,10,20,20 (head dim 64 everywhere) */
   int32_t v_prediction;         /* 0: the UNet predicts epsilon (SD-1.x, SD-2.1-base); 1: v (SD-2.1-768) */
+  int32_t fp8_convs;            /* 1: ResnetBlock2D 3x3 convolutions with fp8 (e4m3) activations and weights on the fp8 matrix
+                                 * instruction (BASELINE.json configs[4]); 0 (the parity configuration): everything bf16 */
 } gill_unet_config;
 
 int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, const gill_tensor* weights, int n_weights);

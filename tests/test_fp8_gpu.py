@@ -53,3 +53,34 @@ def test_conv3x3_fp8_vs_quantised_fp32(cuda, B, H, W, Cin, Cout, sk):
   rel = ((got - full).norm() / full.norm()).item()
   print(f"  vs un-quantised conv: rel-L2 {rel:.3e}")
   assert rel < 6e-2
+
+
+def _bfw(sd):
+  return {k: v.bfloat16().float() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("which", ["tiny", "sd15"])
+def test_fp8_unet_mode_vs_bf16_mode(cuda, which):
+  """gill_unet_config.fp8_convs = 1 against this build's parity (bf16) configuration on the same weights and inputs through
+  gill_sd_denoise (10 PLMS steps, CFG 7.5): the latents must stay within a stated distance — what the e4m3 operands of the 44
+  resnet convolutions cost after 11 recurrent UNet calls — and the fp8 mode must itself be bit-reproducible (its statistics
+  and split-K reductions are the same fixed-order ones)."""
+  import dataclasses
+  from gill_amd.sd import GillSDPipeline
+  cfg = synth.UNetConfig.tiny(16) if which == "tiny" else synth.UNetConfig.sd15()
+  sd = _bfw(synth.unet_state_dict(cfg, seed=41))
+  uncond = synth.uncond_context(cfg.ctx_len, cfg.cross_attention_dim, seed=41).bfloat16().float()
+  B = 2
+  cond = synth.normal("f8_cond", (B, cfg.ctx_len, cfg.cross_attention_dim), 42).bfloat16().float()
+  lat0 = synth.initial_latents(B, 4, cfg.sample_size, seed=4242)
+  kw = dict(prompt_embeds=cond, latents=lat0, guidance_scale=7.5, num_inference_steps=10)
+  ref = GillSDPipeline(sd, cfg, uncond, cuda, max_batch=2 * B)(**kw).images.float().cpu()
+  pipe8 = GillSDPipeline(sd, dataclasses.replace(cfg, fp8_convs=True), uncond, cuda, max_batch=2 * B)
+  got = pipe8(**kw).images.float().cpu()
+  assert torch.isfinite(got).all()
+  rel = ((got - ref).norm() / ref.norm()).item()
+  cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
+  print(f"[fp8 UNet mode vs bf16 mode, {which}, 10-step CFG] rel-L2 {rel:.3e} cos {cos:.5f}")
+  assert rel < 8e-2 and cos > 0.995      # the same bar the bf16 mode is held to against the fp32 oracle
+  again = pipe8(**kw).images.float().cpu()
+  assert torch.equal(again, got)

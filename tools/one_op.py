@@ -2,6 +2,7 @@
 
   GILL_OP_REPEAT=20 python tools/one_op.py conv  B H W C1 C2 Cout [splitk]
   GILL_OP_REPEAT=20 python tools/one_op.py gemm  M N K [splitk]
+  GILL_OP_REPEAT=20 python tools/one_op.py conv8 B H W C1 C2 Cout [splitk]   (fp8 operands)
   GILL_OP_REPEAT=20 python tools/one_op.py attn  B H nq nkv d
   GILL_OP_REPEAT=1  python tools/one_op.py geglu M inner K
 """
@@ -25,6 +26,13 @@ def main():
     x2 = torch.randn(B, H, W, C2, device=dev).bfloat16() if C2 else None
     w = torch.randn(Cout, C1 + C2, 3, 3, device=dev) * 0.02
     fn = lambda: ops.conv3x3(x1, w, x2=x2, splitk=sk)  # noqa: E731
+    flops = 2.0 * B * H * W * Cout * 9 * (C1 + C2)
+  elif kind == "conv8":
+    B, H, W, C1, C2, Cout = a[:6]
+    sk = a[6] if len(a) > 6 else 1
+    x1 = torch.randn(B, H, W, C1 + C2, device=dev).bfloat16()
+    w = torch.randn(Cout, C1 + C2, 3, 3, device=dev) * 0.02
+    fn = lambda: ops.conv3x3_fp8(x1, w, splitk=sk)  # noqa: E731
     flops = 2.0 * B * H * W * Cout * 9 * (C1 + C2)
   elif kind == "gemm":
     M, N, K = a[:3]
