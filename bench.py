@@ -224,7 +224,7 @@ def main():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=5)
   ap.add_argument("--warmup", type=int, default=2)
-  ap.add_argument("--prompts-per-gpu", type=int, default=0, help="default: 4 at --gpus 1 (BASELINE configs[1]), 8 at --gpus > 1 (configs[2])")
+  ap.add_argument("--prompts-per-gpu", type=int, default=0, help="default: 4 at --gpus 1 (BASELINE configs[1]), 8 at --gpus > 1 (configs[2]), 16 with --config c5 (configs[4])")
   ap.add_argument("--infer-steps", type=int, default=50)
   ap.add_argument("--prompt-len", type=int, default=24)
   ap.add_argument("--small", action="store_true", help="opt-125m shapes (debug only; not the benchmark config)")
@@ -254,7 +254,7 @@ def main():
       dist.init_process_group(a.backend, rank=rank, world_size=world)
   assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
   if a.prompts_per_gpu <= 0:
-    a.prompts_per_gpu = 4 if a.gpus == 1 else 8
+    a.prompts_per_gpu = 16 if a.config == "c5" else (4 if a.gpus == 1 else 8)   # configs[4]: batch 128 over 8 GPUs
   dev = torch.device("cuda", local)
   torch.cuda.set_device(dev)
 
