@@ -59,6 +59,7 @@ struct XfW {  // Transformer2DModel with one BasicTransformerBlock
   // norm1/2/3 are folded into wqkv1 / wq2 / wff1 at load (GemmArgs::ln_stats): column sums of g*W and beta.W^T (+ bias)
   float *s_qkv1 = nullptr, *c_qkv1 = nullptr, *s_q2 = nullptr, *c_q2 = nullptr, *s_ff1 = nullptr;
   LinW ff2;                   // [C][4C]
+  bf16_t* wfo = nullptr; float* bfo = nullptr;   // ff2 and proj_out as one map: [C][4C + C] = [Wp W2 | Wp], bias Wp b2 + bp
 };
 
 // stats: optional slot [Bx][H*W/64][C/sbin][2] that the PRODUCING GEMM epilogue fills with this tensor's per-slab GroupNorm
@@ -186,6 +187,33 @@ __global__ __launch_bounds__(256) void pad_head_rows_kernel(const void* src, int
   }
 }
 
+// Feed-forward output and proj_out are two linear maps with only a residual add in between:
+//   out = proj_out(ff2(h) + t) + x_in = h (Wp W2)^T + t Wp^T + (Wp b2 + bp) + x_in
+// so they run as ONE two-source GEMM over K = [h (4C) | t (C)].  This builds its weight rows [Wp W2 | Wp] ([C][5C], products in
+// fp32 from the checkpoint's own dtype, one rounding to bf16) and its bias Wp b2 + bp.  Load time only: plain loops.
+__device__ __forceinline__ float ld_any(const void* p, int dtype, int64_t i) {
+  if (dtype == 0) return bf2f(((const bf16_t*)p)[i]);
+  if (dtype == 1) return ((const float*)p)[i];
+  return (float)(((const __half*)p)[i]);
+}
+__global__ __launch_bounds__(256) void ffo_fuse_kernel(const void* wp, int dt_p, const void* w2, int dt_2, const void* b2, int dt_b2,
+                                                       const void* bp, int dt_bp, int C, bf16_t* w_out, float* b_out) {
+  const int n = blockIdx.y;                       // output row
+  const int k = blockIdx.x * 256 + threadIdx.x;   // column of [4C | C | 1 (bias)]
+  const int K4 = 4 * C;
+  if (k < K4) {
+    float a = 0.f;
+    for (int j = 0; j < C; ++j) a = fmaf(ld_any(wp, dt_p, (int64_t)n * C + j), ld_any(w2, dt_2, (int64_t)j * K4 + k), a);
+    w_out[(size_t)n * 5 * C + k] = f2bf(a);
+  } else if (k < 5 * C) {
+    w_out[(size_t)n * 5 * C + k] = f2bf(ld_any(wp, dt_p, (int64_t)n * C + (k - K4)));
+  } else if (k == 5 * C) {
+    float a = ld_any(bp, dt_bp, n);
+    for (int j = 0; j < C; ++j) a = fmaf(ld_any(wp, dt_p, (int64_t)n * C + j), ld_any(b2, dt_b2, j), a);
+    b_out[n] = a;
+  }
+}
+
 namespace {
 
 struct Loader {
@@ -310,6 +338,18 @@ struct Loader {
       GILL_TRY(permute_f32_launch(tmpb, idx, 2 * inner, x->bff1, s));
     }
     GILL_TRY(lin(b + ".ff.net.2", C, 4 * C, &x->ff2));
+    {
+      const gill_tensor *tp, *t2, *tb2, *tbp;
+      GILL_TRY(wt.get(p + ".proj_out.weight", (int64_t)C * C, &tp));
+      GILL_TRY(wt.get(b + ".ff.net.2.weight", (int64_t)C * 4 * C, &t2));
+      GILL_TRY(wt.get(b + ".ff.net.2.bias", C, &tb2));
+      GILL_TRY(wt.get(p + ".proj_out.bias", C, &tbp));
+      GILL_TRY(pool.alloc(&x->wfo, (size_t)C * 5 * C, false));
+      GILL_TRY(pool.alloc(&x->bfo, (size_t)C, false));
+      hipLaunchKernelGGL(ffo_fuse_kernel, dim3(cdiv(5 * C + 1, 256), C), dim3(256), 0, s, tp->data, tp->dtype, t2->data, t2->dtype,
+                         tb2->data, tb2->dtype, tbp->data, tbp->dtype, C, x->wfo, x->bfo);
+      GILL_CHECK_HIP(hipGetLastError());
+    }
     // fold the three LayerNorms into the projections that consume them
     GILL_TRY(pool.alloc(&x->s_qkv1, (size_t)3 * hdp)); GILL_TRY(pool.alloc(&x->c_qkv1, (size_t)3 * hdp));
     GILL_TRY(pool.alloc(&x->s_q2, (size_t)hdp)); GILL_TRY(pool.alloc(&x->c_q2, (size_t)hdp));
@@ -700,9 +740,14 @@ struct UNetRun {
       g.act = ACT_GEGLU; g.C = ffh; g.ldc = 4 * C;
       GILL_TRY(gemm(g));
     }
-    GILL_TRY(linear(ffh, 4 * C, nullptr, 0, 4 * C, M, w.ff2.w, w.ff2.b, C, 4 * C, t.p, ACT_NONE, t.p, C));
-    // --- proj_out + outer residual
-    GILL_TRY(linear(t.p, C, nullptr, 0, C, M, w.proj_out.w, w.proj_out.b, C, C, xd.p, ACT_NONE, out->p, C, out));
+    // --- feed-forward output, its residual, proj_out and the outer residual: one GEMM over K = [h | t] (see ffo_fuse_kernel)
+    static const bool unfused = getenv("GILL_UNET_FFO_UNFUSED") != nullptr;     // A/B switch: the two GEMMs of the reference graph
+    if (unfused) {
+      GILL_TRY(linear(ffh, 4 * C, nullptr, 0, 4 * C, M, w.ff2.w, w.ff2.b, C, 4 * C, t.p, ACT_NONE, t.p, C));
+      GILL_TRY(linear(t.p, C, nullptr, 0, C, M, w.proj_out.w, w.proj_out.b, C, C, xd.p, ACT_NONE, out->p, C, out));
+    } else {
+      GILL_TRY(linear(ffh, 4 * C, t.p, C, 4 * C, M, w.wfo, w.bfo, C, 5 * C, xd.p, ACT_NONE, out->p, C, out));
+    }
     m->arena.release(mk);
     return 0;
   }
