@@ -264,8 +264,82 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* __restrict_
     if (lane == 0) y[(((size_t)b * Cout + o) * H + yh) * W + xw] = s + (bias ? bias[o] : 0.f);
   }
 }
+// conv_out on the matrix pipe: one wave = 16 consecutive pixels of an image row x all (<= 16) output channels, one
+// v_mfma_f32_16x16x32_bf16 per (tap, 32 input channels).  First operand = the weight rows (rows >= Cout are zero registers; the
+// [Cout][9][Cin] weights sit in LDS, copied once per workgroup), second operand = the 16 pixels' input channels straight from
+// global memory (16 B per lane; the 3x3 halo overlaps of neighbouring waves hit in L1/L2).  A lane ends up with output channels
+// (lane >> 4) * 4 + r of pixel lane & 15: 64-byte fp32 NCHW row segments.  Two accumulators break the MFMA dependency chain.
+// The one-wave-per-pixel kernel above spent 68 us on the UNet's 64 x 64 x 320 -> 4 conv_out (VALU + L1 bound); this one is fetch-bound.
+template <int KS>     // KS = Cin / 32 when compile-time (all of a tap's loads in flight before its MFMAs), 0 = run-time loop
+__global__ __launch_bounds__(256) void conv_out_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                            const float* __restrict__ bias, int B, int Cin, int H, int W,
+                                                            int Cout, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cw_smem[];
+  bf16_t* ws = reinterpret_cast<bf16_t*>(cw_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nw16 = Cout * 9 * Cin / 8;
+  for (int i = tid; i < nw16; i += 256) reinterpret_cast<uint4*>(ws)[i] = reinterpret_cast<const uint4*>(w)[i];
+  __syncthreads();
+  const int gpr = W / 16;                                   // 16-pixel groups per image row
+  const int64_t g = (int64_t)blockIdx.x * 4 + wv;
+  if (g >= (int64_t)B * H * gpr) return;
+  const int gx = (int)(g % gpr);
+  const int yh = (int)((g / gpr) % H);
+  const int b = (int)(g / ((int64_t)gpr * H));
+  const int px = lane & 15, kg = lane >> 4;
+  const int xw = gx * 16 + px;
+  const bool wrow = px < Cout;
+  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int ksteps = KS > 0 ? KS : Cin / 32;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int iy = yh + tap / 3 - 1, ix = xw + tap % 3 - 1;
+    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const bf16_t* xp = x + (((size_t)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cin + kg * 8;
+    const bf16_t* wp = ws + ((size_t)(wrow ? px : 0) * 9 + tap) * Cin + kg * 8;
+    if constexpr (KS > 0) {
+      bf16x8 xf[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xp + ks * 32);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 wf = *reinterpret_cast<const bf16x8*>(wp + ks * 32);
+        if (!wrow) wf = zero;
+        const bf16x8 xv = ok ? xf[ks] : zero;
+        if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xv, acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xv, acc0, 0, 0, 0);
+      }
+    } else {
+      for (int ks = 0; ks < ksteps; ++ks) {
+        bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xp + ks * 32);
+        bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp + ks * 32);
+        if (!ok) x0 = zero;
+        if (!wrow) w0 = zero;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc0, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = kg * 4 + r;
+    if (o < Cout) y[(((size_t)b * Cout + o) * H + yh) * W + xw] = acc0[r] + acc1[r] + (bias ? bias[o] : 0.f);
+  }
+}
+
 int conv_out_launch(const bf16_t* x, const bf16_t* w, const float* bias, int B, int Cin, int H, int W, int Cout, float* y,
                     hipStream_t s) {
+  const size_t wbytes = (size_t)Cout * 9 * Cin * sizeof(bf16_t);
+  static const bool direct = getenv("GILL_CONV_OUT_DIRECT") != nullptr;      // A/B switch: the VALU kernel
+  if (!direct && Cout <= 16 && Cin % 32 == 0 && W % 16 == 0 && wbytes <= 64 * 1024 && (((uintptr_t)w | (uintptr_t)x) & 15) == 0) {
+    const int64_t groups = (int64_t)B * H * (W / 16);
+    const dim3 grid((unsigned)cdiv64(groups, 4));
+    if (Cin == 320) hipLaunchKernelGGL(conv_out_mfma_kernel<10>, grid, dim3(256), wbytes, s, x, w, bias, B, Cin, H, W, Cout, y);
+    else if (Cin == 128) hipLaunchKernelGGL(conv_out_mfma_kernel<4>, grid, dim3(256), wbytes, s, x, w, bias, B, Cin, H, W, Cout, y);
+    else if (Cin == 64) hipLaunchKernelGGL(conv_out_mfma_kernel<2>, grid, dim3(256), wbytes, s, x, w, bias, B, Cin, H, W, Cout, y);
+    else hipLaunchKernelGGL(conv_out_mfma_kernel<0>, grid, dim3(256), wbytes, s, x, w, bias, B, Cin, H, W, Cout, y);
+    GILL_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   GILL_REQUIRE(Cout <= 8 && Cin % 8 == 0, "conv_out: Cout <= 8 and Cin % 8 == 0 required");
   const int64_t pix = (int64_t)B * H * W;
   hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)cdiv64(pix, 4)), dim3(256), 0, s, x, w, bias, B, Cin, H, W, Cout, y);
