@@ -73,7 +73,7 @@ int gemm_row_planes(const GemmArgs& a);
 // can a GEMM with N output columns produce fused GroupNorm statistics for bins of cg channels?
 bool gemm_fused_gn_ok(int N, int cg);
 // heuristic split-K factor for under-filled grids
-int gemm_pick_splitk(int M, int N, int K, int act);
+int gemm_pick_splitk(int M, int N, int K, int act, bool plain = false);   // plain: not a conv (64-row tiles available)
 
 // split-K reducer of gemm_launch on its own (partials a.ws [splitk][M][N] fp32 written by another kernel: conv_fp8.hip)
 int gemm_splitk_reduce_launch(const GemmArgs& a, hipStream_t s);

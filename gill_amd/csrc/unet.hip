@@ -534,7 +534,7 @@ struct UNetRun {
     g.rows_per_batch = y.H * y.W;
   }
   int pick_sk(GemmArgs& g) {
-    g.splitk = gemm_pick_splitk(g.M, g.N, g.K, g.act);
+    g.splitk = gemm_pick_splitk(g.M, g.N, g.K, g.act, !g.conv);
     while (g.splitk > 1 && (size_t)g.splitk * g.M * g.N > m->splitk_ws_floats) --g.splitk;
     g.ws = m->splitk_ws;
     return 0;
