@@ -799,6 +799,11 @@ bool gemm_fused_gn_ok(int N, int cg) {
   return bn % cg == 0 && (64 % cg == 0 || (80 % cg == 0 && N % 80 == 0));
 }
 
+static int env_int(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+}
+
 int gemm_pick_splitk(int M, int N, int K, int act, bool plain) {
   if (act == ACT_GEGLU) return 1;
   const int bn = (N % 160 == 0) ? 160 : 128;
@@ -812,7 +817,8 @@ int gemm_pick_splitk(int M, int N, int K, int act, bool plain) {
   // each split pays an fp32 partial write + a reduce pass: keep >= 24 K steps per split (measured: K = 1280 GEMMs lose
   // from any split, K >= 5120 convs win up to 4-8 ways), except for skinny weight-streaming GEMMs (OPT, M <= 256)
   // where filling every CU with HBM requests matters more than the tiny partials
-  const int min_steps = (M <= 256 || tiles < 64) ? 4 : 24;
+  static const int min_env = env_int("GILL_GEMM_MINSTEPS");
+  const int min_steps = (M <= 256 || tiles < 64) ? 4 : (min_env > 0 ? min_env : 24);
   if (s > ksteps / min_steps) s = ksteps / min_steps;
   if (s > 16) s = 16;
   if (s < 1) s = 1;
@@ -861,10 +867,6 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, int stages, hipStream
 }
 
 // tuning knobs (tests / tools): GILL_GEMM_STAGES = 2|3 forces the ring depth, GILL_GEMM_BN = 128|160 the tile width
-static int env_int(const char* name) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : 0;
-}
 
 template <int BN>
 static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
