@@ -161,6 +161,7 @@ template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const GemmDev d) {
   constexpr int BM = NWV * 32;
   constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
+  constexpr bool PP = (NWV == 8 && BN == 160 && STAGES == 3 && KT == 64);   // ping-pong main loop (see there)
   static_assert(KT == 64 || KT == 32, "stage depth");
   constexpr int LPR = KT / 8;          // lanes (16-B chunks) per tile row
   constexpr int RPI = 64 / LPR;        // tile rows one 1-KiB LDS-DMA wave-instruction covers (8 | 16)
@@ -327,7 +328,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
   };
   int k_issue = kt_beg * KT;     // K coordinate of the next step to stage
   int steps_in_tile = 0;
-  auto issue = [&](int buf) {
+  // One stage = prepare (pointer set-up when the K walk enters a new N tile / (tap, source) segment) + dma (the LDS-DMA
+  // instructions) + post (advance the walk).  The ping-pong loop runs the three in different phases.
+  auto issue_prepare = [&]() {
     if (steps_in_tile == nsteps) {   // next N tile of this workgroup: same A rows from the top, next BN weight rows
       steps_in_tile = 0;
       k_issue = kt_beg * KT;
@@ -335,9 +338,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
       n_issue += BN;
       w_setup();
     }
-    ++steps_in_tile;
     if (seg_left == 0) seg_setup(k_issue);
-    --seg_left;
+  };
+  auto issue_dma = [&](int buf) {
     bf16_t* As = smem + buf * BUF_ELEMS;
     bf16_t* Bs = As + A_ELEMS;
 #pragma unroll
@@ -345,7 +348,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
       bf16_t* l = As + (i * NWV + w) * RPI * KT;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[i],
                                        (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-      a_ptr[i] += KT;
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
@@ -353,9 +355,21 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
       bf16_t* l = Bs + (i * NWV + w) * RPI * KT;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
                                        (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-      w_ptr[i] += KT;
     }
+  };
+  auto issue_post = [&]() {
+    ++steps_in_tile;
+    --seg_left;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) a_ptr[i] += KT;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) w_ptr[i] += KT;
     k_issue += KT;
+  };
+  auto issue = [&](int buf) {
+    issue_prepare();
+    issue_dma(buf);
+    issue_post();
   };
 
   f32x4 acc[4][NT];
@@ -373,10 +387,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
       case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
       case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
       case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
       case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
       case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
       case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
       case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // (waiting for more than needed is always correct)
     }
   };
@@ -402,6 +418,83 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (PP) {
+    // ---- PING-PONG main loop (256 x 160 tile, 8 waves 4 x 2, one workgroup per CU, 3-deep ring).  Waves w and w + 4 share a
+    // SIMD and sit in different groups; the groups run half a K step apart, so in every phase ONE wave of each SIMD issues its
+    // step's 40 MFMAs while the other does its step's memory work (18 ds_read_b128 fragment loads, then its 6-7 LDS-DMA pieces of
+    // stage k + 2 with their address bookkeeping).  Phase p (one s_barrier each):  group A  MEM(k) at p = 2k, MMA(k) at 2k + 1;
+    // group B  MEM(k) at 2k + 1, MMA(k) at 2k + 2.  Invariant: before the barrier into phase 2k every wave has waited for its own
+    // pieces of stage k (in-order vmcnt: at most the pieces of stage k + 1 stay in flight).  Stage k's buffer is last read in
+    // phase 2k + 1 and refilled (as stage k + 3) from phase 2k + 2 on.  Bare loop 1352 vs 1058 TFLOP/s for two co-resident
+    // 128 x 160 workgroups (tools/ubench/gemm_loop.hip).
+    const int grp = w >> 2;
+    int issued = total_steps < STAGES - 1 ? total_steps : STAGES - 1;     // stages this wave has issued so far
+    bf16x8 af[KK][4];
+    bf16x8 bfr[KK][NT];
+    auto landed = [&](int k) {         // own pieces of stage k have landed
+      if (k < nsteps) wait_vm((issued - 1 - k) * lw);
+    };
+    auto mem = [&](int k) {
+      const int sb = k % STAGES;
+      const bf16_t* As = smem + sb * BUF_ELEMS;
+      const bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wm * 64 + i * 16 + frow;
+          af[kk][i] = *reinterpret_cast<const bf16x8*>(As + row * KT + (((kk * 4 + fkc) ^ SWZ(row)) * 8));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int row = wn * (BN / 2) + j * 16 + frow;
+          bfr[kk][j] = *reinterpret_cast<const bf16x8*>(Bs + row * KT + (((kk * 4 + fkc) ^ SWZ(row)) * 8));
+        }
+      }
+      // (the pointers of this stage were prepared during the previous MMA phase: only the DMA instructions here)
+      if (k + STAGES - 1 < nsteps) { issue_dma((k + STAGES - 1) % STAGES); ++issued; }
+    };
+    auto mma = [&](int k) {
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+      // the K walk's bookkeeping (pointer advance, next segment's set-up) rides in the MMA phase, behind the MFMAs
+      if (k + STAGES - 1 < nsteps) {
+        issue_post();
+        if (k + STAGES < nsteps) issue_prepare();
+      }
+    };
+    if (STAGES - 1 < nsteps) issue_prepare();
+    landed(0);
+    __builtin_amdgcn_s_barrier();
+    if (grp == 0) {
+      for (int k = 0; k < nsteps; ++k) {
+        mem(k);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        mma(k);
+        landed(k + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+      }
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __builtin_amdgcn_s_barrier();
+      for (int k = 0; k < nsteps; ++k) {
+        mem(k);
+        landed(k + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        mma(k);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  } else
   for (int it = 0; it < nsteps; ++it, ++flat) {
     // wait for stage `flat` only: the up to STAGES - 2 younger stages (lw instructions each) stay in flight
     if constexpr (STAGES == 2) {
@@ -559,7 +652,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
     // The 64 rows of a wave belong to one slab of one sample (rows_per_batch % 64 == 0).  Fixed-order reduction: 4 rows in the
     // lane, 16 row lanes by xor-shuffles, one LDS cell per (row half, column) written once (the tile ring is dead by now),
     // then one thread per (row half, bin, moment) adds the bin's gn_cg columns and stores the partial: no atomics anywhere.
-    float* red = reinterpret_cast<float*>(smem);     // [2 moments][2 row halves][BN]
+    float* red = reinterpret_cast<float*>(smem);     // [2 moments][BM / 64 row slabs][BN]
     if (p.gn_stats) __syncthreads();                 // every wave is done reading the ring
     float rws[4] = {0.f, 0.f, 0.f, 0.f}, rwq[4] = {0.f, 0.f, 0.f, 0.f};   // row sums for a following (folded) LayerNorm
 #pragma unroll
@@ -615,7 +708,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
           if (frow == 0) {
             const int c = wn * (BN / 2) + j * 16 + fkc * 4 + e;
             red[wm * BN + c] = a;
-            red[2 * BN + wm * BN + c] = q;
+            red[(BM / 64) * BN + wm * BN + c] = q;
           }
         }
       }
@@ -639,7 +732,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
         const int mfirst = m0 + half * 64;
         const int bin = n0 / p.gn_cg + lb;
         if (mfirst < p.M && bin < p.gn_groups) {
-          const float* src = red + which * 2 * BN + half * BN + lb * p.gn_cg;
+          const float* src = red + which * (BM / 64) * BN + half * BN + lb * p.gn_cg;
           float a = 0.f;
           for (int c = 0; c < p.gn_cg; ++c) a += src[c];
           const int b = mfirst / p.rows_per_batch;
@@ -804,6 +897,13 @@ static int env_int(const char* name) {
   return v ? atoi(v) : 0;
 }
 
+// 3x3 convolutions whose row count is a multiple of 256 and whose width tiles by 160 run on the 256 x 160 ping-pong kernel
+// (GILL_GEMM_PP = 0: two co-resident 128 x 160 workgroups instead, the round-1 structure)
+bool gemm_conv_pingpong(int rows_multiple_of, int Cout) {
+  static const int pp_env = [] { const char* v = getenv("GILL_GEMM_PP"); return v ? atoi(v) : 1; }();
+  return pp_env != 0 && rows_multiple_of % 256 == 0 && Cout % 160 == 0;
+}
+
 int gemm_pick_splitk(int M, int N, int K, int act, bool plain) {
   if (act == ACT_GEGLU) return 1;
   const int bn = (N % 160 == 0) ? 160 : 128;
@@ -860,6 +960,9 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, int stages, hipStream
     if constexpr (CONV == 0 && EPI != 2) {
       if (d.nwv == 2) return gemm_launch_inst<2, BN, CONV, EPI, 2>(d, grid, s);
     }
+    if constexpr (BN == 160 && CONV != 0) {
+      if (d.nwv == 8) return gemm_launch_inst<8, BN, CONV, EPI, 3>(d, grid, s);     // ping-pong 256 x 160 tile
+    }
     if (stages == 3) return gemm_launch_inst<4, BN, CONV, EPI, 3>(d, grid, s);
     if (d.kt == 32) return gemm_launch_inst<4, BN, CONV, EPI, 4, 32>(d, grid, s);
     return gemm_launch_inst<4, BN, CONV, EPI, 2>(d, grid, s);
@@ -888,6 +991,9 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   if (forced_bm == 128) d.nwv = 4;
   if (forced_bm == 64 && !a.conv && sk == 1 && stages == 2) d.nwv = 2;
   if (BN == 256) d.nwv = 8;
+  // 3x3 convolutions: 256 x 160 tile with the ping-pong main loop, one workgroup per CU (GILL_GEMM_PP = 0 keeps the two
+  // co-resident 128 x 160 workgroups)
+  if (BN == 160 && a.conv && gemm_conv_pingpong(a.M, a.N) && forced_bm == 0 && forced != 2) { d.nwv = 8; stages = 3; }
   // GILL_GEMM_KT = 32: 4-deep ring of 32-wide stages on the 128-row tiles (see the kernel's KT note).  Off by default: measured
   // 7 % SLOWER on the denoise loop (608 -> 652 ms): the deeper prefetch does not pay for a barrier per 32-wide stage
   static const int forced_kt = env_int("GILL_GEMM_KT");

@@ -196,7 +196,12 @@ int plms_step_launch(const SdLoopArgs& a, hipStream_t s);
 int conv_weight_relayout_launch(const void* w, int dtype, int Cout, int Cin, bf16_t* out /*[Cout][9][Cin]*/, hipStream_t s);   // conv_in / conv_out
 // measured (tools/one_op.py, 8 samples): 64x64x640 -> 320: 150.9 -> 145.4 us, 64x64x960: 207.6 -> 193.7 us; but 64x64x320: 75.9 ->
 // 77.8 us and the split-K level-1 convs lose 14-18 % (32x32x1280 -> 640: 166.8 -> 193.2 us)
-static inline bool conv_k_chunked(int HW, int Cin) { return HW >= 4096 && (int64_t)HW * Cin * 2 > (int64_t)4 << 20; }
+// (not for convolutions that run on the ping-pong 256 x 160 tile — gemm_conv_pingpong(): there a new (tap, chunk) segment every K
+// step lengthens the memory phase, measured 155 us chunk-major against 126 us tap-major for 64 x 64 x 640 -> 320)
+bool gemm_conv_pingpong(int rows_multiple_of, int Cout);     // true: gemm_launch runs this conv's 3x3 GEMM on the ping-pong kernel
+static inline bool conv_k_chunked(int HW, int Cin, int Cout) {
+  return HW >= 4096 && (int64_t)HW * Cin * 2 > (int64_t)4 << 20 && !gemm_conv_pingpong(HW, Cout);
+}
 int conv_weight_relayout_chunked_launch(const void* w, int dtype, int Cout, int Cin, bf16_t* out /*[Cout][Cin/64][9][64]*/, hipStream_t s);   // GemmArgs::conv
 int convert_to_bf16_launch(const void* src, int dtype, int64_t n, bf16_t* dst, hipStream_t s);
 int convert_to_f32_launch(const void* src, int dtype, int64_t n, float* dst, hipStream_t s);

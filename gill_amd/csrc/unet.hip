@@ -227,7 +227,7 @@ struct Loader {
   }
   // hw: pixels per sample of the conv's INPUT (decides the K order, see GemmArgs::k_chunked)
   int conv3(const std::string& p, int cin, int cout, int hw, ConvW* c, bool f8 = false) {
-    c->cin = cin; c->cout = cout; c->chunked = conv_k_chunked(hw, cin) ? 1 : 0;
+    c->cin = cin; c->cout = cout; c->chunked = conv_k_chunked(hw, cin, cout) ? 1 : 0;
     const gill_tensor* t;
     GILL_TRY(wt.get(p + ".weight", (int64_t)cout * cin * 9, &t));
     if (f8) {

@@ -361,6 +361,426 @@ __global__ __launch_bounds__(512, 1) void k_gemm256(const bf16_t* __restrict__ A
   C[(size_t)blockIdx.x * 512 + tid] = result;
 }
 
+
+// 256 x 160 tile, 8 waves 4 x 2, PING-PONG: waves w and w + 4 share a SIMD and belong to different groups; the groups run half a
+// K step apart so that in every phase ONE wave of each SIMD issues the step's 40 MFMAs while the other does the step's memory
+// work (18 ds_read_b128 fragment loads + its 6-7 LDS-DMA pieces of stage k + 2).  One barrier per phase (two per K step),
+// 3-deep ring (156 KiB).  Phase p: group A  MEM(k) at p = 2k, MMA(k) at p = 2k + 1;  group B  MEM(k) at 2k + 1, MMA(k) at 2k + 2.
+// Before the barrier into phase 2k every wave has waited for its own stage-k pieces.
+template <int PRIO>
+__global__ __launch_bounds__(512, 1) void k_gemm256pp(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, float* __restrict__ C,
+                                                      int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  constexpr int A_ELEMS = 256 * BK, B_ELEMS = BN * BK, BUF = A_ELEMS + B_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = N / BN;
+  const int tile = xcd_tile();
+  const int tn = tile % tiles_n, tm = tile / tiles_n;
+  const int m0 = tm * 256, n0 = tn * BN;
+  const int srow = lane >> 3;
+  const int nsteps = K / BK;
+  const bf16_t* a_ptr[4];
+  const bf16_t* w_ptr[3];
+  for (int i = 0; i < 4; ++i) {
+    int row = (i * 8 + w) * 8 + srow;
+    a_ptr[i] = A + (size_t)(m0 + row) * KW + ((lane & 7) ^ (row & 7)) * 8;
+  }
+  const int grp = w >> 2;            // 0: group A (7 pieces per stage), 1: group B (6)
+  for (int i = 0; i < 3; ++i) {
+    int g = i * 8 + w; if (g > 19) g = 19;
+    int row = g * 8 + srow;
+    w_ptr[i] = W + (size_t)(n0 + row) * K + ((lane & 7) ^ (row & 7)) * 8;
+  }
+  int kcol = 0;
+  auto issue = [&](int buf) {
+    bf16_t* As = smem + buf * BUF;
+    bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[i],
+                                       (__attribute__((address_space(3))) void*)(As + (i * 8 + w) * 8 * BK), 16, 0, 0);
+      a_ptr[i] += BK;
+    }
+    if (++kcol == KW / BK) { kcol = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_ptr[i] -= KW; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i < 2 || grp == 0) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
+                                         (__attribute__((address_space(3))) void*)(Bs + (i * 8 + w) * 8 * BK), 16, 0, 0);
+        w_ptr[i] += BK;
+      }
+    }
+  };
+  const int wm = w >> 1, wn = w & 1;
+  f32x4 acc[4][5];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+  const int frow = lane & 15, fkc = lane >> 4;
+  bf16x8 af[2][4], bfr[2][5];
+  auto wait_next = [&](int k) {      // own pieces of stage k + 1 landed (stage k + 2, if issued, may stay in flight)
+    if (k + 2 < nsteps) { if (grp == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto mem = [&](int k) {
+    const bf16_t* As = smem + (k % 3) * BUF;
+    const bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + frow;
+        af[kk][i] = *reinterpret_cast<const bf16x8*>(As + row * BK + (((kk * 4 + fkc) ^ (row & 7)) * 8));
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int row = wn * 80 + j * 16 + frow;
+        bfr[kk][j] = *reinterpret_cast<const bf16x8*>(Bs + row * BK + (((kk * 4 + fkc) ^ (row & 7)) * 8));
+      }
+    }
+    if (k + 2 < nsteps) issue((k + 2) % 3);
+  };
+  auto mma = [&]() {
+    if (PRIO) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+  issue(0);
+  if (nsteps > 1) issue(1);
+  if (nsteps > 1) { if (grp == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 0) {
+    for (int k = 0; k < nsteps; ++k) {
+      mem(k);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      mma();
+      wait_next(k);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __builtin_amdgcn_s_barrier();
+    for (int k = 0; k < nsteps; ++k) {
+      mem(k);
+      wait_next(k);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      mma();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  float result = 0.f;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) result += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  C[(size_t)blockIdx.x * 512 + tid] = result;
+}
+
+template <int PRIO>
+__global__ __launch_bounds__(512, 1) void k_gemm256pp2(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, float* __restrict__ C,
+                                                      int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  constexpr int A_ELEMS = 256 * BK, B_ELEMS = BN * BK, BUF = A_ELEMS + B_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = N / BN;
+  const int tile = xcd_tile();
+  const int tn = tile % tiles_n, tm = tile / tiles_n;
+  const int m0 = tm * 256, n0 = tn * BN;
+  const int srow = lane >> 3;
+  const int nsteps = K / BK;
+  const bf16_t* a_ptr[4];
+  const bf16_t* w_ptr[3];
+  for (int i = 0; i < 4; ++i) {
+    int row = (i * 8 + w) * 8 + srow;
+    a_ptr[i] = A + (size_t)(m0 + row) * KW + ((lane & 7) ^ (row & 7)) * 8;
+  }
+  const int grp = w >> 2;            // 0: group A (7 pieces per stage), 1: group B (6)
+  for (int i = 0; i < 3; ++i) {
+    int g = i * 8 + w; if (g > 19) g = 19;
+    int row = g * 8 + srow;
+    w_ptr[i] = W + (size_t)(n0 + row) * K + ((lane & 7) ^ (row & 7)) * 8;
+  }
+  int kcol = 0;
+  auto issue_piece = [&](int buf, int pc) {     // piece 0..3: A rows, 4..6: W rows
+    bf16_t* As = smem + buf * BUF;
+    bf16_t* Bs = As + A_ELEMS;
+    if (pc < 4) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[pc],
+                                       (__attribute__((address_space(3))) void*)(As + (pc * 8 + w) * 8 * BK), 16, 0, 0);
+      a_ptr[pc] += BK;
+      if (pc == 3) { if (++kcol == KW / BK) { kcol = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_ptr[i] -= KW; } }
+    } else {
+      const int i = pc - 4;
+      if (i < 2 || grp == 0) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
+                                         (__attribute__((address_space(3))) void*)(Bs + (i * 8 + w) * 8 * BK), 16, 0, 0);
+        w_ptr[i] += BK;
+      }
+    }
+  };
+  auto issue = [&](int buf) {
+#pragma unroll
+    for (int pc = 0; pc < 7; ++pc) issue_piece(buf, pc);
+  };
+  const int wm = w >> 1, wn = w & 1;
+  f32x4 acc[4][5];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+  const int frow = lane & 15, fkc = lane >> 4;
+  bf16x8 af[2][4], bfr[2][5];
+  auto wait_next = [&](int k) {      // own pieces of stage k + 1 landed (stage k + 2, if issued, may stay in flight)
+    if (k + 2 < nsteps) { if (grp == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto mem = [&](int k) {
+    const bf16_t* As = smem + (k % 3) * BUF;
+    const bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + frow;
+        af[kk][i] = *reinterpret_cast<const bf16x8*>(As + row * BK + (((kk * 4 + fkc) ^ (row & 7)) * 8));
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int row = wn * 80 + j * 16 + frow;
+        bfr[kk][j] = *reinterpret_cast<const bf16x8*>(Bs + row * BK + (((kk * 4 + fkc) ^ (row & 7)) * 8));
+      }
+    }
+  };
+  // MMA(k) also issues this wave's LDS-DMA pieces of stage `st` (one piece after every 5th MFMA), st < 0: none
+  auto mma = [&](int st) {
+    const bool doit = st >= 0 && st < nsteps;
+    const int buf = doit ? st % 3 : 0;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+        if (doit && kk * 4 + i < 7) { __builtin_amdgcn_sched_barrier(0); issue_piece(buf, kk * 4 + i); __builtin_amdgcn_sched_barrier(0); }
+      }
+  };
+  issue(0);
+  if (nsteps > 1) issue(1);
+  if (nsteps > 1) { if (grp == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 0) {
+    for (int k = 0; k < nsteps; ++k) {
+      mem(k);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      mma(k + 2);
+      wait_next(k);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_s_barrier();
+  } else {
+    if (2 < nsteps) issue(2);
+    __builtin_amdgcn_s_barrier();
+    for (int k = 0; k < nsteps; ++k) {
+      mem(k);
+      // own pieces of stage k + 1 landed; stage k + 2 (issued during MMA(k - 1) / the prologue) may stay in flight
+      if (k + 2 < nsteps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      mma(k + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  float result = 0.f;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) result += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  C[(size_t)blockIdx.x * 512 + tid] = result;
+}
+
+template <int PRIO>
+void run256pp2(const bf16_t* A, const bf16_t* W, float* C, int M, int N, int K, const char* what) {
+  constexpr int smem = 3 * (256 * BK + BN * BK) * 2;
+  hipFuncSetAttribute((const void*)k_gemm256pp2<PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  int grid = (M / 256) * (N / BN);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) k_gemm256pp2<PRIO><<<grid, 512, smem>>>(A, W, C, M, N, K);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  const int R = 20;
+  for (int i = 0; i < R; ++i) k_gemm256pp2<PRIO><<<grid, 512, smem>>>(A, W, C, M, N, K);
+  hipEventRecord(e1); hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double us = ms * 1e3 / R;
+  printf("%-44s prio=%d: %7.1f us  %6.0f TFLOP/s  (%.2f us per K step)  [%s]\n", what, PRIO, us, 2.0 * M * N * K / us / 1e6, us / (K / BK),
+         hipGetErrorString(hipGetLastError()));
+}
+
+
+// Ping-pong as above with v_mfma_f32_32x32x16_bf16 (full rate from ONE wave, which is what a ping-pong phase has per SIMD; 16x16x32
+// needs two): waves 8 (M) x 1, wave tile 32 x 160 = 1 x 5 tiles, 20 MFMAs + 24 ds_read_b128 per K step.
+template <int PRIO>
+void run256pp(const bf16_t* A, const bf16_t* W, float* C, int M, int N, int K, const char* what) {
+  constexpr int smem = 3 * (256 * BK + BN * BK) * 2;
+  hipFuncSetAttribute((const void*)k_gemm256pp<PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  int grid = (M / 256) * (N / BN);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) k_gemm256pp<PRIO><<<grid, 512, smem>>>(A, W, C, M, N, K);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  const int R = 20;
+  for (int i = 0; i < R; ++i) k_gemm256pp<PRIO><<<grid, 512, smem>>>(A, W, C, M, N, K);
+  hipEventRecord(e1); hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double us = ms * 1e3 / R;
+  printf("%-44s prio=%d: %7.1f us  %6.0f TFLOP/s  (%.2f us per K step)  [%s]\n", what, PRIO, us, 2.0 * M * N * K / us / 1e6, us / (K / BK),
+         hipGetErrorString(hipGetLastError()));
+}
+
+
+// Ping-pong as above with v_mfma_f32_32x32x16_bf16 (full rate from ONE wave, which is what a ping-pong phase has per SIMD; 16x16x32
+// needs two): waves 8 (M) x 1, wave tile 32 x 160 = 1 x 5 tiles, 20 MFMAs + 24 ds_read_b128 per K step.
+template <int PRIO>
+__global__ __launch_bounds__(512, 1) void k_gemm256pp32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, float* __restrict__ C,
+                                                        int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  constexpr int A_ELEMS = 256 * BK, B_ELEMS = BN * BK, BUF = A_ELEMS + B_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = N / BN;
+  const int tile = xcd_tile();
+  const int tn = tile % tiles_n, tm = tile / tiles_n;
+  const int m0 = tm * 256, n0 = tn * BN;
+  const int srow = lane >> 3;
+  const int nsteps = K / BK;
+  const bf16_t* a_ptr[4];
+  const bf16_t* w_ptr[3];
+  for (int i = 0; i < 4; ++i) {
+    int row = (i * 8 + w) * 8 + srow;
+    a_ptr[i] = A + (size_t)(m0 + row) * KW + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+  }
+  const int grp = w >> 2;
+  for (int i = 0; i < 3; ++i) {
+    int g = i * 8 + w; if (g > 19) g = 19;
+    int row = g * 8 + srow;
+    w_ptr[i] = W + (size_t)(n0 + row) * K + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+  }
+  int kcol = 0;
+  auto issue = [&](int buf) {
+    bf16_t* As = smem + buf * BUF;
+    bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[i],
+                                       (__attribute__((address_space(3))) void*)(As + (i * 8 + w) * 8 * BK), 16, 0, 0);
+      a_ptr[i] += BK;
+    }
+    if (++kcol == KW / BK) { kcol = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_ptr[i] -= KW; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i < 2 || grp == 0) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
+                                         (__attribute__((address_space(3))) void*)(Bs + (i * 8 + w) * 8 * BK), 16, 0, 0);
+        w_ptr[i] += BK;
+      }
+    }
+  };
+  f32x16 acc[5];
+  for (int j = 0; j < 5; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int l31 = lane & 31, lh = lane >> 5;
+  bf16x8 af[4], bfr[4][5];
+  auto wait_next = [&](int k) {
+    if (k + 2 < nsteps) { if (grp == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto mem = [&](int k) {
+    const bf16_t* As = smem + (k % 3) * BUF;
+    const bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int row = w * 32 + l31;
+      af[st] = *reinterpret_cast<const bf16x8*>(As + row * BK + (((st * 2 + lh) ^ ((row >> 1) & 7)) * 8));
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int brow = j * 32 + l31;
+        bfr[st][j] = *reinterpret_cast<const bf16x8*>(Bs + brow * BK + (((st * 2 + lh) ^ ((brow >> 1) & 7)) * 8));
+      }
+    }
+    if (k + 2 < nsteps) issue((k + 2) % 3);
+  };
+  auto mma = [&]() {
+    if (PRIO) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[st][j], af[st], acc[j], 0, 0, 0);
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+  issue(0);
+  if (nsteps > 1) issue(1);
+  if (nsteps > 1) { if (grp == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 0) {
+    for (int k = 0; k < nsteps; ++k) {
+      mem(k);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      mma();
+      wait_next(k);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __builtin_amdgcn_s_barrier();
+    for (int k = 0; k < nsteps; ++k) {
+      mem(k);
+      wait_next(k);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      mma();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  float result = 0.f;
+  for (int j = 0; j < 5; ++j) for (int r = 0; r < 16; ++r) result += acc[j][r];
+  C[(size_t)blockIdx.x * 512 + tid] = result;
+}
+
+template <int PRIO>
+void run256pp32(const bf16_t* A, const bf16_t* W, float* C, int M, int N, int K, const char* what) {
+  constexpr int smem = 3 * (256 * BK + BN * BK) * 2;
+  hipFuncSetAttribute((const void*)k_gemm256pp32<PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  int grid = (M / 256) * (N / BN);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) k_gemm256pp32<PRIO><<<grid, 512, smem>>>(A, W, C, M, N, K);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  const int R = 20;
+  for (int i = 0; i < R; ++i) k_gemm256pp32<PRIO><<<grid, 512, smem>>>(A, W, C, M, N, K);
+  hipEventRecord(e1); hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double us = ms * 1e3 / R;
+  printf("%-44s prio=%d: %7.1f us  %6.0f TFLOP/s  (%.2f us per K step)  [%s]\n", what, PRIO, us, 2.0 * M * N * K / us / 1e6, us / (K / BK),
+         hipGetErrorString(hipGetLastError()));
+}
+
 template <int STAGES>
 void run256(const bf16_t* A, const bf16_t* W, float* C, int M, int N, int K, const char* what) {
   constexpr int smem = STAGES * (256 * BK + BN * BK) * 2;
@@ -450,6 +870,11 @@ int main(int argc, char** argv) {
   run<1, 0, 0, 0, 1>(A, W, C, M, N, K, "32x32x16 pure MFMA, 1 block/CU");
   run256<2>(A, W, C, M, N, K, "256x160 tile, 8 waves 4x2, 1 block/CU");
   run256<3>(A, W, C, M, N, K, "256x160 tile, 8 waves 4x2, 1 block/CU");
+  run256pp<0>(A, W, C, M, N, K, "256x160 PING-PONG (2 groups of 4 waves)");
+  run256pp<1>(A, W, C, M, N, K, "256x160 PING-PONG (2 groups of 4 waves)");
+  run256pp2<0>(A, W, C, M, N, K, "256x160 PING-PONG, DMA issued inside MMA phase");
+  run256pp32<0>(A, W, C, M, N, K, "256x160 PING-PONG 32x32x16, waves 8x1");
+  run256pp32<1>(A, W, C, M, N, K, "256x160 PING-PONG 32x32x16, waves 8x1");
   run8<2>(A, W, C, M, N, K, "K8: 8 waves 128x160, 1 block/CU");
   run8<3>(A, W, C, M, N, K, "K8: 8 waves 128x160, 1 block/CU");
   run8<4>(A, W, C, M, N, K, "K8: 8 waves 128x160, 1 block/CU");
