@@ -993,7 +993,10 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   if (BN == 256) d.nwv = 8;
   // 3x3 convolutions: 256 x 160 tile with the ping-pong main loop, one workgroup per CU (GILL_GEMM_PP = 0 keeps the two
   // co-resident 128 x 160 workgroups)
-  if (BN == 160 && a.conv && gemm_conv_pingpong(a.M, a.N) && forced_bm == 0 && forced != 2) { d.nwv = 8; stages = 3; }
+  // (GILL_GEMM_PP_MINSTEPS = n keeps convs with fewer than n K steps per split on the 128-row tiles: measured 16 -> +0.2 %, 32 -> +0.5 %)
+  static const int pp_minsteps = env_int("GILL_GEMM_PP_MINSTEPS");
+  if (BN == 160 && a.conv && gemm_conv_pingpong(a.M, a.N) && forced_bm == 0 && forced != 2 &&
+      cdiv(a.K / 64, sk) >= pp_minsteps) { d.nwv = 8; stages = 3; }
   // GILL_GEMM_KT = 32: 4-deep ring of 32-wide stages on the 128-row tiles (see the kernel's KT note).  Off by default: measured
   // 7 % SLOWER on the denoise loop (608 -> 652 ms): the deeper prefetch does not pay for a barrier per 32-wide stage
   static const int forced_kt = env_int("GILL_GEMM_KT");
