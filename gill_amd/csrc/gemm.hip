@@ -1024,6 +1024,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     d.n_major = (forced_nm >= 0) ? forced_nm : (wel > ael && d.groups_n >= 8 ? 1 : 0);
   }
   dim3 grid(tiles_m * d.groups_n, sk, 1);
+  if (BN == 160 && d.nwv == 8) GILL_REQUIRE(d.npw == 1 && d.kt == 64, "internal: the ping-pong kernel walks one N tile per workgroup");
   if constexpr (BN == 256) {   // plain, unsplit GEMMs only (big_tile())
     if (a.act == ACT_GEGLU) GILL_TRY((gemm_launch_stages<BN, 0, 1>(d, grid, stages, s)));
     else if (a.out_mode == OUT_QKV) GILL_TRY((gemm_launch_stages<BN, 0, 3>(d, grid, stages, s)));
