@@ -100,6 +100,11 @@ def _conv_ref(x1, x2, w, bias, rowvec, resid, stride, ups):
   (2, 16, 16, 128, 0, 128, 2, 0),      # downsample
   (2, 8, 8, 128, 0, 128, 1, 1),        # fused nearest-2x upsample
   (3, 8, 8, 640, 640, 640, 1, 0),
+  # M % 256 == 0 and Cout % 160 == 0: the 256 x 160 ping-pong kernel (gemm_kernel<8,160,CONV,EPI,3>)
+  (4, 8, 8, 64, 0, 160, 1, 0),         # one N tile, 9 K steps (3 per split at sk 3)
+  (2, 16, 16, 128, 64, 160, 1, 0),     # two-source concat
+  (4, 32, 32, 128, 0, 160, 2, 0),      # stride 2
+  (2, 8, 8, 128, 0, 320, 1, 1),        # fused nearest-2x upsample
 ])
 def test_conv3x3(cuda, B, H, W, C1, C2, Cout, stride, ups):
   from gill_amd import ops
@@ -115,6 +120,31 @@ def test_conv3x3(cuda, B, H, W, C1, C2, Cout, stride, ups):
                       rowvec=rowvec.to(cuda), resid=resid.to(cuda), stride=stride, upsample=bool(ups), splitk=sk)
     assert tuple(out.shape) == tuple(ref.shape)
     assert _report(f"conv B{B} {H}x{W} {C1}+{C2}->{Cout} s{stride} u{ups} sk{sk}", out, ref) < 1.5e-2
+
+
+def test_conv3x3_pingpong_short_k_and_bit_identity(cuda):
+  """The ping-pong kernel with ONE K step per split (prologue / drain paths of its phase schedule), and its claim of bit-identical
+  outputs against the two-workgroups-per-CU kernel (same per-element summation order): the same seeded conv in two subprocesses,
+  GILL_GEMM_PP=0 and =1 (the switch is read once per process), must print the same digest."""
+  import os, subprocess, sys
+  from gill_amd import ops
+  x = _bf(_rnd((1, 16, 16, 64), 30)); w = _rnd((320, 64, 3, 3), 31, 0.05)
+  ref = _conv_ref(x, None, w, None, None, None, 1, 0)
+  out = ops.conv3x3(x.to(cuda), w.to(cuda), splitk=9)
+  assert _report("conv 16x16 64->320 sk9 (1 K step per split)", out, ref) < 1.5e-2
+  code = ("import hashlib, torch, sys; sys.path.insert(0, %r); from gill_amd import ops, synth\n"
+          "x = synth.normal('pp_x', (2, 32, 32, 320), 1).bfloat16().cuda(); w = synth.normal('pp_w', (640, 320, 3, 3), 2, std=0.05).cuda()\n"
+          "b = synth.normal('pp_b', (640,), 3).cuda()\n"
+          "h = hashlib.sha256()\n"
+          "for sk in (1, 2, 5):\n"
+          "  h.update(ops.conv3x3(x, w, b, splitk=sk).cpu().view(torch.int16).numpy().tobytes())\n"
+          "print('DIGEST', h.hexdigest())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  digests = []
+  for pp in ("0", "1"):
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GILL_GEMM_PP=pp), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0])
+  assert digests[0] == digests[1], digests
 
 
 # ---------------------------------------------------------------- attention
