@@ -173,12 +173,12 @@ def kernel_rooflines(dev):
 
   x = torch.randn(8, 64, 64, 320, device=dev).bfloat16()
   w = torch.randn(320, 320, 3, 3, device=dev) * 0.02
-  timed(lambda: ops.conv3x3(x, w), 2.0 * 8 * 4096 * 320 * 2880, "gemm_kernel<160,1,0,2>: 3x3 conv 320->320 @ 64x64 x 8 (implicit GEMM)")
+  timed(lambda: ops.conv3x3(x, w), 2.0 * 8 * 4096 * 320 * 2880, "gemm_kernel<8,160,1,0,3>: 3x3 conv 320->320 @ 64x64 x 8 (implicit GEMM, 256x160 ping-pong tile)")
   q = torch.randn(8, 4096, 320, device=dev).bfloat16()
   timed(lambda: ops.attention(q, q, q, 8), 4.0 * 8 * 8 * 4096 * 4096 * 40, "attention_kernel<48>: self-attention N=4096, 8 heads x d=40, x 8 (incl. head re-layout wrappers)")
   a = torch.randn(32768, 1280, device=dev).bfloat16()
   wl = (torch.randn(320, 1280, device=dev) * 0.03).bfloat16()
-  timed(lambda: ops.gemm(a, wl), 2.0 * 32768 * 320 * 1280, "gemm_kernel<160,0,0,2>: GEMM 32768 x 320 x 1280 (FF out projection)")
+  timed(lambda: ops.gemm(a, wl), 2.0 * 32768 * 320 * 1280, "gemm_kernel<4,160,0,0,2>: GEMM 32768 x 320 x 1280 (level-0 feed-forward output shape)")
   return out
 
 

@@ -1,5 +1,8 @@
 """MFMA-pipe busy fraction per kernel family from one rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass.
   python tools/pmc_mfma.py <dir> [out.md]
+Collect with eager UNet forwards:  GILL_NO_GRAPH=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d <dir> -o m --output-format csv --
+python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pmc   (SQ counters over hipGraph replays did not finish within minutes on
+ROCm 7.2: three attempts of 200 s each, with and without the ping-pong kernel; the eager run takes 7 s and launches the same kernels)
 busy = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (1024 SIMDs x sum(GRBM_GUI_ACTIVE) / 8 XCDs)   (profiles/r01_pmc_conv_L0.md: the SQ counter is
 in cycles summed over SIMDs, GRBM_GUI_ACTIVE is summed over the 8 XCDs)."""
 import csv, glob, sys, collections, re
