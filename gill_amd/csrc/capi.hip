@@ -75,8 +75,7 @@ extern "C" int gill_op_conv3x3(const void* x1, int C1, const void* x2, int C2, c
   DevBuf wr, ws;
   GILL_TRY(wr.alloc(sizeof(bf16_t) * (size_t)Cout * 9 * Cin));
   // K order as the engines choose it (GILL_CONV_KORDER = 0 | 1 forces tap-major / chunk-major for tests and tools)
-  static const int korder = [] { const char* v = getenv("GILL_CONV_KORDER"); return v ? atoi(v) : -1; }();
-  const int chunked = korder >= 0 ? korder : (conv_k_chunked(IH * IW, Cin, Cout) ? 1 : 0);
+  const int chunked = conv_k_chunked(IH * IW, Cin, Cout) ? 1 : 0;
   if (chunked) GILL_TRY(conv_weight_relayout_chunked_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wr.p, s));
   else GILL_TRY(conv_weight_relayout_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wr.p, s));
   GemmArgs g;

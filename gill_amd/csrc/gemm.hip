@@ -904,6 +904,12 @@ bool gemm_conv_pingpong(int rows_multiple_of, int Cout) {
   return pp_env != 0 && rows_multiple_of % 256 == 0 && Cout % 160 == 0;
 }
 
+bool conv_k_chunked(int HW, int Cin, int Cout) {
+  static const int korder = [] { const char* v = getenv("GILL_CONV_KORDER"); return v ? atoi(v) : -1; }();
+  if (korder >= 0) return korder != 0;
+  return HW >= 4096 && (int64_t)HW * Cin * 2 > (int64_t)4 << 20 && !gemm_conv_pingpong(HW, Cout);
+}
+
 int gemm_pick_splitk(int M, int N, int K, int act, bool plain) {
   if (act == ACT_GEGLU) return 1;
   const int bn = (N % 160 == 0) ? 160 : 128;

@@ -481,3 +481,32 @@ def test_safety_checker_vs_oracle(cuda):
   pipe.safety_checker = None
   r = pipe(prompt_embeds=cond, latents=lat0, num_inference_steps=3, output_type="np")
   assert r.nsfw_content_detected is None and float(np.abs(r.images).max()) > 0
+
+
+@SLOW
+def test_pingpong_conv_kernel_leaves_the_unet_bit_identical(cuda):
+  """gemm_kernel<8,160,CONV,EPI,3> (256 x 160 ping-pong tile) against the 128-row kernel it replaced, through the whole SD-1.5
+  UNet loop (fused GroupNorm statistics, time-embedding rows, residuals, fused shortcuts, split-K partials, stride-2 and
+  upsampling convs): same per-element summation order (the K order is pinned to tap-major for both runs: the 128-row kernel
+  would otherwise pick chunk-major for the largest level-0 convs), so the latents of a 3-step CFG run must have the same digest
+  with GILL_GEMM_PP=1 and =0 (the switches are read once per process, hence two subprocesses)."""
+  import subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  code = ("import hashlib, sys, torch; sys.path.insert(0, %r)\n"
+          "from gill_amd import synth\n"
+          "from gill_amd.sd import GillSDPipeline\n"
+          "cfg = synth.UNetConfig.sd15()\n"
+          "sd = {k: v.bfloat16() for k, v in synth.unet_state_dict(cfg, seed=41).items()}\n"
+          "uncond = synth.uncond_context(cfg.ctx_len, cfg.cross_attention_dim, seed=41)\n"
+          "pipe = GillSDPipeline(sd, cfg, uncond, 'cuda:0', max_batch=4)\n"
+          "cond = synth.normal('pp_cond', (2, 77, 768), 42).bfloat16()\n"
+          "lat0 = synth.initial_latents(2, 4, 64, seed=11)\n"
+          "lat = pipe(prompt_embeds=cond, latents=lat0, guidance_scale=7.5, num_inference_steps=3, output_type='latent').images\n"
+          "assert torch.isfinite(lat).all()\n"
+          "print('DIGEST', hashlib.sha256(lat.float().cpu().numpy().tobytes()).hexdigest())\n") % root
+  digests = []
+  for pp in ("0", "1"):
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GILL_GEMM_PP=pp, GILL_CONV_KORDER="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0])
+  assert digests[0] == digests[1], digests
