@@ -3,7 +3,8 @@
 //   C[M,N] = epilogue(alpha * A[M,K] . W[N,K]^T)
 //
 // Tile: 128 x BN x 64 per 256-thread workgroup (4 waves as 2x2, each wave 64 x BN/2 via
-// v_mfma_f32_16x16x32_bf16).  Both operands are K-contiguous, so both LDS tiles are
+// v_mfma_f32_16x16x32_bf16), two workgroups per CU; the 3x3 convolutions run on a 256 x 160 tile of 8 waves, one workgroup
+// per CU, 3-deep ring, with a ping-pong main loop (see "PING-PONG" in the kernel).  Both operands are K-contiguous, so both LDS tiles are
 // [rows][64 bf16] = 128 B rows filled by direct-to-LDS DMA (global_load_lds_dwordx4: one
 // wave instruction = 1 KiB = 8 tile rows) into a 2-deep ring: the DMA of K step i+1 flies while
 // step i is multiplied.  The DMA destination is lane-linear, so the bank-conflict swizzle
@@ -149,7 +150,8 @@ __device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& 
 
 // NWV: waves per workgroup.  4 -> 128-row tile (waves 2 x 2).  2 -> 64-row tile (waves 1 x 2) for problems with so few
 // 128-row tiles that half the CUs would idle (UNet level 2-3 projections: M = 2048 / 512).
-// 8 -> 256-row tile (waves 4 x 2, one workgroup per CU): with BN = 256 a K step fetches 64 KiB for 8.4 MFLOP — half the
+// 8 -> 256-row tile (waves 4 x 2, one workgroup per CU).  BN = 160, STAGES = 3: the convolutions' ping-pong kernel.
+// BN = 256 (GILL_GEMM_BIG only): a K step fetches 64 KiB for 8.4 MFLOP — half the
 // bytes per FLOP of the 128 x 160 tile, whose 36.8 KiB per 2.6 MFLOP is 89 % of the 64 B/clk a CU can pull from L2 at the
 // MFMA peak — for the wide plain GEMMs (GEGLU, QKV) with enough 256 x 256 tiles to fill the chip.
 // KT: K elements per ring stage (64 | 32).  With a 2-deep ring the loads of stage t+1 can only be issued after the barrier of
