@@ -880,6 +880,11 @@ static inline int tile_width(const GemmArgs& a) {
   // measured on MI355X (profiles/r01_sweep_gemm_tiles.md): the 128x160 tile (5 N sub-tiles per wave: more MFMAs per LDS
   // byte) beats 128x128 by 15-40 % on every UNet width, all of which are multiples of 160
   if (bn != 128 && bn != 160) bn = (a.N % 160 == 0) ? 160 : 128;
+  // ... except on the 64-row tile (plain GEMMs with few tiles, see gemm_launch_bn): 64 x 128 needs 48 KiB of LDS, i.e. three
+  // workgroups (six waves) per CU instead of two (four) — loop 587.3 -> 584.7 ms (GILL_GEMM_BN64 = 160 restores 64 x 160)
+  static const int bn64 = [] { const char* v = getenv("GILL_GEMM_BN64"); return v ? atoi(v) : 128; }();
+  if (bn64 == 128 && forced_bn == 0 && !a.conv && a.splitk <= 1 && a.N % 128 == 0 && a.out_mode != OUT_QKV && !a.gn_stats &&
+      (int64_t)cdiv(a.M, 128) * cdiv(a.N, 160) < 300 && a.M > 64) bn = 128;
   return bn;
 }
 int gemm_row_planes(const GemmArgs& a) {
