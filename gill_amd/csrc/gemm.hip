@@ -55,6 +55,7 @@ struct GemmDev {
   int npw;           // N tiles one workgroup walks back to back (plain GEMM, no split-K): the LDS ring keeps flowing
   int groups_n;      // cdiv(tiles_n, npw)
   int nwv;           // waves per workgroup: 4 (128-row tile) or 2 (64-row tile)
+  int mi;            // 16-row M sub-tiles per wave: 4, or 2 (nwv = 4: the 64-row tile on four waves)
   int kt;            // K elements per ring stage: 64 (2-deep ring) or 32 (4-deep ring, 128-row tiles only)
   int n_major;       // 1: consecutive tile ids walk M first (an XCD's contiguous id range = a range of N tiles over every M tile)
   int tiles_m;
@@ -159,9 +160,12 @@ __device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& 
 // 4-deep ring of half-size stages: loads are issued three stages (1.5 K steps of 64) ahead and waited for with counted
 // s_waitcnt vmcnt(N), at the price of a barrier per 32-wide stage.  Measured: that price is higher than the gain (the
 // launcher keeps KT = 64 unless GILL_GEMM_KT = 32).
-template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT>
-__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const GemmDev d) {
-  constexpr int BM = NWV * 32;
+// MI: 16-row M sub-tiles per wave (4 | 2).  MI = 2 with NWV = 4 is a 64-row tile on FOUR waves (2 x 2, wave tile 32 x BN/2) for the
+// small plain GEMMs: the same 48 KiB of LDS as the 2-wave 64 x 128 tile (three workgroups per CU), twice the waves per CU.
+template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT, int MI>
+__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void gemm_kernel(const GemmDev d) {
+  constexpr int BM = (NWV / 2) * MI * 16;
+  static_assert(MI == 4 || (MI == 2 && NWV == 4 && CONV == 0 && STAGES == 2 && KT == 64), "MI = 2: 4-wave 64-row plain tile only");
   constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
   constexpr bool PP = (NWV == 8 && BN == 160 && STAGES == 3 && KT == 64);   // ping-pong main loop (see there)
   static_assert(KT == 64 || KT == 32, "stage depth");
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
     issue_post();
   };
 
-  f32x4 acc[4][NT];
+  f32x4 acc[MI][NT];
 
   const int wm = w >> 1, wn = w & 1;
   const int frow = lane & 15;       // fragment row within a 16-row sub-tile
@@ -403,12 +407,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < total_steps) issue(s);
   // folded LayerNorm (GEGLU / QKV epilogues): the row factors are loaded here, under the first tile's DMA latency
-  float ln_rr[4] = {1.f, 1.f, 1.f, 1.f}, ln_rm[4] = {0.f, 0.f, 0.f, 0.f};
+  float ln_rr[4] = {1.f, 1.f, 1.f, 1.f}, ln_rm[4] = {0.f, 0.f, 0.f, 0.f};   // (first MI entries used)
   if constexpr (EPI == 1 || EPI == 3) {
     if (p.ln_stats) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + frow;
+      for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (MI * 16) + i * 16 + frow;
         if (m < p.M) ln_row_factors(p, m, ln_rr[i], ln_rm[i]);
       }
     }
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
   int flat = 0;          // K steps consumed over all N tiles of this workgroup
   for (int t = 0; t < ntl; ++t, n0 += BN) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if constexpr (PP) {
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
     // 128 x 160 workgroups (tools/ubench/gemm_loop.hip).
     const int grp = w >> 2;
     int issued = total_steps < STAGES - 1 ? total_steps : STAGES - 1;     // stages this wave has issued so far
-    bf16x8 af[KK][4];
+    bf16x8 af[KK][MI];
     bf16x8 bfr[KK][NT];
     auto landed = [&](int k) {         // own pieces of stage k have landed
       if (k < nsteps) wait_vm((issued - 1 - k) * lw);
@@ -443,8 +447,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = wm * 64 + i * 16 + frow;
+        for (int i = 0; i < MI; ++i) {
+          const int row = wm * (MI * 16) + i * 16 + frow;
           af[kk][i] = *reinterpret_cast<const bf16x8*>(As + row * KT + (((kk * 4 + fkc) ^ SWZ(row)) * 8));
         }
 #pragma unroll
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
@@ -514,12 +518,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
     // fragment sets live), and sched_barriers pin that order.  Left alone, the compiler recycles one 4-register A fragment
     // for the second k step (read -> s_waitcnt lgkmcnt(0) -> 5 MFMAs, three times over): every one of those waits exposes a
     // full LDS round trip.
-    bf16x8 af[KK][4];
+    bf16x8 af[KK][MI];
     bf16x8 bfr[KK][NT];
     auto frag_load = [&](int kk) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = wm * 64 + i * 16 + frow;
+      for (int i = 0; i < MI; ++i) {
+        const int row = wm * (MI * 16) + i * 16 + frow;
         const int slot = (kk * 4 + fkc) ^ SWZ(row);
         af[kk][i] = *reinterpret_cast<const bf16x8*>(As + row * KT + slot * 8);
       }
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
@@ -550,12 +554,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
   }
 
   // ---- epilogue.  acc[i][j][r]: m = m0 + wm*64 + i*16 + (lane&15), n = n0 + wn*BN/2 + j*16 + (lane>>4)*4 + r
-  const int mrow = m0 + wm * 64 + frow;
+  const int mrow = m0 + wm * (MI * 16) + frow;
   const int ncol = n0 + wn * (BN / 2) + fkc * 4;
   if constexpr (EPI == 2) {
     float* ws = p.ws + (size_t)z * p.M * p.N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const int m = mrow + i * 16;
       if (m >= p.M) continue;
 #pragma unroll
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
       const float4 sv = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + nv) : make_float4(0, 0, 0, 0);
       const float4 sg = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + ng) : make_float4(0, 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MI; ++i) {
         const int m = mrow + i * 16;
         if (m >= p.M) continue;
         const float o0 = (acc[i][j][0] * rr[i] - rm[i] * sv.x + bv.x) * gelu_erf(acc[i][j + 1][0] * rr[i] - rm[i] * sg.x + bg.x);
@@ -593,10 +597,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
     }
   } else if constexpr (EPI == 3) {
     // head-major scatter; all divisions hoisted: per-row (b, t) once, per-column (segment, head, dd) once
-    int rq[4], rk[4], rv[4]; bool mok[4];
-    float rr[4], rm[4];
+    int rq[MI], rk[MI], rv[MI]; bool mok[MI];
+    float rr[MI], rm[MI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const int m = mrow + i * 16;
       mok[i] = m < p.M;
       rr[i] = p.ln_stats ? ln_rr[i] : p.alpha; rm[i] = ln_rm[i];
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
       const float4 bz = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
       const float4 cs = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + n) : make_float4(0, 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MI; ++i) {
         if (!mok[i]) continue;
         float v0 = acc[i][j][0] * rr[i] - rm[i] * cs.x + bz.x, v1 = acc[i][j][1] * rr[i] - rm[i] * cs.y + bz.y;
         float v2 = acc[i][j][2] * rr[i] - rm[i] * cs.z + bz.z, v3 = acc[i][j][3] * rr[i] - rm[i] * cs.w + bz.w;
@@ -641,9 +645,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
     }
   } else {
     // row-major epilogue; per-row offsets (incl. the batch index of the row vector) hoisted out of the column loop
-    size_t crow[4], rrow[4]; int vrow[4]; bool mok[4];
+    size_t crow[MI], rrow[MI]; int vrow[MI]; bool mok[MI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const int m = mrow + i * 16;
       mok[i] = m < p.M;
       crow[i] = (size_t)m * p.ldc;
@@ -664,7 +668,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
       const float4 bz = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
       float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MI; ++i) {
         if (!mok[i]) continue;
         float v[4] = {acc[i][j][0] * p.alpha + bz.x, acc[i][j][1] * p.alpha + bz.y, acc[i][j][2] * p.alpha + bz.z,
                       acc[i][j][3] * p.alpha + bz.w};
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : 2) void gemm_kernel(const 
       // a row's BN/2 columns of this wave sit in the 4 lanes {frow, frow+16, frow+32, frow+48}; plane = (N tile, wave column)
       float* plane = p.row_stats + (size_t)((n0 / BN) * 2 + wn) * p.M * 2;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MI; ++i) {
         rws[i] += __shfl_xor(rws[i], 16, 64); rwq[i] += __shfl_xor(rwq[i], 16, 64);
         rws[i] += __shfl_xor(rws[i], 32, 64); rwq[i] += __shfl_xor(rwq[i], 32, 64);
         if (fkc == 0 && mok[i]) *reinterpret_cast<float2*>(plane + (size_t)(mrow + i * 16) * 2) = make_float2(rws[i], rwq[i]);
@@ -883,7 +887,7 @@ static inline int tile_width(const GemmArgs& a) {
   // ... except on the 64-row tile (plain GEMMs with few tiles, see gemm_launch_bn): 64 x 128 needs 48 KiB of LDS, i.e. three
   // workgroups (six waves) per CU instead of two (four) — loop 587.3 -> 584.7 ms (GILL_GEMM_BN64 = 160 restores 64 x 160)
   static const int bn64 = [] { const char* v = getenv("GILL_GEMM_BN64"); return v ? atoi(v) : 128; }();
-  if (bn64 == 128 && forced_bn == 0 && !a.conv && a.splitk <= 1 && a.N % 128 == 0 && a.out_mode != OUT_QKV && !a.gn_stats &&
+  if (bn64 == 128 && forced_bn == 0 && !a.conv && a.splitk <= 1 && a.N % 128 == 0 && !a.gn_stats &&
       (int64_t)cdiv(a.M, 128) * cdiv(a.N, 160) < 300 && a.M > 64) bn = 128;
   return bn;
 }
@@ -950,16 +954,16 @@ int gemm_splitk_reduce_launch(const GemmArgs& a, hipStream_t s) {
   return 0;
 }
 
-template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT = BK>
+template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT = BK, int MI = 4>
 static int gemm_launch_inst(const GemmDev& d, dim3 grid, hipStream_t s) {
   static bool attr_set = false;
-  constexpr int smem = STAGES * (NWV * 32 * KT + BN * KT) * (int)sizeof(bf16_t);
+  constexpr int smem = STAGES * ((NWV / 2) * MI * 16 * KT + BN * KT) * (int)sizeof(bf16_t);
   if (!attr_set) {
-    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<NWV, BN, CONV, EPI, STAGES, KT>,
+    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<NWV, BN, CONV, EPI, STAGES, KT, MI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<NWV, BN, CONV, EPI, STAGES, KT>), grid, dim3(NWV * 64), smem, s, d);
+  hipLaunchKernelGGL((gemm_kernel<NWV, BN, CONV, EPI, STAGES, KT, MI>), grid, dim3(NWV * 64), smem, s, d);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -972,6 +976,9 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, int stages, hipStream
   } else {
     if constexpr (CONV == 0 && EPI != 2) {
       if (d.nwv == 2) return gemm_launch_inst<2, BN, CONV, EPI, 2>(d, grid, s);
+    }
+    if constexpr (CONV == 0 && (EPI == 0 || EPI == 3) && BN == 128) {
+      if (d.nwv == 4 && d.mi == 2) return gemm_launch_inst<4, BN, CONV, EPI, 2, BK, 2>(d, grid, s);   // 64-row tile on four waves
     }
     if constexpr (BN == 160 && CONV != 0) {
       if (d.nwv == 8) return gemm_launch_inst<8, BN, CONV, EPI, 3>(d, grid, s);     // ping-pong 256 x 160 tile
@@ -1001,7 +1008,12 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   static const int forced_bm = env_int("GILL_GEMM_BM");
   d.nwv = 4;
   if (!a.conv && sk == 1 && stages == 2 && (int64_t)cdiv(a.M, 128) * d.tiles_n < 300 && a.M > 64) d.nwv = 2;   // measured: < 300 +0.3 %, < 520 -3 % end to end
-  if (forced_bm == 128) d.nwv = 4;
+  d.mi = 4;
+  // the 64-row tile on FOUR waves (2 x 2, wave tile 32 x 64) where its width is 128: same LDS, twice the waves per CU —
+  // loop 580.4 -> 576.3 ms, 2048 x 1280 x 1280 19.8 -> 17.3 us (GILL_GEMM_MI2 = 0: two waves of 64 x 64)
+  static const int mi2 = [] { const char* v = getenv("GILL_GEMM_MI2"); return v ? atoi(v) : 1; }();
+  if (mi2 && d.nwv == 2 && BN == 128 && a.act != ACT_GEGLU && !a.gn_stats) { d.nwv = 4; d.mi = 2; }
+  if (forced_bm == 128) { d.nwv = 4; d.mi = 4; }
   if (forced_bm == 64 && !a.conv && sk == 1 && stages == 2) d.nwv = 2;
   if (BN == 256) d.nwv = 8;
   // 3x3 convolutions: 256 x 160 tile with the ping-pong main loop, one workgroup per CU (GILL_GEMM_PP = 0 keeps the two
@@ -1016,7 +1028,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   d.kt = (forced_kt == 32 && d.nwv == 4 && stages == 2) ? 32 : 64;
   d.ksteps = a.K / d.kt;
   d.ksteps_per_split = cdiv(d.ksteps, sk);
-  const int tiles_m = cdiv(a.M, d.nwv * 32);
+  const int tiles_m = cdiv(a.M, (d.nwv / 2) * d.mi * 16);
   // Short-K GEMMs with many N tiles (GEGLU, QKV: K = 320..1280, 6..80 N tiles) spend most of a tile's life in the first-load
   // latency and the epilogue.  Let one workgroup walk `npw` N tiles back to back instead: the ring is staged across tile
   // boundaries, so the loads of tile t+1 fly during the epilogue of tile t.  Keep ~2 workgroups per CU.
