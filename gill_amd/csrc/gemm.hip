@@ -1007,6 +1007,8 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   // 64-row tiles for plain GEMMs whose 128-row tiling leaves CUs without a tile (GILL_GEMM_BM = 64 | 128 forces it)
   static const int forced_bm = env_int("GILL_GEMM_BM");
   d.nwv = 4;
+  // (tile_width() counts 128 x 160 tiles when it hands these GEMMs BN = 128, this rule counts 128 x 128 tiles: an 8192 x 640 GEMM
+  // — 256 vs 320 — therefore lands on the 4-wave 128 x 128 tile, not the 64-row one; measured better that way: 567.8 vs 575.5 ms)
   if (!a.conv && sk == 1 && stages == 2 && (int64_t)cdiv(a.M, 128) * d.tiles_n < 300 && a.M > 64) d.nwv = 2;   // measured: < 300 +0.3 %, < 520 -3 % end to end
   d.mi = 4;
   // the 64-row tile on FOUR waves (2 x 2, wave tile 32 x 64) where its width is 128: same LDS, twice the waves per CU —
