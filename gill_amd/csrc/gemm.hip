@@ -884,6 +884,10 @@ static inline int tile_width(const GemmArgs& a) {
   // measured on MI355X (profiles/r01_sweep_gemm_tiles.md): the 128x160 tile (5 N sub-tiles per wave: more MFMAs per LDS
   // byte) beats 128x128 by 15-40 % on every UNet width, all of which are multiples of 160
   if (bn != 128 && bn != 160) bn = (a.N % 160 == 0) ? 160 : 128;
+  // ... and except for the head-major scatter epilogue (QKV / to_q), whose columns fall into 48..160-wide heads: 128-wide tiles
+  // measured 579.3 -> 576.3 ms on the loop (GILL_GEMM_QKV128 = 0 restores 160)
+  static const int qkv128 = [] { const char* v = getenv("GILL_GEMM_QKV128"); return v ? atoi(v) : 1; }();
+  if (qkv128 && forced_bn == 0 && !a.conv && a.out_mode == OUT_QKV && a.N % 128 == 0) bn = 128;
   // ... except on the 64-row tile (plain GEMMs with few tiles, see gemm_launch_bn): 64 x 128 needs 48 KiB of LDS, i.e. three
   // workgroups (six waves) per CU instead of two (four) — loop 587.3 -> 584.7 ms (GILL_GEMM_BN64 = 160 restores 64 x 160)
   static const int bn64 = [] { const char* v = getenv("GILL_GEMM_BN64"); return v ? atoi(v) : 128; }();
