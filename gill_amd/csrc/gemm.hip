@@ -858,7 +858,13 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
 }
 
 // width of the split-K reducer's blocks: 80 when the fused GroupNorm bins do not divide 64 (UNet: 5 / 10 / 20 / 40 channels)
-static inline int reduce_width(const GemmArgs& a) { return (a.gn_stats && 64 % a.gn_cg != 0) ? 80 : 64; }
+// (160 where N allows: a block row is then 640 B = five whole 128-B lines of a partial slice; 80-wide blocks read 320-B pieces, every
+// other one straddling a line.  GILL_REDUCE_W160 = 0 keeps 80)
+static inline int reduce_width(const GemmArgs& a) {
+  static const int w160 = [] { const char* v = getenv("GILL_REDUCE_W160"); return v ? atoi(v) : 1; }();
+  if (a.gn_stats && 64 % a.gn_cg != 0) return (w160 && a.N % 160 == 0 && 160 % a.gn_cg == 0) ? 160 : 80;
+  return 64;
+}
 // rows per block of the reducer: 64 for large outputs, 16 when there would be too few blocks to pull the partials
 static inline int reduce_rows(const GemmArgs& a) {
   return ((int64_t)cdiv(a.N, reduce_width(a)) * cdiv(a.M, 64) >= 1024) ? 64 : 16;
@@ -950,7 +956,9 @@ int gemm_splitk_reduce_launch(const GemmArgs& a, hipStream_t s) {
   GILL_REQUIRE(a.splitk > 1 && a.ws != nullptr, "split-K reducer: no partials");
   const int rw = reduce_width(a), rr = reduce_rows(a);
   const dim3 rg(cdiv(a.N, rw), cdiv(a.M, rr));
-  if (rw == 80 && rr == 64) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<80, 4>), rg, dim3(320), 0, s, a);
+  if (rw == 160 && rr == 64) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<160, 4>), rg, dim3(640), 0, s, a);
+  else if (rw == 160) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<160, 1>), rg, dim3(640), 0, s, a);
+  else if (rw == 80 && rr == 64) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<80, 4>), rg, dim3(320), 0, s, a);
   else if (rw == 80) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<80, 1>), rg, dim3(320), 0, s, a);
   else if (rr == 64) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<64, 4>), rg, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((gemm_splitk_reduce_kernel<64, 1>), rg, dim3(256), 0, s, a);
