@@ -165,7 +165,9 @@ __device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& 
 template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT, int MI>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void gemm_kernel(const GemmDev d) {
   constexpr int BM = (NWV / 2) * MI * 16;
-  static_assert(MI == 4 || (MI == 2 && NWV == 4 && CONV == 0 && STAGES == 2 && KT == 64), "MI = 2: 4-wave 64-row plain tile only");
+  static_assert(MI == 4 || (MI == 2 && NWV == 4 && CONV == 0 && STAGES == 2 && KT == 64) ||
+                    (MI == 2 && NWV == 8 && BN == 160 && CONV != 0 && STAGES == 3 && KT == 64),
+                "MI = 2: the 4-wave 64-row plain tile, or the 128 x 160 ping-pong conv tile (8 waves of 32 x 80)");
   constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
   constexpr bool PP = (NWV == 8 && BN == 160 && STAGES == 3 && KT == 64);   // ping-pong main loop (see there)
   static_assert(KT == 64 || KT == 32, "stage depth");
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
     // The 64 rows of a wave belong to one slab of one sample (rows_per_batch % 64 == 0).  Fixed-order reduction: 4 rows in the
     // lane, 16 row lanes by xor-shuffles, one LDS cell per (row half, column) written once (the tile ring is dead by now),
     // then one thread per (row half, bin, moment) adds the bin's gn_cg columns and stores the partial: no atomics anywhere.
-    float* red = reinterpret_cast<float*>(smem);     // [2 moments][BM / 64 row slabs][BN]
+    float* red = reinterpret_cast<float*>(smem);     // [2 moments][NWV / 2 wave rows][BN]
     if (p.gn_stats) __syncthreads();                 // every wave is done reading the ring
     float rws[4] = {0.f, 0.f, 0.f, 0.f}, rwq[4] = {0.f, 0.f, 0.f, 0.f};   // row sums for a following (folded) LayerNorm
 #pragma unroll
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
           if (frow == 0) {
             const int c = wn * (BN / 2) + j * 16 + fkc * 4 + e;
             red[wm * BN + c] = a;
-            red[(BM / 64) * BN + wm * BN + c] = q;
+            red[(NWV / 2) * BN + wm * BN + c] = q;
           }
         }
       }
@@ -738,9 +740,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
         const int mfirst = m0 + half * 64;
         const int bin = n0 / p.gn_cg + lb;
         if (mfirst < p.M && bin < p.gn_groups) {
-          const float* src = red + which * (BM / 64) * BN + half * BN + lb * p.gn_cg;
+          // a 64-row slab holds 64 / (MI * 16) wave rows (1, or 2 on the MI = 2 tiles): added in wave-row order, then column order
+          constexpr int GPS = 64 / (MI * 16);
           float a = 0.f;
-          for (int c = 0; c < p.gn_cg; ++c) a += src[c];
+#pragma unroll
+          for (int g = 0; g < GPS; ++g) {
+            const float* src = red + which * (NWV / 2) * BN + (half * GPS + g) * BN + lb * p.gn_cg;
+            for (int c = 0; c < p.gn_cg; ++c) a += src[c];
+          }
           const int b = mfirst / p.rows_per_batch;
           const int slab = (mfirst - b * p.rows_per_batch) / GN_SLAB_ROWS;
           const int nslab = p.rows_per_batch / GN_SLAB_ROWS;
@@ -920,6 +927,10 @@ static int env_int(const char* name) {
 
 // 3x3 convolutions whose row count is a multiple of 256 and whose width tiles by 160 run on the 256 x 160 ping-pong kernel
 // (GILL_GEMM_PP = 0: two co-resident 128 x 160 workgroups instead, the round-1 structure)
+static bool pp128_on() {
+  static const int v = [] { const char* e = getenv("GILL_GEMM_PP128"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
 bool gemm_conv_pingpong(int rows_multiple_of, int Cout) {
   static const int pp_env = [] { const char* v = getenv("GILL_GEMM_PP"); return v ? atoi(v) : 1; }();
   return pp_env != 0 && rows_multiple_of % 256 == 0 && Cout % 160 == 0;
@@ -937,6 +948,15 @@ int gemm_pick_splitk(int M, int N, int K, int act, bool plain) {
   const int tiles = cdiv(M, BM_HOST) * cdiv(N, bn);
   const int ksteps = K / BK;
   if (tiles >= 384 || ksteps < 8) return 1;
+  {   // convs that gemm_launch_bn puts on 128 x 160 ping-pong tiles: one workgroup per CU, 256 slots
+    if (pp128_on() && !plain && gemm_conv_pingpong(M, N) && tiles <= 256 && M % 128 == 0) {
+      int s = (256 + tiles / 2) / tiles;
+      const int min_steps = (M <= 256 || tiles < 64) ? 4 : 24;
+      if (s > ksteps / min_steps) s = ksteps / min_steps;
+      if (s > 16) s = 16;
+      return s < 1 ? 1 : s;
+    }
+  }
   // plain GEMMs with 150..383 128-row tiles run on 64-row tiles instead (gemm_launch: >= 300 workgroups, no partials):
   // measured 8192 x 640 x 3200 unsplit 49.1 us, two-way split + reducer 54.6 us
   if (plain && tiles >= 150 && tiles < 300 && M > 64) return 1;
@@ -993,6 +1013,7 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, int stages, hipStream
       if (d.nwv == 4 && d.mi == 2) return gemm_launch_inst<4, BN, CONV, EPI, 2, BK, 2>(d, grid, s);   // 64-row tile on four waves
     }
     if constexpr (BN == 160 && CONV != 0) {
+      if (d.nwv == 8 && d.mi == 2) return gemm_launch_inst<8, BN, CONV, EPI, 3, BK, 2>(d, grid, s);   // ping-pong 128 x 160 tile
       if (d.nwv == 8) return gemm_launch_inst<8, BN, CONV, EPI, 3>(d, grid, s);     // ping-pong 256 x 160 tile
     }
     if (stages == 3) return gemm_launch_inst<4, BN, CONV, EPI, 3>(d, grid, s);
@@ -1035,7 +1056,14 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   // (GILL_GEMM_PP_MINSTEPS = n keeps convs with fewer than n K steps per split on the 128-row tiles: measured 16 -> +0.2 %, 32 -> +0.5 %)
   static const int pp_minsteps = env_int("GILL_GEMM_PP_MINSTEPS");
   if (BN == 160 && a.conv && gemm_conv_pingpong(a.M, a.N) && forced_bm == 0 && forced != 2 &&
-      cdiv(a.K / 64, sk) >= pp_minsteps) { d.nwv = 8; stages = 3; }
+      cdiv(a.K / 64, sk) >= pp_minsteps) {
+    d.nwv = 8; stages = 3;
+    // Where the 256-row tiling x split-K gives at most 128 workgroups (UNet levels 1-3 at the 8-sample batch), run
+    // 128 x 160 ping-pong tiles (eight waves of 32 x 80); gemm_pick_splitk() then aims at 256 workgroups of those, i.e. half the
+    // split factor: half the fp32 partials (none at level 1)
+    // (loop 561.1 -> 558.0 ms; GILL_GEMM_PP128 = 0 keeps the 256-row tile with twice the split)
+    if (pp128_on() && (int64_t)cdiv(a.M, 256) * d.tiles_n * sk <= 128 && a.M % 128 == 0) d.mi = 2;
+  }
   // GILL_GEMM_KT = 32: 4-deep ring of 32-wide stages on the 128-row tiles (see the kernel's KT note).  Off by default: measured
   // 7 % SLOWER on the denoise loop (608 -> 652 ms): the deeper prefetch does not pay for a barrier per 32-wide stage
   static const int forced_kt = env_int("GILL_GEMM_KT");
