@@ -82,7 +82,7 @@ def shapes_of(builder_name, cfg):
   return shapes
 
 
-def build_model(dev, opt_cfg, unet_cfg, max_prompts, vae_cfg=None):
+def build_model(dev, opt_cfg, unet_cfg, max_prompts, vae_cfg=None, keep_unet_cpu=False):
   from types import SimpleNamespace
   from gill_amd import synth
   from gill_amd.models import GILL
@@ -94,6 +94,8 @@ def build_model(dev, opt_cfg, unet_cfg, max_prompts, vae_cfg=None):
   vae_cfg = vae_cfg or synth.VAEConfig.sd15()
   vae_sd = gpu_state_dict(lambda c, meta: shapes_of("vae_decoder_state_dict", c), vae_cfg, dev, 3)
   pipe = GillSDPipeline(unet_sd, unet_cfg, uncond, dev, max_batch=2 * min(8, max_prompts), vae_state=vae_sd, vae_cfg=vae_cfg)
+  # fp32 host copy of the very weights the handle holds (bf16 values, exact): what the cpu_baseline leg's oracle forward runs on
+  pipe.bench_unet_sd_cpu = {k: v.float().cpu() for k, v in unet_sd.items()} if keep_unet_cpu else None
   del unet_sd, vae_sd
   name = "facebook/opt-6.7b" if opt_cfg.hidden_size == 4096 else "facebook/opt-125m"
   args = SimpleNamespace(freeze_lm=True, freeze_vm=True, opt_version=name, visual_encoder="openai/clip-vit-large-patch14",
@@ -182,29 +184,39 @@ def kernel_rooflines(dev):
   return out
 
 
-def cpu_baseline(n_infer_steps):
-  """The CPU oracle timed on this host's cores on a bounded sample of the same workload: ONE full-size SD-1.5 UNet
-  forward of the CFG pair (batch 2) + the GILLMapper, extrapolated to images/s (OPT-6.7b fp32 would need 27 GB and
-  minutes; it is 0.65 % of an image's FLOPs and is left out of the sample, which flatters the CPU slightly)."""
+def cpu_baseline(n_infer_steps, pipe, unet_cfg, fp8):
+  """The CPU oracle timed on this host's cores on a bounded sample of the same workload: ONE full-size UNet forward of a CFG
+  pair (batch 2) ON THE WEIGHTS THE GPU HANDLE HOLDS + the GILLMapper, extrapolated to images/s (OPT-6.7b fp32 would need 27 GB
+  and minutes; it is 0.65 % of an image's FLOPs and is left out of the sample, which flatters the CPU slightly).
+  The oracle's output doubles as the bench's correctness gate: the same forward through gill_unet_forward must land within
+  FWD_BAR of it (bench.py's own step-vs-step check only proves determinism).  Returns (record, forward_check)."""
   from gill_amd import synth
   from oracle import mapper_ref, unet_ref
   cores = synth.host_cores()
   torch.set_num_threads(cores)
-  cfg = synth.UNetConfig.sd15()
-  sd = synth.unet_state_dict(cfg, seed=0)
-  x = synth.initial_latents(2, 4, 64)
-  ctx = synth.normal("cpu_ctx", (2, 77, 768), 0)
+  L, cd = unet_cfg.sample_size, unet_cfg.cross_attention_dim
+  x = synth.initial_latents(2, 4, L)
+  ctx = synth.normal("cpu_ctx", (2, unet_cfg.ctx_len, cd), 0).bfloat16().float()
+  t = torch.tensor([961.0, 961.0])
+  heads = unet_cfg.heads_per_level if unet_cfg.heads_per_level else unet_cfg.num_heads
   t0 = time.time()
-  unet_ref.unet_forward(sd, x, torch.tensor([961.0, 961.0]), ctx)
+  ref = unet_ref.unet_forward(pipe.bench_unet_sd_cpu, x, t, ctx, unet_cfg.block_out_channels, heads, unet_cfg.norm_num_groups)
   t_unet = time.time() - t0
-  msd = synth.mapper_state_dict(synth.MapperConfig(in_dim=4096), seed=0)
+  got = pipe.unet(x, t, ctx).float().cpu()
+  rel = float(((got - ref).norm() / ref.norm()).item())
+  cos = float(torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item())
+  bar = 8e-2 if fp8 else 5e-2          # the bars of tests/test_stages_gpu.py (bf16) and tests/test_fp8_gpu.py (fp8 convolutions)
+  check = {"what": f"one full-size UNet forward (batch 2, t = 961, {L}x{L} latents) through gill_unet_forward vs the fp32 CPU oracle on the same weights",
+           "rel_l2": rel, "cosine": cos, "bar_rel_l2": bar, "ok": bool(rel == rel and rel < bar)}
+  msd = synth.mapper_state_dict(synth.MapperConfig(in_dim=4096, out_dim=cd), seed=0)
   t0 = time.time()
   mapper_ref.mapper_forward(msd, synth.normal("cpu_x", (1, 8, 4096), 0), synth.normal("cpu_e", (1, 8, 4096), 0))
   t_map = time.time() - t0
   per_image = (n_infer_steps + 1) * t_unet + t_map
-  return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
-          "sample": f"UNet loop + GILLMapper only: 1 SD-1.5 UNet forward of the CFG pair (batch 2, 1.61 TFLOP): {t_unet:.2f} s; GILLMapper B=1: {t_map * 1e3:.0f} ms; "
-                    f"extrapolated x{n_infer_steps + 1} UNet calls per image (OPT forward excluded from the sample)"}
+  rec = {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
+         "sample": f"UNet loop + GILLMapper only: 1 UNet forward of the CFG pair (batch 2, {L}x{L} latents): {t_unet:.2f} s; GILLMapper B=1: {t_map * 1e3:.0f} ms; "
+                   f"extrapolated x{n_infer_steps + 1} UNet calls per image (OPT forward excluded from the sample)"}
+  return rec, check
 
 
 def respawn_under_torchrun(a):
@@ -225,6 +237,9 @@ def main():
   ap.add_argument("--steps", type=int, default=5)
   ap.add_argument("--warmup", type=int, default=2)
   ap.add_argument("--prompts-per-gpu", type=int, default=0, help="default: 4 at --gpus 1 (BASELINE configs[1]), 8 at --gpus > 1 (configs[2]), 16 with --config c5 (configs[4])")
+  ap.add_argument("--total-prompts", type=int, default=0, help="global batch (default prompts-per-gpu x gpus); any value: uneven and empty shards are "
+                  "legal (contiguous split, first B %% N ranks take one more)")
+  ap.add_argument("--no-scale-origin", action="store_true", help="skip the 8-prompts-per-GPU side measurement of the N = 1 line")
   ap.add_argument("--infer-steps", type=int, default=50)
   ap.add_argument("--prompt-len", type=int, default=24)
   ap.add_argument("--small", action="store_true", help="opt-125m shapes (debug only; not the benchmark config)")
@@ -267,9 +282,22 @@ def main():
   tflop_fwd = UNET_TFLOP_SD21_768 if a.config == "c4" else UNET_TFLOP_PER_SAMPLE_FORWARD
   side = 8 * unet_cfg.sample_size
   P = a.prompts_per_gpu
-  g = build_model(dev, opt_cfg, unet_cfg, P, vae_cfg)
-  ids = synth.synthetic_prompt_ids(P * world, a.prompt_len, seed=0)[:, :a.prompt_len]   # [IMG] ids are appended by generate_images
-  lat0 = synth.initial_latents(P * world, 4, unet_cfg.sample_size, seed=1337).to(dev)
+  from gill_amd.parallel import shard_bounds
+  B_total = a.total_prompts if a.total_prompts > 0 else P * world
+  lo, hi = shard_bounds(B_total, rank, world)
+  P_local = hi - lo                        # == P unless --total-prompts makes the shards uneven
+  P_max = (B_total + world - 1) // world
+  # the N = 1 headline line also carries the 8-prompts-per-GPU figure (the per-GPU load of the N > 1 lines): the origin of the
+  # driver's 1 -> 8 GPU weak-scaling curve must be measured at the same per-GPU work as its other points
+  want_origin = (world == 1 and a.config == "c2" and not a.small and not a.no_scale_origin and not a.child_pmc and
+                 a.total_prompts == 0 and P != 8)
+  t_build0 = time.time()
+  want_cpu = world == 1 and not a.no_cpu_baseline and not a.child_pmc and not a.small
+  g = build_model(dev, opt_cfg, unet_cfg, max(P_max, 8 if want_origin else 1), vae_cfg, keep_unet_cpu=want_cpu)
+  torch.cuda.synchronize()
+  t_build = time.time() - t_build0
+  ids = synth.synthetic_prompt_ids(B_total, a.prompt_len, seed=0)[:, :a.prompt_len]   # [IMG] ids are appended by generate_images
+  lat0 = synth.initial_latents(B_total, 4, unet_cfg.sample_size, seed=1337).to(dev)
 
   # HIP events around the UNet loop: recorded on torch's current stream, which gill_sd_denoise fences its private launch stream
   # to on both sides (event record -> stream wait), so the pair brackets exactly the loop's kernels
@@ -326,14 +354,14 @@ def main():
   ref_lat, ref_img = kept[0][0].float(), kept[0][1].float()
   table, ok = [], True
   for i, (lat, img) in enumerate(kept):
-    shape_ok = tuple(lat.shape) == (P * world, 4, unet_cfg.sample_size, unet_cfg.sample_size) and \
-        tuple(img.shape) == (P, side, side, 3) and img.dtype == torch.uint8
+    shape_ok = tuple(lat.shape) == (B_total, 4, unet_cfg.sample_size, unet_cfg.sample_size) and \
+        tuple(img.shape) == (P_local, side, side, 3) and img.dtype == torch.uint8
     lat = lat.float()
     n_bad = int((~torch.isfinite(lat)).sum().item())
     rel = float(((lat - ref_lat).norm() / ref_lat.norm()).item()) if n_bad == 0 else float("nan")
     img_mad = float((img.float() - ref_img).abs().mean().item())
-    img_std = float(img.float().std().item())
-    good = shape_ok and n_bad == 0 and rel <= REL_STEP_TOL and img_std > 1.0
+    img_std = float(img.float().std().item()) if P_local > 0 else float("nan")
+    good = shape_ok and n_bad == 0 and rel <= REL_STEP_TOL and (P_local == 0 or img_std > 1.0)
     ok &= good
     table.append((i, shape_ok, n_bad, rel, img_mad, img_std, good))
   okt = torch.tensor([1 if ok else 0], device=dev)
@@ -350,12 +378,44 @@ def main():
     sys.exit(3)
   max_rel = max(r[3] for r in table)
 
+  scale_origin = None
+  if want_origin and rank == 0:
+    # same model, same loop, 8 prompts on the GPU (UNet batch 16): BASELINE configs[2]'s per-GPU share
+    ids8 = synth.synthetic_prompt_ids(8, a.prompt_len, seed=0)[:, :a.prompt_len]
+    lat8 = synth.initial_latents(8, 4, unet_cfg.sample_size, seed=1337).to(dev)
+
+    def step8():
+      return g.generate_images(ids8, num_inference_steps=a.infer_steps, guidance_scale=7.5, latents=lat8, decode=True)
+    ev_main, vae_main = list(ev["t"]), list(vae_ev)
+    first = step8()
+    ev["t"].clear()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    n8 = max(2, min(a.steps, 4))
+    outs8 = [step8() for _ in range(n8)]
+    torch.cuda.synchronize()
+    dt8 = time.perf_counter() - t1
+    ms8 = sum(e0.elapsed_time(e1) for e0, e1 in ev["t"]) / max(1, len(ev["t"]))
+    same8 = all(torch.equal(o[0], first[0]) for o in outs8) and bool(torch.isfinite(first[0]).all().item())
+    ach8 = tflop_fwd * 2 * (a.infer_steps + 1) * 8 / (ms8 * 1e-3)
+    scale_origin = {"prompts_per_gpu": 8, "value": 8 * n8 / dt8, "unit": "images/s", "steps": n8, "ms_per_step": dt8 / n8 * 1e3,
+                    "frac": ach8 / PEAK_BF16_TFLOPS, "achieved": ach8, "avg_launch_ms": ms8, "all_steps_bit_identical": same8,
+                    "note": "N = 1 at the per-GPU load of the N > 1 lines (BASELINE configs[2]: 8 prompts per GPU): like-for-like origin of the weak-scaling curve"}
+    if not same8:
+      print("[bench] scale_origin: 8-prompt steps differ or are non-finite", file=sys.stderr)
+      sys.exit(3)
+    ev["t"][:] = ev_main
+    vae_ev[:] = vae_main
+    del outs8, first
+
   if rank == 0:
-    images = P * world * a.steps
+    images = B_total * a.steps
     value = images / dt
     unet_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev["t"]) / max(1, len(ev["t"]))   # per sd_pipe call (<= 8 prompts)
     vae_ms = sum(e0.elapsed_time(e1) for e0, e1 in vae_ev) / max(1, len(vae_ev))
-    per_call = min(P, 8)                                                               # gen_max_bs = 8 chunks (models.py:726)
+    per_call = min(P_local, 8)                                                         # gen_max_bs = 8 chunks (models.py:726)
+    if P_local > 8 and P_local % 8:
+      per_call = P_local / ((P_local + 7) // 8)                                        # (average over the chunks of this rank)
     flop_per_call = tflop_fwd * 2 * (a.infer_steps + 1) * per_call
     achieved = flop_per_call / (unet_ms * 1e-3)
     traffic, traffic_detail = (None, "skipped (--no-pmc or N > 1)")
@@ -363,6 +423,8 @@ def main():
       del kept
       traffic, traffic_detail = pmc_traffic_live(a)
     cfg_name = "configs[1]" if (world == 1 and P == 4) else ("configs[2]" if P == 8 else "custom")
+    if a.total_prompts > 0:
+      cfg_name = "custom (--total-prompts)"
     unet_name = "SD-1.5 UNet"
     metric = "512x512 images/sec/node, OPT-6.7B+SD1.5 50-step"
     if a.config == "c4":
@@ -378,10 +440,13 @@ def main():
       "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
       "config": {"workload": f"BASELINE {cfg_name}: {'opt-125m' if a.small else 'opt-6.7b'} + GILLMapper + {unet_name} + VAE decoder "
-                             f"(random-init weights of the exact shapes), {P} prompts/GPU x {world} GPU = batch {P * world}, prompt "
+                             f"(random-init weights of the exact shapes), {P if a.total_prompts == 0 else 'uneven'} prompts/GPU x {world} GPU = batch {B_total}, prompt "
                              f"{a.prompt_len}+8 [IMG] tokens, {a.infer_steps} PLMS steps ({a.infer_steps + 1} UNet calls, CFG 7.5, UNet batch "
                              f"{2 * per_call}), final latents all-gathered, then VAE decode of the local shard to uint8 {side}x{side} "
-                             f"({vae_ms:.1f} ms per {P} images)", "parallelism": f"dp{world}", "prompts_per_gpu": P},
+                             f"({vae_ms:.1f} ms per {P_local} images)", "parallelism": f"dp{world}", "prompts_per_gpu": P if a.total_prompts == 0 else B_total / world,
+                 "global_batch": B_total, "model_build_s": round(t_build, 1),
+                 "collective": (f"{a.backend} ({'RCCL ' + '.'.join(str(v) for v in torch.cuda.nccl.version()) if a.backend == 'nccl' else 'test rig'}): one all_gather_into_tensor of the final latents per step"
+                                if world > 1 else "none (single rank)")},
       "output_check": {"steps_checked": len(table), "max_rel_l2_vs_first_step": max_rel, "tolerance": REL_STEP_TOL, "all_finite": True},
       "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                    "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
@@ -390,13 +455,19 @@ def main():
                    "kernel": f"{unet_name.split(' (')[0]} denoise loop (gill_sd_denoise: MFMA GEMM/implicit-conv + flash attention kernels)",
                    "algorithmic_tflop_per_launch": flop_per_call, "avg_launch_ms": unet_ms},
     }
+    if want_origin:
+      rec["scale_origin"] = scale_origin
     if world == 1 and not a.small and a.config == "c2":
       rec["roofline_kernels"] = kernel_rooflines(dev)
-    if not a.no_cpu_baseline and world == 1 and a.config == "c2":
-      rec["cpu_baseline"] = cpu_baseline(a.infer_steps)
-    else:
-      rec["cpu_baseline"] = None
+    rec["cpu_baseline"], rec["forward_check"] = None, None
+    if want_cpu:
+      # (every config: the oracle forward is both the reported CPU baseline and the correctness gate of this very build of the
+      # UNet — c4 / c5 included, whose step-vs-step check alone could not see a deterministic error)
+      rec["cpu_baseline"], rec["forward_check"] = cpu_baseline(a.infer_steps, g.sd_pipe, unet_cfg, a.config == "c5")
     print(json.dumps(rec), flush=True)
+    if rec["forward_check"] is not None and not rec["forward_check"]["ok"]:
+      print(f"[bench] FORWARD CHECK FAILED: {rec['forward_check']}", file=sys.stderr)
+      sys.exit(4)
   if world > 1:
     dist.destroy_process_group()
 

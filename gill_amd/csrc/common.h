@@ -62,6 +62,10 @@ __device__ __forceinline__ float silu_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));   // v_exp_f32 + v_rcp_f32
 }
 
+// saturate to the e4m3 range but keep NaN a NaN (fminf / fmaxf return the non-NaN operand: a plain clamp would launder a
+// non-finite activation into +-448 before the fp8 convolution, out of sight of every isfinite check downstream)
+__device__ __forceinline__ float clamp_fp8_keep_nan(float x) { return (x != x) ? x : fminf(fmaxf(x, -448.f), 448.f); }
+
 // ---- host side error plumbing (thread-local message, int status across the C ABI) ----
 void gill_set_error(const std::string& msg);
 

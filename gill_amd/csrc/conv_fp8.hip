@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_w_quant_fp8_kernel(const void* w, in
       const int q = kk >> 6, cc = kk & 63;
       const int tap = q / hpt, c = (q - tap * hpt) * 64 + cc;
       v[e] = (q < 9 * hpt) ? load(c * 9 + tap) * inv : 0.f;       // OIHW: ((o*Cin + c)*9 + tap)
-      v[e] = fminf(fmaxf(v[e], -448.f), 448.f);
+      v[e] = clamp_fp8_keep_nan(v[e]);
     }
     const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
     *reinterpret_cast<unsigned short*>(dst + k) = (unsigned short)(pk & 0xffff);
@@ -340,8 +340,8 @@ __global__ __launch_bounds__(256) void quant_bf16_fp8_kernel(const bf16_t* __res
     float o[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      o[2 * e] = fminf(fmaxf(bf2f((bf16_t)(uu[e] & 0xffff)) * scale, -448.f), 448.f);
-      o[2 * e + 1] = fminf(fmaxf(bf2f((bf16_t)(uu[e] >> 16)) * scale, -448.f), 448.f);
+      o[2 * e] = clamp_fp8_keep_nan(bf2f((bf16_t)(uu[e] & 0xffff)) * scale);
+      o[2 * e + 1] = clamp_fp8_keep_nan(bf2f((bf16_t)(uu[e] >> 16)) * scale);
     }
     int lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], 0, false);
     lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], lo, true);

@@ -432,11 +432,12 @@ __global__ __launch_bounds__(256) void plms_step_kernel(const SdLoopArgs a) {
   const int step = a.ctr[1];          // written by this step's stage kernel; nobody writes it while this kernel runs
   const PlmsRow r = a.rows[step];
   const int64_t total = (int64_t)a.B * a.n;
+  const float guidance = a.cfg ? a.guidance[0] : 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float e = a.eps[i];
     if (a.cfg) {
       const float ec = a.eps[total + i];
-      e = e + a.guidance * (ec - e);
+      e = e + guidance * (ec - e);
     }
     float sample = a.lat[i];
     float ep;

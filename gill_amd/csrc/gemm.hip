@@ -942,14 +942,14 @@ bool conv_k_chunked(int HW, int Cin, int Cout) {
   return HW >= 4096 && (int64_t)HW * Cin * 2 > (int64_t)4 << 20 && !gemm_conv_pingpong(HW, Cout);
 }
 
-int gemm_pick_splitk(int M, int N, int K, int act, bool plain) {
+int gemm_pick_splitk(int M, int N, int K, int act, bool plain, bool generic) {
   if (act == ACT_GEGLU) return 1;
   const int bn = (N % 160 == 0) ? 160 : 128;
   const int tiles = cdiv(M, BM_HOST) * cdiv(N, bn);
   const int ksteps = K / BK;
   if (tiles >= 384 || ksteps < 8) return 1;
   {   // convs that gemm_launch_bn puts on 128 x 160 ping-pong tiles: one workgroup per CU, 256 slots
-    if (pp128_on() && !plain && gemm_conv_pingpong(M, N) && tiles <= 256 && M % 128 == 0) {
+    if (pp128_on() && !plain && !generic && gemm_conv_pingpong(M, N) && tiles <= 256 && M % 128 == 0) {
       int s = (256 + tiles / 2) / tiles;
       const int min_steps = (M <= 256 || tiles < 64) ? 4 : 24;
       if (s > ksteps / min_steps) s = ksteps / min_steps;
@@ -959,7 +959,7 @@ int gemm_pick_splitk(int M, int N, int K, int act, bool plain) {
   }
   // plain GEMMs with 150..383 128-row tiles run on 64-row tiles instead (gemm_launch: >= 300 workgroups, no partials):
   // measured 8192 x 640 x 3200 unsplit 49.1 us, two-way split + reducer 54.6 us
-  if (plain && tiles >= 150 && tiles < 300 && M > 64) return 1;
+  if (plain && !generic && tiles >= 150 && tiles < 300 && M > 64) return 1;
   int s = (512 + tiles / 2) / tiles;   // aim for ~2 workgroups per CU (512 resident slots)
   // each split pays an fp32 partial write + a reduce pass: keep >= 24 K steps per split (measured: K = 1280 GEMMs lose
   // from any split, K >= 5120 convs win up to 4-8 ways), except for skinny weight-streaming GEMMs (OPT, M <= 256)

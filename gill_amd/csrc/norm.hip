@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
     }
     if (out8_scale > 0.f) {     // fp8 (e4m3) output: the A operand of the fp8 convolution (conv_fp8.hip), 8 bytes per thread
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = fminf(fmaxf(o[e] * out8_scale, -448.f), 448.f);
+      for (int e = 0; e < 8; ++e) o[e] = clamp_fp8_keep_nan(o[e] * out8_scale);
       int lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], 0, false);
       lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], lo, true);
       int hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[4], o[5], 0, false);
@@ -371,19 +371,21 @@ int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, 
   hipLaunchKernelGGL(groupnorm_stats_kernel, g1, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, stats);
   GILL_CHECK_HIP(hipGetLastError());
   // `stats` holds nslab partial {sum, sum of squares} per group of the whole (concatenated) input
+  // (the totals scratch is the tail of `stats`: groupnorm_stats_floats() counts it)
   return groupnorm_apply_launch(x1, C1, x2, C2, B, HW, groups, gamma, beta, eps, silu, y, stats, C / groups, C, nslab, nullptr, 0, 0, s,
-                                out8_scale);
+                                out8_scale, stats + (size_t)B * nslab * groups * 2);
 }
 
-// Partial counts beyond GN_MAX_PARTIALS (the VAE's 128^2 .. 512^2 maps): total them once, in slab order, IN PLACE — the sum
-// of (sample, bin, moment) replaces its slab-0 partial, which only the thread that owns that sum ever touches — and let
-// the apply kernel read one "partial" per (sample, bin).
+// Partial counts beyond GN_MAX_PARTIALS (the VAE's 128^2 .. 512^2 maps, the SD-2.1-768 UNet's 96^2 maps): total them once, in slab
+// order, OUT OF PLACE into a caller-provided scratch [B][bins][2] and let the apply kernel read one "partial" per (sample, bin).
+// (A producer's partials are never modified: a UNet skip tensor is normalised twice — by the next block and by the up block's
+// concatenated norm1 — and the second consumer must see the same partials as the first.)
 #define GN_MAX_PARTIALS 64
-__global__ __launch_bounds__(256) void groupnorm_total_kernel(float* __restrict__ stats, int ns, int nb) {
+__global__ __launch_bounds__(256) void groupnorm_total_kernel(const float* __restrict__ stats, int ns, int nb, float* __restrict__ tot) {
   const int b = blockIdx.y;
   const int idx = blockIdx.x * 256 + threadIdx.x;      // (bin, moment)
   if (idx >= nb * 2) return;
-  float* base = stats + (size_t)b * ns * nb * 2 + idx;
+  const float* base = stats + (size_t)b * ns * nb * 2 + idx;
   const size_t step = (size_t)nb * 2;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
   int sl = 0;
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256) void groupnorm_total_kernel(float* __restrict_
     a6 += base[(size_t)(sl + 6) * step]; a7 += base[(size_t)(sl + 7) * step];
   }
   for (; sl < ns; ++sl) a0 += base[(size_t)sl * step];
-  base[0] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  tot[(size_t)b * nb * 2 + idx] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
 }
 
 static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
@@ -402,7 +404,7 @@ static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t
 // stats2 = [B][(C - sc1) / bin2][2] over the rest (nullptr when stats1 covers everything).
 int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups, const float* gamma,
                            const float* beta, float eps, int silu, bf16_t* y, const float* stats1, int bin1, int sc1, int nslab1,
-                           const float* stats2, int bin2, int nslab2, hipStream_t s, float out8_scale) {
+                           const float* stats2, int bin2, int nslab2, hipStream_t s, float out8_scale, float* tot_scratch) {
   const int C = C1 + C2;
   GILL_REQUIRE(groups <= 64 && C % groups == 0 && (C / groups) % 2 == 0, "groupnorm: channels/group must be even");
   GILL_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "groupnorm: channel counts must be multiples of 8");
@@ -412,14 +414,18 @@ int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, i
                "groupnorm: group boundaries must fall on statistics bin boundaries");
   GILL_REQUIRE(sc1 == C || (stats2 != nullptr && bin2 > 0 && (C - sc1) % bin2 == 0), "groupnorm: second statistics block missing");
   GILL_REQUIRE(nslab1 >= 1 && (stats2 == nullptr || nslab2 >= 1), "groupnorm: partial counts missing");
-  int ns1 = nslab1, ns2 = nslab2;
-  if (nslab1 > GN_MAX_PARTIALS) {     // (the statistics buffers are scratch of this forward: totalling in place is fine)
-    hipLaunchKernelGGL(groupnorm_total_kernel, dim3(cdiv(2 * (sc1 / bin1), 256), B), dim3(256), 0, s, const_cast<float*>(stats1), nslab1, sc1 / bin1);
-    ns1 = 1;
+  int ns1 = nslab1, ns2 = nslab2, bs1 = nslab1, bs2 = nslab2;
+  const int nb1 = sc1 / bin1, nb2 = stats2 ? (C - sc1) / bin2 : 0;
+  if (nslab1 > GN_MAX_PARTIALS || (stats2 && nslab2 > GN_MAX_PARTIALS))
+    GILL_REQUIRE(tot_scratch != nullptr, "groupnorm: more than 64 partials per bin need a totals scratch (groupnorm_totals_floats)");
+  if (nslab1 > GN_MAX_PARTIALS) {
+    hipLaunchKernelGGL(groupnorm_total_kernel, dim3(cdiv(2 * nb1, 256), B), dim3(256), 0, s, stats1, nslab1, nb1, tot_scratch);
+    stats1 = tot_scratch; ns1 = 1; bs1 = 1;
   }
   if (stats2 && nslab2 > GN_MAX_PARTIALS) {
-    hipLaunchKernelGGL(groupnorm_total_kernel, dim3(cdiv(2 * ((C - sc1) / bin2), 256), B), dim3(256), 0, s, const_cast<float*>(stats2), nslab2, (C - sc1) / bin2);
-    ns2 = 1;
+    float* t2 = tot_scratch + (size_t)B * nb1 * 2;
+    hipLaunchKernelGGL(groupnorm_total_kernel, dim3(cdiv(2 * nb2, 256), B), dim3(256), 0, s, stats2, nslab2, nb2, t2);
+    stats2 = t2; ns2 = 1; bs2 = 1;
   }
   GILL_CHECK_HIP(hipGetLastError());
   GILL_REQUIRE(sc1 / bin1 <= 128 && (stats2 == nullptr || (C - sc1) / bin2 <= 128), "groupnorm: more than 128 statistics bins per block");
@@ -434,8 +440,8 @@ int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, i
   while (rows > 4 && (int64_t)cdiv(HW, rows) * B * nch < 1024) rows >>= 1;
   dim3 g2(cdiv(HW, rows), B, nch);
   hipLaunchKernelGGL(groupnorm_apply_kernel, g2, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, gamma, beta,
-                     eps, silu, stats1, sc1 / bin1, cg / bin1, ns1, nslab1, stats2, stats2 ? (C - sc1) / bin2 : 0,
-                     stats2 ? cg / bin2 : 0, stats2 ? sc1 / bin2 : 0, stats2 ? ns2 : 0, stats2 ? nslab2 : 0, y, rows, cc, out8_scale);
+                     eps, silu, stats1, sc1 / bin1, cg / bin1, ns1, bs1, stats2, stats2 ? (C - sc1) / bin2 : 0,
+                     stats2 ? cg / bin2 : 0, stats2 ? sc1 / bin2 : 0, stats2 ? ns2 : 0, stats2 ? bs2 : 0, y, rows, cc, out8_scale);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -73,7 +73,8 @@ int gemm_row_planes(const GemmArgs& a);
 // can a GEMM with N output columns produce fused GroupNorm statistics for bins of cg channels?
 bool gemm_fused_gn_ok(int N, int cg);
 // heuristic split-K factor for under-filled grids
-int gemm_pick_splitk(int M, int N, int K, int act, bool plain = false);   // plain: not a conv (64-row tiles available)
+int gemm_pick_splitk(int M, int N, int K, int act, bool plain = false, bool generic = false);   // plain: not a conv (64-row tiles available);
+                                                                                               // generic: 128-row 4-wave tiles only (the fp8 conv kernel): neither the 64-row nor the ping-pong rules
 
 // split-K reducer of gemm_launch on its own (partials a.ws [splitk][M][N] fp32 written by another kernel: conv_fp8.hip)
 int gemm_splitk_reduce_launch(const GemmArgs& a, hipStream_t s);
@@ -123,8 +124,10 @@ int layernorm_f32out_launch(const void* x, int x_f32, const float* gamma, const 
 //   stats: fp32 scratch of groupnorm_stats_floats(B, HW, groups) floats (per-slab partial sums, written here).
 #define GN_STATS_ROWS 32       // pixels per partial of the stand-alone statistics pass
 static inline size_t groupnorm_stats_floats(int B, int HW, int groups) {
-  return (size_t)B * ((HW + GN_STATS_ROWS - 1) / GN_STATS_ROWS) * groups * 2;
+  return (size_t)B * ((HW + GN_STATS_ROWS - 1) / GN_STATS_ROWS) * groups * 2 + (size_t)B * groups * 2;   // partials + totals scratch
 }
+// floats of the totals scratch groupnorm_apply_launch needs when a statistics block holds more than 64 partials per bin
+static inline size_t groupnorm_totals_floats(int B, int nbins1, int nbins2) { return (size_t)B * (nbins1 + nbins2) * 2; }
 int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups,
                      const float* gamma, const float* beta, float eps, int silu, bf16_t* y,
                      float* stats, hipStream_t s, float out8_scale = 0.f);
@@ -133,7 +136,8 @@ int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, 
 // combination is usable
 int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups, const float* gamma,
                            const float* beta, float eps, int silu, bf16_t* y, const float* stats1, int bin1, int sc1, int nslab1,
-                           const float* stats2, int bin2, int nslab2, hipStream_t s, float out8_scale = 0.f);
+                           const float* stats2, int bin2, int nslab2, hipStream_t s, float out8_scale = 0.f,
+                           float* tot_scratch = nullptr);
 // out8_scale > 0: y is an fp8 (e4m3) tensor [B][HW][C] holding fp8(out8_scale * value) — the A operand of conv3x3_fp8_launch
 bool groupnorm_bins_align(int cg, int sc1, int bin1, int bin2);
 
@@ -180,7 +184,7 @@ struct SdLoopArgs {
   float* cur_sample;     // [B][n] saved sample (PLMS warm-up)
   float* ets;            // [4][B][n] ring of past eps'
   int B; int64_t n;      // n = C*H*W per sample
-  float guidance;
+  const float* guidance; // device scalar (not a kernel argument: one captured step graph serves every guidance value)
   int cfg;               // 1: eps holds [uncond | cond] halves and guidance is applied; 0: eps is [B][n]
 };
 // plain device-side fill / copy kernels for use INSIDE a captured forward: hipMemsetAsync / hipMemcpyAsync become memset /

@@ -87,12 +87,11 @@ struct Arena {
 
 }  // namespace
 
-struct GraphKey {
-  int Bx, cfg; float guidance;
+struct GraphKey {     // (the guidance scale is a device-side scalar, not part of the captured step)
+  int Bx, cfg;
   bool operator<(const GraphKey& o) const {
     if (Bx != o.Bx) return Bx < o.Bx;
-    if (cfg != o.cfg) return cfg < o.cfg;
-    return guidance < o.guidance;
+    return cfg < o.cfg;
   }
 };
 
@@ -139,6 +138,7 @@ struct gill_unet {
   float* temb_cur = nullptr;    // [temb_total]: time-embedding row of the step being replayed
   PlmsRow* plms_rows = nullptr; // [temb_rows_cap]: per-step PLMS coefficients of the running loop
   int* step_ctr = nullptr;      // [2]: next / current step of the running loop (SdLoopArgs::ctr)
+  float* guidance_dev = nullptr; // [1]: guidance scale of the running loop (SdLoopArgs::guidance)
   // hipGraph of one UNet forward per UNet batch size (captured after the first eager forward of that size)
   std::map<GraphKey, hipGraphExec_t> graphs;
   std::set<GraphKey> warmed;
@@ -533,8 +533,8 @@ struct UNetRun {
     g.gn_stats = y.stats; g.gn_groups = y.C / y.sbin; g.gn_cg = y.sbin;
     g.rows_per_batch = y.H * y.W;
   }
-  int pick_sk(GemmArgs& g) {
-    g.splitk = gemm_pick_splitk(g.M, g.N, g.K, g.act, !g.conv);
+  int pick_sk(GemmArgs& g, bool generic = false) {
+    g.splitk = gemm_pick_splitk(g.M, g.N, g.K, g.act, !g.conv, generic);
     while (g.splitk > 1 && (size_t)g.splitk * g.M * g.N > m->splitk_ws_floats) --g.splitk;
     g.ws = m->splitk_ws;
     return 0;
@@ -554,12 +554,15 @@ struct UNetRun {
                        groupnorm_bins_align(C / m->cfg.norm_num_groups, x1.C, x1.sbin, x2 ? x2->sbin : 0);
     const int HW = x1.H * x1.W;
     float* stats = ready ? nullptr : stats_slot(groupnorm_stats_floats(Bx, HW, m->cfg.norm_num_groups));
+    // out-of-place totals for producers that wrote more than 64 partials per bin (SD-2.1-768: 96x96 maps); a skip tensor's
+    // partials are read again by the up block's concatenated norm1 and must stay as their producer wrote them
+    float* tot = ready ? stats_slot(groupnorm_totals_floats(Bx, x1.C / x1.sbin, x2 ? x2->C / x2->sbin : 0)) : nullptr;
     if (dry) return 0;
     GILL_REQUIRE(m->gn_next <= m->gn_floats, "internal: GroupNorm stats pool exhausted");
     if (ready)
       return groupnorm_apply_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, HW, m->cfg.norm_num_groups,
                                     n.g, n.b, eps, silu, y.p, x1.stats, x1.sbin, x1.C, x1.nslab,
-                                    x2 ? x2->stats : nullptr, x2 ? x2->sbin : 0, x2 ? x2->nslab : 0, s, y8_scale);
+                                    x2 ? x2->stats : nullptr, x2 ? x2->sbin : 0, x2 ? x2->nslab : 0, s, y8_scale, tot);
     return groupnorm_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, HW, m->cfg.norm_num_groups, n.g,
                             n.b, eps, silu, y.p, stats, s, y8_scale);
   }
@@ -573,7 +576,7 @@ struct UNetRun {
     a.rows_per_batch = x8.H * x8.W;
     GemmArgs g;      // split-K geometry + the reducer's epilogue
     g.M = a.M; g.N = a.N; g.K = 9 * w.cin;
-    pick_sk(g);
+    pick_sk(g, true);     // (the fp8 kernel has neither 64-row tiles nor a ping-pong variant: generic split rule)
     a.splitk = g.splitk;
     if (a.splitk > 1) {
       a.ws = g.ws;
@@ -873,6 +876,7 @@ static int unet_plan_and_alloc(gill_unet* m) {
   GILL_TRY(m->pool.alloc(&m->temb_cur, (size_t)m->temb_total));
   GILL_TRY(m->pool.alloc(&m->plms_rows, (size_t)m->temb_rows_cap));
   GILL_TRY(m->pool.alloc(&m->step_ctr, (size_t)2));
+  GILL_TRY(m->pool.alloc(&m->guidance_dev, (size_t)4));
   { const char* e = getenv("GILL_NO_GRAPH"); m->use_graph = !(e && e[0] == '1'); }
   return 0;
 }
@@ -1042,6 +1046,7 @@ static int sd_denoise_on(gill_unet* m, const void* cond_bf16, const void* uncond
   }
   GILL_CHECK_HIP(hipMemcpyAsync(m->plms_rows, rows.data(), sizeof(PlmsRow) * ncalls, hipMemcpyHostToDevice, s));
   GILL_CHECK_HIP(hipMemsetAsync(m->step_ctr, 0, sizeof(int) * 2, s));
+  GILL_CHECK_HIP(hipMemcpyAsync(m->guidance_dev, &guidance, sizeof(float), hipMemcpyHostToDevice, s));   // (synchronised below)
   // hoisted: time-embedding table for every call (its stream sync also covers the host `rows` buffer), prompt K/V caches
   std::vector<float> tf(ncalls);
   for (int i = 0; i < ncalls; ++i) tf[i] = (float)ts[i];
@@ -1067,7 +1072,7 @@ static int sd_denoise_on(gill_unet* m, const void* cond_bf16, const void* uncond
   SdLoopArgs la;
   la.rows = m->plms_rows; la.ctr = m->step_ctr; la.temb_table = m->temb_table; la.temb_total = m->temb_total;
   la.temb_cur = m->temb_cur; la.eps = m->eps; la.lat = m->lat; la.lat2 = m->lat2; la.cur_sample = m->cur_sample; la.ets = m->ets;
-  la.B = B; la.n = n_lat; la.guidance = guidance; la.cfg = cfg ? 1 : 0;
+  la.B = B; la.n = n_lat; la.guidance = m->guidance_dev; la.cfg = cfg ? 1 : 0;
   auto one_step = [&](hipStream_t st) -> int {
     GILL_TRY(sd_stage_launch(la, st));
     UNetRun r{m, st, Bx, m->temb_cur, 0, false};
@@ -1075,8 +1080,8 @@ static int sd_denoise_on(gill_unet* m, const void* cond_bf16, const void* uncond
     GILL_TRY(r.forward(m->lat2, m->eps));
     return plms_step_launch(la, st);
   };
-  // the graph bakes in B, guidance and the CFG flag besides the buffer addresses
-  const GraphKey gkey{Bx, cfg ? 1 : 0, guidance};
+  // the graph bakes in B and the CFG flag besides the buffer addresses
+  const GraphKey gkey{Bx, cfg ? 1 : 0};
   for (int i = 0; i < ncalls; ++i) {
     auto git = m->graphs.find(gkey);
     if (git == m->graphs.end() && m->use_graph && m->warmed.count(gkey)) {

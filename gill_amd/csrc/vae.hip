@@ -227,10 +227,11 @@ struct VRun {
     const bool ready = x.stats != nullptr;
     const int HW = x.H * x.W, G = m->cfg.norm_num_groups;
     float* stats = ready ? x.stats : stats_slot(groupnorm_stats_floats(B, HW, G));
+    float* tot = ready ? stats_slot(groupnorm_totals_floats(B, G, 0)) : nullptr;   // out-of-place totals (> 64 partials per group)
     if (dry) return 0;
     if (ready)
       return groupnorm_apply_launch(x.p, x.C, nullptr, 0, B, HW, G, n.g, n.b, 1e-6f, silu, y.p, stats, x.C / G, x.C,
-                                    x.nslab, nullptr, 0, 0, s);
+                                    x.nslab, nullptr, 0, 0, s, 0.f, tot);
     return groupnorm_launch(x.p, x.C, nullptr, 0, B, HW, G, n.g, n.b, 1e-6f, silu, y.p, stats, s);
   }
   int conv(const VTensor& x, const ConvW& w, int ups, const bf16_t* resid, VTensor& y) {

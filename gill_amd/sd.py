@@ -8,8 +8,9 @@ The reference builds `StableDiffusionPipeline.from_pretrained("runwayml/stable-d
 guidance_scale / num_inference_steps / output_type) and runs the UNet + PNDM loop in libgill_amd
 (gill_sd_denoise: csrc/unet.hip).
 
-`output_type="latent"` (default here: the hot path hands latents to the all-gather) returns the final latents (B,4,64,64)
-fp32 in `.images`; "pil" / "np" / "pt" run the VAE decoder (gill_vae_decode: csrc/vae.hip, custom_sd.py:385-392, :654-661) and
+`output_type` defaults to "pil" like the reference's (gill/custom_sd.py:491) when the handle holds VAE weights (a UNet-only
+handle defaults to "latent"); "latent" (what `GILL.generate_images` passes: the hot path hands latents to the all-gather) returns
+the final latents (B,4,64,64) fp32 in `.images`; "pil" / "np" / "pt" run the VAE decoder (gill_vae_decode: csrc/vae.hip, custom_sd.py:385-392, :654-661) and
 need the handle to have been built with VAE weights.
 """
 from __future__ import annotations
@@ -203,13 +204,17 @@ class GillSDPipeline:
   def __call__(self, prompt=None, height=None, width=None, num_inference_steps: int = 50, guidance_scale: float = 7.5,
                negative_prompt=None, num_images_per_prompt: int = 1, eta: float = 0.0, generator=None,
                latents: Optional[torch.Tensor] = None, prompt_embeds: Optional[torch.Tensor] = None,
-               negative_prompt_embeds: Optional[torch.Tensor] = None, output_type: str = "latent", return_dict: bool = True,
+               negative_prompt_embeds: Optional[torch.Tensor] = None, output_type: Optional[str] = None, return_dict: bool = True,
                **_ignored):
     if prompt is not None:
       raise ValueError("GillSDPipeline is driven by prompt_embeds (gill/models.py:730); text prompts need the CLIP text "
                        "encoder, which is outside this path")
     if prompt_embeds is None:
       raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+    if output_type is None:
+      # the reference's default is "pil" (gill/custom_sd.py:491: `.images` is a list of PIL images); a handle built WITHOUT VAE
+      # weights (UNet-only parity rigs) can only return latents
+      output_type = "pil" if self._vae is not None else "latent"
     L = self.cfg.sample_size
     if (height is not None and height != L * 8) or (width is not None and width != L * 8):
       raise ValueError(f"this handle was built for {L * 8}x{L * 8} images")

@@ -12,6 +12,7 @@ What is executed from the reference, unmodified:
   F5  gill.models.GILLModel.get_visual_embs(mode='captioning')                  (gill/models.py:129-146)
   F6  generate_for_images_and_texts([PIL image, text])                          (gill/models.py:606-613)
   F7  the retrieval branch of the same method (emb_matrix / path_array given)  (gill/models.py:671-696)
+  F9  GILLModel.get_visual_embs(mode='retrieval') + the CLIP rerank of generated images   (gill/models.py:141-146, 724-751)
   F8  gill.custom_sd.StableDiffusionPipeline.__call__ — the CFG / scheduler / decode DRIVER     (gill/custom_sd.py:567-666,
       with _encode_prompt :224-373, prepare_latents :458-473, decode_latents :385-392) — run with the ORACLE's UNet, PNDM
       scheduler and VAE decoder injected as self.unet / self.scheduler / self.vae.  This pins the order of operations of the
@@ -245,9 +246,35 @@ def golden_visual(ref_models, tmp):
   ret_scores = np.array([r[2] for r in rets], dtype=np.float64)
   ret_ids = np.array([int(np.asarray(r[0])[0, 0, 0]) for r in rets], dtype=np.int64)     # red channel = (7 k) % 256 identifies k
   print("F7 ret", ret_ids.tolist(), ret_scores.tolist(), ret7[1]["decision"])
+  # ---- F9: get_visual_embs(mode='retrieval') (gill/models.py:141-146: pooler_output -> visual_fc -> (B,1,256)) and the CLIP
+  # rerank of GENERATED images (gill/models.py:724-751).  Harness shim: the reference's sd_pipe is replaced by a stand-in that
+  # returns two fixed PIL images (stage 3 has its own fixtures); everything after the call — resize, feature extractor,
+  # get_visual_embs(mode='retrieval'), normalise, scores against ret_emb, the sort — is the reference's code.
+  vfc = {}
+  synth._linear(vfc, "visual_fc", 256, ccfg.hidden_size, 13)
+  vfc = {k: v.bfloat16().float() for k, v in vfc.items()}
+  with torch.no_grad():
+    gm.visual_fc.weight.copy_(vfc["visual_fc.weight"]); gm.visual_fc.bias.copy_(vfc["visual_fc.bias"])
+    ve_ret = gm.get_visual_embs(px, mode="retrieval")
+  rng9 = np.random.default_rng(17)
+  gen_arrs = rng9.integers(0, 256, (2, 64, 64, 3), dtype=np.uint8)
+  gen_arrs[0, 0, 0, 0], gen_arrs[1, 0, 0, 0] = 11, 222        # red value of pixel (0,0) identifies the image after the sort
+
+  class _StubPipe:
+    def __call__(self, prompt_embeds=None, **kw):
+      return types.SimpleNamespace(images=[Image.fromarray(a) for a in gen_arrs[:prompt_embeds.shape[0]]])
+  gill.sd_pipe, gill.load_sd, gill.num_gen_images = _StubPipe(), True, 2
+  with torch.no_grad():
+    ret9 = gill.generate_for_images_and_texts([text], num_words=2, gen_scale_factor=1e5)
+  gens = ret9[1]["gen"]
+  rerank_scores = np.array([s for _, s in gens], dtype=np.float64)
+  rerank_red = np.array([int(np.asarray(im)[0, 0, 0]) for im, _ in gens], dtype=np.int64)
+  print("F9", tuple(ve_ret.shape), float(ve_ret.abs().mean()), "rerank", rerank_red.tolist(), rerank_scores.tolist())
+  gill.sd_pipe, gill.load_sd, gill.num_gen_images = None, False, 1
   gill.emb_matrix = None
   gill.path_array = None
   np.savez_compressed(os.path.join(OUT, "gill_visual_tiny.npz"), ret_scores=ret_scores, ret_red=ret_ids, n_img=np.int64(n_img),
+                      visual_embs_retrieval=ve_ret.numpy(), rerank_images=gen_arrs, rerank_scores=rerank_scores, rerank_red=rerank_red,
                       ret_decision=np.array(str(ret7[1]["decision"])), pixel_values=px.numpy(), visual_embs=ve.numpy(),
                       image=img_arr, text=np.array(text), caption=np.array(ret[0]), decision=np.array(str(ret[1]["decision"])),
                       gen_emb=gen.numpy(), clip_seed=np.int64(13), opt_seed=np.int64(5), mapper_seed=np.int64(7))

@@ -1,0 +1,204 @@
+"""BASELINE.json configs[2] / configs[3] at their real per-GPU sizes, a teacher-forced per-timestep check of the full-size UNet, and
+the GroupNorm-partials path of feature maps with more than 64 slabs (VERDICT r02 "next round" item 1).
+
+  * C3 (batch 64 over 8 GPUs): the per-GPU share is 8 prompts -> UNet batch 16 through GILL.generate_images
+    (ref gill/models.py:724-731: gen_max_bs = 8 chunks), and 16 prompts to cross the chunk boundary;
+  * C4 (SD-2.1-768): one full-size forward at 96x96 latents against the oracle, and a reduced-width UNet at 96x96 whose level-0
+    tensors carry 144 GroupNorm partials per bin (the skip tensors are normalised twice: by the next block and by the up block's
+    concatenated norm1);
+  * teacher forcing: the oracle's own latent at each of the 11 timesteps of a 10-step schedule goes through gill_unet_forward, so
+    every call is compared on identical inputs (the recurrent loop tests cannot see a 2 % kernel regression: a random-weight UNet
+    amplifies any re-ordering to 3e-2 after 4 calls, tools/chaos_probe.py).  Ref call sites: gill/custom_sd.py:633-646.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from gill_amd import synth
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_stages_gpu import _bfw, _gill_opt125m, _stats   # noqa: E402  (shared helpers)
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SLOW = pytest.mark.skipif(os.environ.get("GILL_SKIP_SLOW") == "1", reason="slow CPU oracle")
+
+
+@pytest.fixture(scope="module")
+def sd15_pipe16(cuda):
+  from gill_amd.sd import GillSDPipeline
+  cfg = synth.UNetConfig.sd15()
+  sd = _bfw(synth.unet_state_dict(cfg, seed=51))
+  uncond = synth.uncond_context(cfg.ctx_len, cfg.cross_attention_dim, seed=51).bfloat16().float()
+  return cfg, sd, uncond, GillSDPipeline(sd, cfg, uncond, cuda, max_batch=16)
+
+
+@SLOW
+def test_c3_per_gpu_share_batch16_vs_oracle(cuda, sd15_pipe16):
+  """8 prompts on one GPU = BASELINE configs[2]'s per-GPU share: OPT -> mapper -> ONE gill_sd_denoise call at UNet batch 16
+  (2 PLMS steps = 3 calls: eager, captured, replayed).  Prompts are independent end to end, so the oracle runs on two of the eight
+  (the first and the last of the batch) with the embeddings the GPU produced."""
+  from oracle import pipeline_ref
+  cfg, sd, uncond, pipe = sd15_pipe16
+  g = _gill_opt125m(cuda, load_sd=True, sd_pipe=pipe)
+  ids = synth.synthetic_prompt_ids(16, 12, seed=21)[:, :12]
+  lat0 = synth.initial_latents(16, 4, 64, seed=2121)
+  lat8, emb8 = g.generate_images(ids[:8], num_inference_steps=2, guidance_scale=7.5, latents=lat0[:8].to(cuda),
+                                 return_embeddings=True, distributed=False)
+  assert lat8.shape == (8, 4, 64, 64) and emb8.shape == (8, 77, 768)
+  pick = [0, 7]
+  cond = emb8[pick].float().cpu().bfloat16().float()      # what the SD handle saw (bf16)
+  ref = pipeline_ref.denoise(sd, cond, uncond, lat0[pick], 2, 7.5)
+  _, rel, cos = _stats("C3 share: 8 prompts (UNet batch 16), 2 steps, prompts 0 and 7", lat8[pick], ref)
+  assert rel < 5e-2 and cos > 0.998
+  # 16 prompts: two gen_max_bs = 8 chunks (gill/models.py:724-731).  The second chunk is the same launch sequence on the same
+  # batch size as a call with prompts 8..15 alone, so it must match that call bit for bit; the first chunk matches the run above.
+  lat16 = g.generate_images(ids, num_inference_steps=2, guidance_scale=7.5, latents=lat0.to(cuda), distributed=False)
+  assert lat16.shape == (16, 4, 64, 64) and bool(torch.isfinite(lat16).all())
+  assert torch.equal(lat16[:8], lat8), "chunk 0 of the 16-prompt call differs from the 8-prompt call"
+  solo = g.generate_images(ids[8:], num_inference_steps=2, guidance_scale=7.5, latents=lat0[8:].to(cuda), distributed=False)
+  assert torch.equal(lat16[8:], solo), "chunk 1 of the 16-prompt call differs from the same prompts alone"
+
+
+@SLOW
+def test_sd15_teacher_forced_eps_all_timesteps_vs_oracle(cuda, sd15_pipe16):
+  """Full-size SD-1.5, CFG pair of one prompt, the 11 UNet calls of a 10-step PLMS schedule: the ORACLE's latent is fed to both
+  sides at every timestep (custom_sd.py:630-638) and the predicted noise is compared per call.  Bar 2.5e-2 = about twice the
+  single-forward distance of a bf16 UNet to the fp32 oracle (1.1e-2 at t = 961)."""
+  from oracle import scheduler_ref, unet_ref
+  cfg, sd, uncond, pipe = sd15_pipe16
+  cond = synth.normal("tf_cond", (1, 77, 768), 52).bfloat16().float()
+  ctx = torch.cat([uncond, cond], 0)
+  sched = scheduler_ref.PNDMSchedulerRef()
+  sched.set_timesteps(10)
+  lat = synth.initial_latents(1, 4, 64, seed=5252) * sched.init_noise_sigma
+  worst = 0.0
+  assert len(sched.timesteps) == 11
+  for i, t in enumerate(sched.timesteps):
+    inp = sched.scale_model_input(torch.cat([lat] * 2), t)
+    tt = torch.full((2,), float(t))
+    ref = unet_ref.unet_forward(sd, inp, tt, ctx)
+    got = pipe.unet(inp, tt, ctx)
+    _, rel, cos = _stats(f"teacher-forced eps, call {i}, t = {t}", got, ref)
+    worst = max(worst, rel)
+    assert rel < 2.5e-2 and cos > 0.9995, f"call {i} (t = {t}): rel-L2 {rel:.3e}"
+    eu, ec = ref.chunk(2)
+    lat = sched.step(eu + 7.5 * (ec - eu), t, lat)          # the oracle's trajectory (custom_sd.py:641-646)
+  print(f"[teacher-forced eps] worst rel-L2 over 11 calls {worst:.3e}")
+
+
+@SLOW
+def test_sd21_768_full_size_forward_vs_oracle(cuda):
+  """BASELINE configs[3] at its real size: SD-2.1-768 UNet (96x96 latents -> 96/48/24/12-wide maps, 5/10/20/20 heads of 64, 1024-d
+  context, N_kv = 9216 self-attention), one forward of batch 2 against the oracle.  144 GroupNorm partials per bin at level 0:
+  the out-of-place totals path."""
+  from gill_amd.sd import GillSDPipeline
+  from oracle import unet_ref
+  cfg = synth.UNetConfig.sd21_768()
+  sd = _bfw(synth.unet_state_dict(cfg, seed=61))
+  uncond = synth.uncond_context(cfg.ctx_len, cfg.cross_attention_dim, seed=61).bfloat16().float()
+  pipe = GillSDPipeline(sd, cfg, uncond, cuda, max_batch=2)
+  x = synth.initial_latents(2, 4, 96, seed=6161)
+  ctx = torch.cat([uncond, synth.normal("sd21_ctx", (1, 77, 1024), 62)], 0).bfloat16().float()
+  t = torch.tensor([801.0, 801.0])
+  ref = unet_ref.unet_forward(sd, x, t, ctx, cfg.block_out_channels, cfg.heads_per_level, cfg.norm_num_groups)
+  got = pipe.unet(x, t, ctx)
+  _, rel, cos = _stats("SD-2.1-768 full-size forward (96x96)", got, ref)
+  assert got.shape == ref.shape == (2, 4, 96, 96)
+  assert rel < 5e-2 and cos > 0.998
+  # the CFG shared-prefix path of gill_sd_denoise at this size (the first total covers only half the batch): finite, repeatable
+  lat0 = synth.initial_latents(1, 4, 96, seed=6262)
+  a = pipe(prompt_embeds=ctx[1:], latents=lat0, guidance_scale=7.5, num_inference_steps=2, output_type="latent").images
+  b = pipe(prompt_embeds=ctx[1:], latents=lat0, guidance_scale=7.5, num_inference_steps=2, output_type="latent").images
+  assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("sample_size", [96, 72])
+def test_unet_reduced_width_many_groupnorm_partials_vs_oracle(cuda, sample_size):
+  """with more than 64 partial sums per (sample, bin) the totals used to overwrite the producer's slab-0
+  partial, and the up block's concatenated norm1 — the SECOND consumer of every skip tensor — then totalled {T, p1, ...} again.
+  Reduced width (64/128/256/256), 96x96 latents (144 partials at level 0; split-K reducers with 16-row slabs at level 1) and
+  72x72 (81 partials): one forward and a 4-step CFG loop (shared-prefix path) against the oracle."""
+  from gill_amd.sd import GillSDPipeline
+  from oracle import pipeline_ref, unet_ref
+  cfg = synth.UNetConfig.tiny(sample_size)
+  sd = _bfw(synth.unet_state_dict(cfg, seed=71))
+  uncond = synth.uncond_context(cfg.ctx_len, cfg.cross_attention_dim, seed=71).bfloat16().float()
+  pipe = GillSDPipeline(sd, cfg, uncond, cuda, max_batch=4)
+  B = 3
+  x = synth.normal("gnp_x", (B, 4, sample_size, sample_size), 72)
+  ctx = synth.normal("gnp_ctx", (B, 77, cfg.cross_attention_dim), 72).bfloat16().float()
+  t = torch.tensor([981.0, 501.0, 21.0])
+  ref = unet_ref.unet_forward(sd, x, t, ctx, cfg.block_out_channels, cfg.num_heads, cfg.norm_num_groups)
+  got = pipe.unet(x, t, ctx)
+  _, rel, cos = _stats(f"reduced-width UNet forward at {sample_size}x{sample_size}", got, ref)
+  assert rel < 5e-2 and cos > 0.998
+  cond = ctx[:2]
+  lat0 = synth.initial_latents(2, 4, sample_size, seed=7373)
+  refl = pipeline_ref.denoise(sd, cond, uncond, lat0, 4, 7.5, cfg.block_out_channels, cfg.num_heads, cfg.norm_num_groups)
+  gotl = pipe(prompt_embeds=cond, latents=lat0, guidance_scale=7.5, num_inference_steps=4).images
+  _, rell, cosl = _stats(f"reduced-width 4-step CFG loop at {sample_size}x{sample_size}", gotl, refl)
+  assert rell < 8e-2 and cosl > 0.995
+
+
+def test_guidance_scale_is_not_baked_into_the_captured_step(cuda):
+  """the guidance scale used to be part of the graph key (one captured hipGraphExec per value, never evicted).  It is
+  a device-side scalar now: a sweep re-uses ONE captured step and every value still gives its own (oracle-checked) answer."""
+  from gill_amd.sd import GillSDPipeline
+  from oracle import pipeline_ref
+  cfg = synth.UNetConfig.tiny(16)
+  sd = _bfw(synth.unet_state_dict(cfg, seed=3))
+  uncond = synth.uncond_context(cfg.ctx_len, cfg.cross_attention_dim, seed=3).bfloat16().float()
+  pipe = GillSDPipeline(sd, cfg, uncond, cuda, max_batch=2)
+  cond = synth.normal("gs_cond", (1, 77, cfg.cross_attention_dim), 4).bfloat16().float()
+  lat0 = synth.initial_latents(1, 4, 16, seed=1337)
+  outs = {}
+  for gs in (7.5, 3.0, 12.0, 7.5):
+    got = pipe(prompt_embeds=cond, latents=lat0, guidance_scale=gs, num_inference_steps=4).images
+    if gs in outs:
+      assert torch.equal(got, outs[gs]), "same guidance scale, different latents"
+      continue
+    outs[gs] = got
+    ref = pipeline_ref.denoise(sd, cond, uncond, lat0, 4, gs, cfg.block_out_channels, cfg.num_heads, cfg.norm_num_groups)
+    _, rel, cos = _stats(f"guidance {gs}, 4 steps", got, ref)
+    assert rel < 8e-2 and cos > 0.995
+  assert not torch.equal(outs[3.0], outs[12.0])
+
+
+def _run_bench(args, timeout=1500):
+  r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                     timeout=timeout, cwd=ROOT)
+  assert r.returncode == 0, r.stderr.decode()[-3000:]
+  lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+  assert len(lines) == 1, r.stdout.decode()[-2000:]
+  return json.loads(lines[0])
+
+
+def test_bench_two_ranks_full_size_c3_share_gloo(cuda):
+  """Two ranks, each with the FULL-SIZE models (opt-6.7b + SD-1.5 + VAE shapes) and BASELINE configs[2]'s 8 prompts per rank (UNet
+  batch 16), sharing cuda:0 over gloo: the per-rank program of the 8-GPU run (shard, denoise, all-gather, local decode), 2 PLMS
+  steps.  On an N-GPU node the same code runs with backend nccl (= RCCL), one rank per GPU."""
+  rec = _run_bench(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--prompts-per-gpu", "8", "--infer-steps", "2", "--steps", "2",
+                    "--warmup", "1", "--no-cpu-baseline", "--no-pmc"])
+  assert rec["n_gpus"] == 2 and rec["config"]["prompts_per_gpu"] == 8 and rec["config"]["global_batch"] == 16
+  assert "configs[2]" in rec["config"]["workload"] and rec["scaling"] == "weak"
+  assert rec["output_check"]["max_rel_l2_vs_first_step"] == 0.0 and rec["value"] > 0
+  print(f"[bench 2 ranks full size] model build {rec['config']['model_build_s']} s per rank, {rec['ms_per_step']:.0f} ms per step")
+
+
+def test_bench_eight_ranks_uneven_shards_gloo(cuda):
+  """World size 8 dry run: `python bench.py --gpus 8` self-spawns eight ranks on 127.0.0.1; 61 prompts split
+  8,8,8,8,8,7,7,7 (uneven shards are padded for the collective and trimmed); small OPT, real SD-1.5-sized kernels would not fit
+  eight times in a test budget, so --small shapes.  Also B = 5 < world: three ranks enter the collective with empty shards."""
+  rec = _run_bench(["--gpus", "8", "--backend", "gloo", "--share-gpu", "--small", "--total-prompts", "61", "--infer-steps", "2",
+                    "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pmc"])
+  assert rec["n_gpus"] == 8 and rec["config"]["global_batch"] == 61
+  assert rec["output_check"]["max_rel_l2_vs_first_step"] == 0.0 and rec["value"] > 0
+  print(f"[bench 8 ranks, 61 prompts] model build {rec['config']['model_build_s']} s per rank, {rec['ms_per_step']:.0f} ms per step")
+  rec = _run_bench(["--gpus", "8", "--backend", "gloo", "--share-gpu", "--small", "--total-prompts", "5", "--infer-steps", "2",
+                    "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-pmc"])
+  assert rec["n_gpus"] == 8 and rec["config"]["global_batch"] == 5 and rec["value"] > 0

@@ -164,6 +164,65 @@ def test_image_prompt_vs_reference_golden(cuda):
   assert gen.shape == (1, 77, 768) and mse < 1e-4
 
 
+def test_retrieval_visual_embs_and_rerank_vs_reference_golden(cuda, tmp_path):
+  """Golden F9: GILLModel.get_visual_embs(mode='retrieval') (gill/models.py:141-146: CLIP pooler_output -> visual_fc -> (B,1,256))
+  and the CLIP rerank of generated images (gill/models.py:733-751: resize, feature extractor, retrieval embeddings, normalise,
+  scores against ret_emb, sort) against the REFERENCE's own outputs.  As in the fixture's generating script, the SD pipeline is a
+  stand-in that returns the fixture's two fixed images: stage 3 has its own fixtures, the code under test is everything after."""
+  from PIL import Image
+  from gill_amd.models import GILL
+  g = np.load(os.path.join(GOLD, "gill_visual_tiny.npz"))
+  ccfg = synth.ClipConfig.tiny()
+  tok = synth.HashTokenizer()
+  ocfg = synth.OptConfig(vocab_size=50274, hidden_size=768, num_layers=12, num_heads=12, ffn_dim=3072)
+  args = SimpleNamespace(freeze_lm=True, freeze_vm=True, opt_version="facebook/opt-125m", visual_encoder="openai/clip-tiny",
+                         n_visual_tokens=4, ret_emb_dim=256, gen_emb_dim=768, text_emb_layers=[-1], text_fc_mode="gill_mapper",
+                         ret_text_fc_mode="linear", num_tokens=8, num_clip_tokens=77, retrieval_token_idx=synth.IMG_TOKEN_IDS,
+                         gen_token_idx=synth.IMG_TOKEN_IDS, opt_state_dict=_bfw(synth.opt_state_dict(ocfg, seed=int(g["opt_seed"]))),
+                         clip_state_dict=_bfw(synth.clip_state_dict(ccfg, seed=int(g["clip_seed"]))), clip_config=ccfg)
+  n_img = int(g["n_img"])
+  paths = []
+  for k in range(n_img):
+    arr = np.full((20, 20, 3), (7 * k) % 256, dtype=np.uint8)
+    arr[:, :, 1] = (13 * k + 5) % 256
+    p = str(tmp_path / f"{k}.png")
+    Image.fromarray(arr).save(p)
+    paths.append(p)
+  emb_matrix = synth.normal("cc3m_emb_matrix", (n_img, 256), int(g["clip_seed"]))
+  emb_matrix = emb_matrix / emb_matrix.norm(dim=-1, keepdim=True)
+  gen_arrs = g["rerank_images"]
+
+  class _StubPipe:      # the stand-in of oracle/gen_golden.py F9
+    _vae = True         # "holds VAE weights": .images are PIL images (gill/custom_sd.py:491 default output_type)
+
+    def __call__(self, prompt_embeds=None, **kw):
+      return SimpleNamespace(images=[Image.fromarray(a) for a in gen_arrs[:prompt_embeds.shape[0]]])
+  m = GILL(tok, args, path_array=paths, emb_matrix=emb_matrix, load_sd=True, sd_pipe=_StubPipe(), num_gen_images=2)
+  w = {}
+  synth._linear(w, "visual_fc", 256, ccfg.hidden_size, int(g["clip_seed"]))
+  synth._linear(w, "ret_text_hidden_fcs.0.model", 256, 768, int(g["clip_seed"]))
+  with torch.no_grad():
+    m.model.visual_fc.weight.copy_(w["visual_fc.weight"].bfloat16().float())
+    m.model.visual_fc.bias.copy_(w["visual_fc.bias"].bfloat16().float())
+    m.model.ret_text_hidden_fcs[0].model.weight.copy_(w["ret_text_hidden_fcs.0.model.weight"].bfloat16().float())
+    m.model.ret_text_hidden_fcs[0].model.bias.copy_(w["ret_text_hidden_fcs.0.model.bias"].bfloat16().float())
+  m.model.gen_text_hidden_fcs[0].load_state_dict(_bfw(synth.mapper_state_dict(synth.MapperConfig(in_dim=768), seed=int(g["mapper_seed"]))),
+                                                 strict=True)
+  m = m.eval().bfloat16().cuda()
+  m.emb_matrix = emb_matrix.to(cuda)
+  ve = m.model.get_visual_embs(torch.from_numpy(g["pixel_values"]).to(cuda), mode="retrieval")
+  assert ve.shape == (3, 1, 256)
+  _, rel, cos = _stats("get_visual_embs(mode='retrieval') vs the reference", ve, torch.from_numpy(g["visual_embs_retrieval"]))
+  assert rel < 3e-2 and cos > 0.999
+  ret = m.generate_for_images_and_texts([str(g["text"])], num_words=2, gen_scale_factor=1e5)
+  gens = ret[1]["gen"]
+  reds = [int(np.asarray(im)[0, 0, 0]) for im, _ in gens]
+  scores = np.array([sc for _, sc in gens])
+  print("[rerank] order", reds, "scores", scores.tolist(), "reference", g["rerank_red"].tolist(), g["rerank_scores"].tolist())
+  assert reds == g["rerank_red"].tolist()
+  assert np.abs(scores - g["rerank_scores"]).max() < 3e-3
+
+
 def test_retrieval_branch_vs_reference_golden(cuda, tmp_path):
   """ret_text_hidden_fcs Linear -> normalise -> emb_matrix @ ret_emb.T -> top-3 local images,
   against the reference's own scores / picks (golden F7), plus the decision MLP against plain fp32 math."""
@@ -446,6 +505,9 @@ def test_vae_decode_tiny_vs_oracle(cuda):
   cond = synth.normal("dn_cond", (1, 77, cfg.cross_attention_dim), 4).bfloat16().float()
   ims = pipe(prompt_embeds=cond, latents=lat[:1], guidance_scale=7.5, num_inference_steps=3, output_type="pil").images
   assert len(ims) == 1 and ims[0].size == (128, 128)
+  # the default output type is the reference's (custom_sd.py:491 output_type="pil") once VAE weights are loaded
+  dflt = pipe(prompt_embeds=cond, latents=lat[:1], guidance_scale=7.5, num_inference_steps=3).images
+  assert isinstance(dflt, list) and np.array_equal(np.asarray(dflt[0]), np.asarray(ims[0]))
   arr = pipe(prompt_embeds=cond, latents=lat[:1], guidance_scale=7.5, num_inference_steps=3, output_type="np").images
   assert arr.shape == (1, 128, 128, 3) and 0.0 <= arr.min() and arr.max() <= 1.0
   # run-to-run: every reduction is fixed-order (per-slab partial sums, no atomics), so two runs are bit-identical
