@@ -261,10 +261,30 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
   const int lw = AI + (w_last_ok ? WI : WI - 1);           // LDS-DMA instructions this wave issues per stage
   const bf16_t* w_ptr[WI];
   int n_issue = n0;        // first column of the N tile being staged
+  // WIDE EPILOGUE STORES.  The MFMA (W fragment as the A operand) leaves a lane with 4 consecutive output columns of one row per
+  // 16-wide sub-tile j; stored as they are, a wave instruction writes 16 rows x 32 B.  Which weight row sits in which LDS tile row
+  // is free (the DMA source address is per lane), so tile row (j, x) of a wave's half is loaded with column c(j, x) such that the
+  // sub-tiles j, j + 1 of a lane hold 8 CONSECUTIVE columns: c = (j >> 1) * 32 + (x >> 2) * 8 + (j & 1) * 4 + (x & 3) — one 16-B
+  // store per lane, 64 contiguous bytes per row per instruction, half the store instructions (a last unpaired sub-tile, NT odd,
+  // keeps c = j * 16 + x).  GEGLU (EPI 1; weight rows come in [16 value | 16 gate] blocks of 16 outputs): value and gate
+  // sub-tiles of two pairs are laid out so that the lane's two products are 8 consecutive OUTPUT columns.
+  auto tile_col = [&](int R) -> int {    // LDS tile row R -> column of the tile whose weight row it holds
+    const int half = R / (BN / 2), q = R - half * (BN / 2);
+    const int j = q >> 4, x = q & 15;
+    int c;
+    if constexpr (EPI == 1) {
+      static_assert(EPI != 1 || NT % 4 == 0, "GEGLU: whole value/gate quads per wave");
+      const int o = (x >> 2) * 8 + ((j >> 1) & 1) * 4 + (x & 3);          // output column within the quad's 32
+      c = (j >> 2) * 64 + (o >> 4) * 32 + (o & 15) + (j & 1) * 16;       // physical: [16 value | 16 gate] per 16 outputs
+    } else {
+      c = ((j | 1) < NT) ? (j >> 1) * 32 + (x >> 2) * 8 + (j & 1) * 4 + (x & 3) : q;
+    }
+    return half * (BN / 2) + c;
+  };
   auto w_setup = [&]() {
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      int row = (i * NWV + w) * RPI + srow;
+      int row = tile_col((i * NWV + w) * RPI + srow);
       int n = n_issue + row;
       if (n > p.N - 1) n = p.N - 1;
       w_ptr[i] = p.W + (size_t)n * p.K + schunk * 8 + kt_beg * KT;
@@ -555,9 +575,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
     }
   }
 
-  // ---- epilogue.  acc[i][j][r]: m = m0 + wm*64 + i*16 + (lane&15), n = n0 + wn*BN/2 + j*16 + (lane>>4)*4 + r
+  // ---- epilogue.  acc[i][j][r]: m = m0 + wm*(MI*16) + i*16 + (lane&15); column: see tile_col() — sub-tiles (2g, 2g+1) of a lane
+  // hold the 8 consecutive columns nbase + g*32 + fkc*8 .. +7 (registers r of sub-tile 2g, then of 2g+1); an unpaired last
+  // sub-tile (NT odd) holds nbase + j*16 + fkc*4 .. +3
   const int mrow = m0 + wm * (MI * 16) + frow;
-  const int ncol = n0 + wn * (BN / 2) + fkc * 4;
+  const int nbase = n0 + wn * (BN / 2);
+  constexpr int NG = (NT + 1) / 2;      // column groups per lane
   if constexpr (EPI == 2) {
     float* ws = p.ws + (size_t)z * p.M * p.N;
 #pragma unroll
@@ -565,40 +588,55 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       const int m = mrow + i * 16;
       if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = ncol + j * 16;
+      for (int g = 0; g < NG; ++g) {
+        const bool pair = (2 * g + 1 < NT);
+        const int j1 = pair ? 2 * g + 1 : 2 * g;
+        const int n = nbase + (pair ? g * 32 + fkc * 8 : (2 * g) * 16 + fkc * 4);
         if (n >= p.N) continue;
-        *reinterpret_cast<float4*>(ws + (size_t)m * p.N + n) =
-            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        float* dst = ws + (size_t)m * p.N + n;
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[i][2 * g][0], acc[i][2 * g][1], acc[i][2 * g][2], acc[i][2 * g][3]);
+        if (pair && n + 4 < p.N)
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[i][j1][0], acc[i][j1][1], acc[i][j1][2], acc[i][j1][3]);
       }
     }
   } else if constexpr (EPI == 1) {
-    // weight rows are interleaved in 16-row blocks: even block = value rows, odd block = gate rows
+    // weight rows are interleaved in 16-row blocks (even block = value rows, odd block = gate rows of 16 outputs); tile_col() deals
+    // a quad of sub-tiles (value, gate, value, gate) so that the lane's 2 x 4 products are 8 consecutive output columns
     const float* rr = ln_rr; const float* rm = ln_rm;
 #pragma unroll
-    for (int j = 0; j + 1 < NT; j += 2) {
-      const int nv = ncol + j * 16;         // physical column of the value block
-      const int ng = nv + 16;               // physical column of the gate block
-      if (ng >= p.N) continue;
-      const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + nv) : make_float4(0, 0, 0, 0);
-      const float4 bg = p.bias ? *reinterpret_cast<const float4*>(p.bias + ng) : make_float4(0, 0, 0, 0);
-      const int no = (nv >> 5) * 16 + (nv & 15);  // logical output column
-      const float4 sv = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + nv) : make_float4(0, 0, 0, 0);
-      const float4 sg = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + ng) : make_float4(0, 0, 0, 0);
+    for (int qd = 0; qd < NT / 4; ++qd) {
+      const int ol = fkc * 8;                                          // output column within the quad's 32 (first of 8)
+      const int pv = nbase + qd * 64 + (ol >> 4) * 32 + (ol & 15);     // physical column of the first value row (4 consecutive; +4: second pair)
+      if (nbase + qd * 64 >= p.N) continue;            // (N % 128 == 0: a quad's 64 physical columns are all inside or all outside)
+      const int no = (nbase + qd * 64) / 2 + ol;                       // logical output column (8 consecutive)
+      float4 bv[2], bg[2], sv[2], sg[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bv[h] = p.bias ? *reinterpret_cast<const float4*>(p.bias + pv + 4 * h) : make_float4(0, 0, 0, 0);
+        bg[h] = p.bias ? *reinterpret_cast<const float4*>(p.bias + pv + 16 + 4 * h) : make_float4(0, 0, 0, 0);
+        sv[h] = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + pv + 4 * h) : make_float4(0, 0, 0, 0);
+        sg[h] = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + pv + 16 + 4 * h) : make_float4(0, 0, 0, 0);
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int m = mrow + i * 16;
         if (m >= p.M) continue;
-        const float o0 = (acc[i][j][0] * rr[i] - rm[i] * sv.x + bv.x) * gelu_erf(acc[i][j + 1][0] * rr[i] - rm[i] * sg.x + bg.x);
-        const float o1 = (acc[i][j][1] * rr[i] - rm[i] * sv.y + bv.y) * gelu_erf(acc[i][j + 1][1] * rr[i] - rm[i] * sg.y + bg.y);
-        const float o2 = (acc[i][j][2] * rr[i] - rm[i] * sv.z + bv.z) * gelu_erf(acc[i][j + 1][2] * rr[i] - rm[i] * sg.z + bg.z);
-        const float o3 = (acc[i][j][3] * rr[i] - rm[i] * sv.w + bv.w) * gelu_erf(acc[i][j + 1][3] * rr[i] - rm[i] * sg.w + bg.w);
-        uint2 o; o.x = pack_bf2(o0, o1); o.y = pack_bf2(o2, o3);
-        *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + no) = o;
+        float o[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 av = acc[i][qd * 4 + 2 * h], ag = acc[i][qd * 4 + 2 * h + 1];
+          o[4 * h + 0] = (av[0] * rr[i] - rm[i] * sv[h].x + bv[h].x) * gelu_erf(ag[0] * rr[i] - rm[i] * sg[h].x + bg[h].x);
+          o[4 * h + 1] = (av[1] * rr[i] - rm[i] * sv[h].y + bv[h].y) * gelu_erf(ag[1] * rr[i] - rm[i] * sg[h].y + bg[h].y);
+          o[4 * h + 2] = (av[2] * rr[i] - rm[i] * sv[h].z + bv[h].z) * gelu_erf(ag[2] * rr[i] - rm[i] * sg[h].z + bg[h].z);
+          o[4 * h + 3] = (av[3] * rr[i] - rm[i] * sv[h].w + bv[h].w) * gelu_erf(ag[3] * rr[i] - rm[i] * sg[h].w + bg[h].w);
+        }
+        uint4 ov; ov.x = pack_bf2(o[0], o[1]); ov.y = pack_bf2(o[2], o[3]); ov.z = pack_bf2(o[4], o[5]); ov.w = pack_bf2(o[6], o[7]);
+        *reinterpret_cast<uint4*>((bf16_t*)p.C + (size_t)m * p.ldc + no) = ov;
       }
     }
   } else if constexpr (EPI == 3) {
-    // head-major scatter; all divisions hoisted: per-row (b, t) once, per-column (segment, head, dd) once
+    // head-major scatter; all divisions hoisted: per-row (b, t) once, per-column-group (segment, head, dd) once (dp % 8 == 0: the 8
+    // columns of a group lie in one head of one segment)
     int rq[MI], rk[MI], rv[MI]; bool mok[MI];
     float rr[MI], rm[MI];
 #pragma unroll
@@ -613,75 +651,118 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
     }
     const int hd = p.heads * p.dp;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = ncol + j * 16;
+    for (int g = 0; g < NG; ++g) {
+      const bool pair = (2 * g + 1 < NT);
+      const int j1 = pair ? 2 * g + 1 : 2 * g;
+      const int n = nbase + (pair ? g * 32 + fkc * 8 : (2 * g) * 16 + fkc * 4);
       if (n >= p.N) continue;
+      const bool hi = pair && (n + 4 < p.N);
       const int segl = n / hd;
       const int within = n - segl * hd;
       const int h = within / p.dp, dd = within - h * p.dp;
       const int seg = p.seg_base + segl;
-      const float4 bz = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
-      const float4 cs = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + n) : make_float4(0, 0, 0, 0);
+      float4 bz[2], cs[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bool ok = (e == 0) || hi;
+        bz[e] = (p.bias && ok) ? *reinterpret_cast<const float4*>(p.bias + n + 4 * e) : make_float4(0, 0, 0, 0);
+        cs[e] = (p.ln_stats && ok) ? *reinterpret_cast<const float4*>(p.ln_colsum + n + 4 * e) : make_float4(0, 0, 0, 0);
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         if (!mok[i]) continue;
-        float v0 = acc[i][j][0] * rr[i] - rm[i] * cs.x + bz.x, v1 = acc[i][j][1] * rr[i] - rm[i] * cs.y + bz.y;
-        float v2 = acc[i][j][2] * rr[i] - rm[i] * cs.z + bz.z, v3 = acc[i][j][3] * rr[i] - rm[i] * cs.w + bz.w;
+        float v[8];
+        const f32x4 a0 = acc[i][2 * g], a1 = acc[i][j1];
+        v[0] = a0[0] * rr[i] - rm[i] * cs[0].x + bz[0].x; v[1] = a0[1] * rr[i] - rm[i] * cs[0].y + bz[0].y;
+        v[2] = a0[2] * rr[i] - rm[i] * cs[0].z + bz[0].z; v[3] = a0[3] * rr[i] - rm[i] * cs[0].w + bz[0].w;
+        v[4] = a1[0] * rr[i] - rm[i] * cs[1].x + bz[1].x; v[5] = a1[1] * rr[i] - rm[i] * cs[1].y + bz[1].y;
+        v[6] = a1[2] * rr[i] - rm[i] * cs[1].z + bz[1].z; v[7] = a1[3] * rr[i] - rm[i] * cs[1].w + bz[1].w;
         if (seg == 0) {
-          v0 *= p.qscale; v1 *= p.qscale; v2 *= p.qscale; v3 *= p.qscale;   // softmax scale * log2(e) folded into Q
-          uint2 o; o.x = pack_bf2(v0, v1); o.y = pack_bf2(v2, v3);
-          *reinterpret_cast<uint2*>(p.Cq + (size_t)rq[i] + (size_t)h * p.ntok_pad_q * p.dp + dd) = o;
-        } else if (seg == 1) {
-          uint2 o; o.x = pack_bf2(v0, v1); o.y = pack_bf2(v2, v3);
-          *reinterpret_cast<uint2*>(p.Ck + (size_t)rk[i] + (size_t)h * p.ntok_pad_kv * p.dp + dd) = o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= p.qscale;   // softmax scale * log2(e) folded into Q
+        }
+        if (seg <= 1) {
+          bf16_t* dst = (seg == 0) ? p.Cq + (size_t)rq[i] + (size_t)h * p.ntok_pad_q * p.dp + dd
+                                   : p.Ck + (size_t)rk[i] + (size_t)h * p.ntok_pad_kv * p.dp + dd;
+          if (hi) {
+            uint4 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
+            *reinterpret_cast<uint4*>(dst) = o;
+          } else {
+            uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(dst) = o;
+          }
         } else {
           bf16_t* base = p.Cvt + (size_t)rv[i] + (size_t)(h * p.dpv + dd) * p.ntok_pad_kv;
-          base[0] = f2bf(v0);
-          base[(size_t)p.ntok_pad_kv] = f2bf(v1);
-          base[(size_t)2 * p.ntok_pad_kv] = f2bf(v2);
-          base[(size_t)3 * p.ntok_pad_kv] = f2bf(v3);
+          const int ne = hi ? 8 : 4;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (e < ne) base[(size_t)e * p.ntok_pad_kv] = f2bf(v[e]);
           // spare row dp of Vt := 1.0: the attention kernel reads the softmax row sum off the PV MFMAs
-          if (dd + 4 == p.dp && p.dpv > p.dp) base[(size_t)4 * p.ntok_pad_kv] = (bf16_t)0x3F80;
+          if (dd + ne == p.dp && p.dpv > p.dp) base[(size_t)ne * p.ntok_pad_kv] = (bf16_t)0x3F80;
         }
       }
     }
   } else {
     // row-major epilogue; per-row offsets (incl. the batch index of the row vector) hoisted out of the column loop
-    size_t crow[MI], rrow[MI]; int vrow[MI]; bool mok[MI];
+    // (32-bit element offsets: gemm_launch() checks M * max(ldc, ldr) < 2^31)
+    int crow[MI], rrow[MI], vrow[MI]; bool mok[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = mrow + i * 16;
       mok[i] = m < p.M;
-      crow[i] = (size_t)m * p.ldc;
-      rrow[i] = (size_t)m * p.ldr;
+      crow[i] = m * p.ldc;
+      rrow[i] = m * p.ldr;
       vrow[i] = p.rowvec ? (m / p.rows_per_batch) * p.rowvec_bstride : 0;
     }
     // fused GroupNorm statistics of the OUTPUT tensor (consumed by the next GroupNorm: saves its whole stats pass).
     // The 64 rows of a wave belong to one slab of one sample (rows_per_batch % 64 == 0).  Fixed-order reduction: 4 rows in the
     // lane, 16 row lanes by xor-shuffles, one LDS cell per (row half, column) written once (the tile ring is dead by now),
     // then one thread per (row half, bin, moment) adds the bin's gn_cg columns and stores the partial: no atomics anywhere.
-    float* red = reinterpret_cast<float*>(smem);     // [2 moments][NWV / 2 wave rows][BN]
+    float2* red = reinterpret_cast<float2*>(smem);   // [NWV / 2 wave rows][BN] {sum, sum of squares}: one 8-byte LDS write per column at
+                                                     // base + immediate offset (separate moment planes cost one address register per column)
+    float2* red_lane = red + wm * BN + wn * (BN / 2);
     if (p.gn_stats) __syncthreads();                 // every wave is done reading the ring
     float rws[4] = {0.f, 0.f, 0.f, 0.f}, rwq[4] = {0.f, 0.f, 0.f, 0.f};   // row sums for a following (folded) LayerNorm
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = ncol + j * 16;
+    for (int g = 0; g < NG; ++g) {
+      const bool pair = (2 * g + 1 < NT);
+      const int j1 = pair ? 2 * g + 1 : 2 * g;
+      const int cl = pair ? g * 32 + fkc * 8 : (2 * g) * 16 + fkc * 4;    // first column of the group within the wave's half
+      const int n = nbase + cl;
       if (n >= p.N) continue;
-      const float4 bz = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
-      float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+      const bool hi = pair && (n + 4 < p.N);
+      float4 bz[2];
+      bz[0] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
+      bz[1] = (p.bias && hi) ? *reinterpret_cast<const float4*>(p.bias + n + 4) : make_float4(0, 0, 0, 0);
+      float gs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         if (!mok[i]) continue;
-        float v[4] = {acc[i][j][0] * p.alpha + bz.x, acc[i][j][1] * p.alpha + bz.y, acc[i][j][2] * p.alpha + bz.z,
-                      acc[i][j][3] * p.alpha + bz.w};
+        const f32x4 a0 = acc[i][2 * g], a1 = acc[i][j1];
+        float v[8] = {a0[0] * p.alpha + bz[0].x, a0[1] * p.alpha + bz[0].y, a0[2] * p.alpha + bz[0].z, a0[3] * p.alpha + bz[0].w,
+                      a1[0] * p.alpha + bz[1].x, a1[1] * p.alpha + bz[1].y, a1[2] * p.alpha + bz[1].z, a1[3] * p.alpha + bz[1].w};
         if (p.rowvec) {
-          const float4 b = *reinterpret_cast<const float4*>(p.rowvec + vrow[i] + n);
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+          const float4 b0 = *reinterpret_cast<const float4*>(p.rowvec + vrow[i] + n);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+          if (hi) {
+            const float4 b1 = *reinterpret_cast<const float4*>(p.rowvec + vrow[i] + n + 4);
+            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+          }
         }
         if (p.resid) {
           if (p.resid_f32) {
-            const float4 r = *reinterpret_cast<const float4*>((const float*)p.resid + rrow[i] + n);
-            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+            const float4 r0 = *reinterpret_cast<const float4*>((const float*)p.resid + rrow[i] + n);
+            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+            if (hi) {
+              const float4 r1 = *reinterpret_cast<const float4*>((const float*)p.resid + rrow[i] + n + 4);
+              v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            }
+          } else if (hi) {
+            const uint4 r = *reinterpret_cast<const uint4*>((const bf16_t*)p.resid + rrow[i] + n);
+            v[0] += bf2f((bf16_t)(r.x & 0xffff)); v[1] += bf2f((bf16_t)(r.x >> 16));
+            v[2] += bf2f((bf16_t)(r.y & 0xffff)); v[3] += bf2f((bf16_t)(r.y >> 16));
+            v[4] += bf2f((bf16_t)(r.z & 0xffff)); v[5] += bf2f((bf16_t)(r.z >> 16));
+            v[6] += bf2f((bf16_t)(r.w & 0xffff)); v[7] += bf2f((bf16_t)(r.w >> 16));
           } else {
             const uint2 r = *reinterpret_cast<const uint2*>((const bf16_t*)p.resid + rrow[i] + n);
             v[0] += bf2f((bf16_t)(r.x & 0xffff)); v[1] += bf2f((bf16_t)(r.x >> 16));
@@ -690,34 +771,39 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
         }
         if (p.act != ACT_NONE) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+          for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
         }
         if (p.out_mode == OUT_F32) {
           *reinterpret_cast<float4*>((float*)p.C + crow[i] + n) = make_float4(v[0], v[1], v[2], v[3]);
+          if (hi) *reinterpret_cast<float4*>((float*)p.C + crow[i] + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
-          uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-          *reinterpret_cast<uint2*>((bf16_t*)p.C + crow[i] + n) = o;
+          uint4 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
+          if (hi) *reinterpret_cast<uint4*>((bf16_t*)p.C + crow[i] + n) = o;
+          else *reinterpret_cast<uint2*>((bf16_t*)p.C + crow[i] + n) = make_uint2(o.x, o.y);
           if (p.row_stats) {   // statistics of what the consumer will read: the rounded values
             const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
             const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
             rws[i] += (r0 + r1) + (r2 + r3);
             rwq[i] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+            if (hi) {
+              const float r4 = __uint_as_float(o.z << 16), r5 = __uint_as_float(o.z & 0xffff0000u);
+              const float r6 = __uint_as_float(o.w << 16), r7 = __uint_as_float(o.w & 0xffff0000u);
+              rws[i] += (r4 + r5) + (r6 + r7);
+              rwq[i] += (r4 * r4 + r5 * r5) + (r6 * r6 + r7 * r7);
+            }
           }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
+        for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
       }
       if (p.gn_stats) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 8; ++e) {
+          if (e >= 4 && !pair) break;
           float a = gs[e], q = gq[e];
 #pragma unroll
           for (int off = 1; off < 16; off <<= 1) { a += __shfl_xor(a, off, 64); q += __shfl_xor(q, off, 64); }
-          if (frow == 0) {
-            const int c = wn * (BN / 2) + j * 16 + fkc * 4 + e;
-            red[wm * BN + c] = a;
-            red[(NWV / 2) * BN + wm * BN + c] = q;
-          }
+          if (frow == 0) red_lane[cl + e] = make_float2(a, q);
         }
       }
     }
@@ -745,8 +831,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
           float a = 0.f;
 #pragma unroll
           for (int g = 0; g < GPS; ++g) {
-            const float* src = red + which * (NWV / 2) * BN + (half * GPS + g) * BN + lb * p.gn_cg;
-            for (int c = 0; c < p.gn_cg; ++c) a += src[c];
+            const float* src = reinterpret_cast<const float*>(red + (half * GPS + g) * BN + lb * p.gn_cg) + which;
+            for (int c = 0; c < p.gn_cg; ++c) a += src[2 * c];
           }
           const int b = mfirst / p.rows_per_batch;
           const int slab = (mfirst - b * p.rows_per_batch) / GN_SLAB_ROWS;
@@ -866,46 +952,29 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
 
 // width of the split-K reducer's blocks: 80 when the fused GroupNorm bins do not divide 64 (UNet: 5 / 10 / 20 / 40 channels)
 // (160 where N allows: a block row is then 640 B = five whole 128-B lines of a partial slice; 80-wide blocks read 320-B pieces, every
-// other one straddling a line.  GILL_REDUCE_W160 = 0 keeps 80)
+// other one straddling a line: loop 568.3 -> 562.5 ms, profiles/r02_big_tile.md)
 static inline int reduce_width(const GemmArgs& a) {
-  static const int w160 = [] { const char* v = getenv("GILL_REDUCE_W160"); return v ? atoi(v) : 1; }();
-  if (a.gn_stats && 64 % a.gn_cg != 0) return (w160 && a.N % 160 == 0 && 160 % a.gn_cg == 0) ? 160 : 80;
+  if (a.gn_stats && 64 % a.gn_cg != 0) return (a.N % 160 == 0 && 160 % a.gn_cg == 0) ? 160 : 80;
   return 64;
 }
 // rows per block of the reducer: 64 for large outputs, 16 when there would be too few blocks to pull the partials
 static inline int reduce_rows(const GemmArgs& a) {
   return ((int64_t)cdiv(a.N, reduce_width(a)) * cdiv(a.M, 64) >= 1024) ? 64 : 16;
 }
-// 256 x 256 tiles (8 waves, one workgroup per CU) for plain GEMMs without split-K / fused GroupNorm statistics.  OFF by
-// default: measured on the UNet's wide GEMMs (profiles/r02_big_tile.md) the level-0 GEGLU went 94 -> 100 us and the level-0 QKV
-// 46.6 -> 48.3 us — those kernels are bound by their epilogues (GELU / head scatter: VALU and stores), not by operand
-// fetch, and one workgroup per CU has nothing to hide an epilogue behind.  GILL_GEMM_BIG = 1 turns it on where legal
-// (2 = only where the output holds >= 256 such tiles and N wastes < 15 %).
-static inline bool big_tile(const GemmArgs& a) {
-  static const int forced = [] { const char* v = getenv("GILL_GEMM_BIG"); return v ? atoi(v) : 0; }();
-  if (forced <= 0 || a.conv || a.splitk > 1 || a.gn_stats || a.N < 256 || a.M < 256 || (a.stages == 3)) return false;
-  const int tn = cdiv(a.N, 256);
-  if (forced == 1) return true;
-  return (int64_t)cdiv(a.M, 256) * tn >= 256 && tn * 256 * 100 <= a.N * 115;
-}
+// Tile width.  Tried and removed (numbers in profiles/r02_big_tile.md, profiles/r01_sweep_gemm_tiles.md): a 256 x 256 8-wave tile for
+// the wide plain GEMMs (GEGLU 94 -> 100 us, QKV 46.6 -> 48.3 us: those kernels are bound by their epilogues), a 4-deep ring of
+// 32-wide K stages (+7 % on the loop), a 3-deep ring on the 4-wave tiles.
 static inline int tile_width(const GemmArgs& a) {
-  if (big_tile(a)) return 256;
   if (a.act == ACT_GEGLU) return 128;
-  static const int forced_bn = [] { const char* v = getenv("GILL_GEMM_BN"); return v ? atoi(v) : 0; }();
-  int bn = a.bn;
-  if (forced_bn == 128 || forced_bn == 160) bn = forced_bn;
   // measured on MI355X (profiles/r01_sweep_gemm_tiles.md): the 128x160 tile (5 N sub-tiles per wave: more MFMAs per LDS
   // byte) beats 128x128 by 15-40 % on every UNet width, all of which are multiples of 160
-  if (bn != 128 && bn != 160) bn = (a.N % 160 == 0) ? 160 : 128;
+  int bn = (a.N % 160 == 0) ? 160 : 128;
   // ... and except for the head-major scatter epilogue (QKV / to_q), whose columns fall into 48..160-wide heads: 128-wide tiles
-  // measured 579.3 -> 576.3 ms on the loop (GILL_GEMM_QKV128 = 0 restores 160)
-  static const int qkv128 = [] { const char* v = getenv("GILL_GEMM_QKV128"); return v ? atoi(v) : 1; }();
-  if (qkv128 && forced_bn == 0 && !a.conv && a.out_mode == OUT_QKV && a.N % 128 == 0) bn = 128;
+  // measured 579.3 -> 576.3 ms on the loop
+  if (!a.conv && a.out_mode == OUT_QKV && a.N % 128 == 0) bn = 128;
   // ... except on the 64-row tile (plain GEMMs with few tiles, see gemm_launch_bn): 64 x 128 needs 48 KiB of LDS, i.e. three
-  // workgroups (six waves) per CU instead of two (four) — loop 587.3 -> 584.7 ms (GILL_GEMM_BN64 = 160 restores 64 x 160)
-  static const int bn64 = [] { const char* v = getenv("GILL_GEMM_BN64"); return v ? atoi(v) : 128; }();
-  if (bn64 == 128 && forced_bn == 0 && !a.conv && a.splitk <= 1 && a.N % 128 == 0 && !a.gn_stats &&
-      (int64_t)cdiv(a.M, 128) * cdiv(a.N, 160) < 300 && a.M > 64) bn = 128;
+  // workgroups (six waves) per CU instead of two (four) — loop 587.3 -> 584.7 ms
+  if (!a.conv && a.splitk <= 1 && a.N % 128 == 0 && !a.gn_stats && (int64_t)cdiv(a.M, 128) * cdiv(a.N, 160) < 300 && a.M > 64) bn = 128;
   return bn;
 }
 int gemm_row_planes(const GemmArgs& a) {
@@ -1002,27 +1071,19 @@ static int gemm_launch_inst(const GemmDev& d, dim3 grid, hipStream_t s) {
 
 // d.nwv = 2 selects the 64-row tile (plain GEMMs, 2-deep ring, no split-K)
 template <int BN, int CONV, int EPI>
-static int gemm_launch_stages(const GemmDev& d, dim3 grid, int stages, hipStream_t s) {
-  if constexpr (BN == 256) {
-    return gemm_launch_inst<8, BN, CONV, EPI, 2>(d, grid, s);
-  } else {
-    if constexpr (CONV == 0 && EPI != 2) {
-      if (d.nwv == 2) return gemm_launch_inst<2, BN, CONV, EPI, 2>(d, grid, s);
-    }
-    if constexpr (CONV == 0 && (EPI == 0 || EPI == 3) && BN == 128) {
-      if (d.nwv == 4 && d.mi == 2) return gemm_launch_inst<4, BN, CONV, EPI, 2, BK, 2>(d, grid, s);   // 64-row tile on four waves
-    }
-    if constexpr (BN == 160 && CONV != 0) {
-      if (d.nwv == 8 && d.mi == 2) return gemm_launch_inst<8, BN, CONV, EPI, 3, BK, 2>(d, grid, s);   // ping-pong 128 x 160 tile
-      if (d.nwv == 8) return gemm_launch_inst<8, BN, CONV, EPI, 3>(d, grid, s);     // ping-pong 256 x 160 tile
-    }
-    if (stages == 3) return gemm_launch_inst<4, BN, CONV, EPI, 3>(d, grid, s);
-    if (d.kt == 32) return gemm_launch_inst<4, BN, CONV, EPI, 4, 32>(d, grid, s);
-    return gemm_launch_inst<4, BN, CONV, EPI, 2>(d, grid, s);
+static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
+  if constexpr (CONV == 0 && EPI != 2) {
+    if (d.nwv == 2) return gemm_launch_inst<2, BN, CONV, EPI, 2>(d, grid, s);
   }
+  if constexpr (CONV == 0 && (EPI == 0 || EPI == 3) && BN == 128) {
+    if (d.nwv == 4 && d.mi == 2) return gemm_launch_inst<4, BN, CONV, EPI, 2, BK, 2>(d, grid, s);   // 64-row tile on four waves
+  }
+  if constexpr (BN == 160 && CONV != 0) {
+    if (d.nwv == 8 && d.mi == 2) return gemm_launch_inst<8, BN, CONV, EPI, 3, BK, 2>(d, grid, s);   // ping-pong 128 x 160 tile
+    if (d.nwv == 8) return gemm_launch_inst<8, BN, CONV, EPI, 3>(d, grid, s);     // ping-pong 256 x 160 tile
+  }
+  return gemm_launch_inst<4, BN, CONV, EPI, 2>(d, grid, s);
 }
-
-// tuning knobs (tests / tools): GILL_GEMM_STAGES = 2|3 forces the ring depth, GILL_GEMM_BN = 128|160 the tile width
 
 template <int BN>
 static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
@@ -1033,41 +1094,29 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   const int sk = a.splitk > 1 ? a.splitk : 1;
   d.a.splitk = sk;
   d.tiles_n = cdiv(a.N, BN);
-  static const int forced = env_int("GILL_GEMM_STAGES");
-  int stages = a.stages;
-  if (forced == 2 || forced == 3) stages = forced;
-  if (stages != 3) stages = 2;
-  // 64-row tiles for plain GEMMs whose 128-row tiling leaves CUs without a tile (GILL_GEMM_BM = 64 | 128 forces it)
+  // 64-row tiles for plain GEMMs whose 128-row tiling leaves CUs without a tile (GILL_GEMM_BM = 64 | 128 forces it: tools/soak.py)
   static const int forced_bm = env_int("GILL_GEMM_BM");
   d.nwv = 4;
   // (tile_width() counts 128 x 160 tiles when it hands these GEMMs BN = 128, this rule counts 128 x 128 tiles: an 8192 x 640 GEMM
   // — 256 vs 320 — therefore lands on the 4-wave 128 x 128 tile, not the 64-row one; measured better that way: 567.8 vs 575.5 ms)
-  if (!a.conv && sk == 1 && stages == 2 && (int64_t)cdiv(a.M, 128) * d.tiles_n < 300 && a.M > 64) d.nwv = 2;   // measured: < 300 +0.3 %, < 520 -3 % end to end
+  if (!a.conv && sk == 1 && (int64_t)cdiv(a.M, 128) * d.tiles_n < 300 && a.M > 64) d.nwv = 2;   // measured: < 300 +0.3 %, < 520 -3 % end to end
   d.mi = 4;
   // the 64-row tile on FOUR waves (2 x 2, wave tile 32 x 64) where its width is 128: same LDS, twice the waves per CU —
-  // loop 580.4 -> 576.3 ms, 2048 x 1280 x 1280 19.8 -> 17.3 us (GILL_GEMM_MI2 = 0: two waves of 64 x 64)
-  static const int mi2 = [] { const char* v = getenv("GILL_GEMM_MI2"); return v ? atoi(v) : 1; }();
-  if (mi2 && d.nwv == 2 && BN == 128 && a.act != ACT_GEGLU && !a.gn_stats) { d.nwv = 4; d.mi = 2; }
+  // loop 580.4 -> 576.3 ms, 2048 x 1280 x 1280 19.8 -> 17.3 us
+  if (d.nwv == 2 && BN == 128 && a.act != ACT_GEGLU && !a.gn_stats) { d.nwv = 4; d.mi = 2; }
   if (forced_bm == 128) { d.nwv = 4; d.mi = 4; }
-  if (forced_bm == 64 && !a.conv && sk == 1 && stages == 2) d.nwv = 2;
-  if (BN == 256) d.nwv = 8;
+  if (forced_bm == 64 && !a.conv && sk == 1) { d.nwv = 2; d.mi = 4; }
   // 3x3 convolutions: 256 x 160 tile with the ping-pong main loop, one workgroup per CU (GILL_GEMM_PP = 0 keeps the two
   // co-resident 128 x 160 workgroups)
-  // (GILL_GEMM_PP_MINSTEPS = n keeps convs with fewer than n K steps per split on the 128-row tiles: measured 16 -> +0.2 %, 32 -> +0.5 %)
-  static const int pp_minsteps = env_int("GILL_GEMM_PP_MINSTEPS");
-  if (BN == 160 && a.conv && gemm_conv_pingpong(a.M, a.N) && forced_bm == 0 && forced != 2 &&
-      cdiv(a.K / 64, sk) >= pp_minsteps) {
-    d.nwv = 8; stages = 3;
+  if (BN == 160 && a.conv && gemm_conv_pingpong(a.M, a.N) && forced_bm == 0) {
+    d.nwv = 8;
     // Where the 256-row tiling x split-K gives at most 128 workgroups (UNet levels 1-3 at the 8-sample batch), run
     // 128 x 160 ping-pong tiles (eight waves of 32 x 80); gemm_pick_splitk() then aims at 256 workgroups of those, i.e. half the
     // split factor: half the fp32 partials (none at level 1)
     // (loop 561.1 -> 558.0 ms; GILL_GEMM_PP128 = 0 keeps the 256-row tile with twice the split)
     if (pp128_on() && (int64_t)cdiv(a.M, 256) * d.tiles_n * sk <= 128 && a.M % 128 == 0) d.mi = 2;
   }
-  // GILL_GEMM_KT = 32: 4-deep ring of 32-wide stages on the 128-row tiles (see the kernel's KT note).  Off by default: measured
-  // 7 % SLOWER on the denoise loop (608 -> 652 ms): the deeper prefetch does not pay for a barrier per 32-wide stage
-  static const int forced_kt = env_int("GILL_GEMM_KT");
-  d.kt = (forced_kt == 32 && d.nwv == 4 && stages == 2) ? 32 : 64;
+  d.kt = 64;
   d.ksteps = a.K / d.kt;
   d.ksteps_per_split = cdiv(d.ksteps, sk);
   const int tiles_m = cdiv(a.M, (d.nwv / 2) * d.mi * 16);
@@ -1076,8 +1125,8 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   // boundaries, so the loads of tile t+1 fly during the epilogue of tile t.  Keep ~2 workgroups per CU.
   d.npw = 1;
   static const int npw_off = env_int("GILL_GEMM_NPW_OFF");
-  if (!a.conv && sk == 1 && stages == 2 && !a.gn_stats && d.tiles_n >= 2 && !npw_off) {
-    int groups = cdiv(BN == 256 ? 256 : 512, tiles_m);   // ~2 workgroups per CU (one for the 8-wave tile)
+  if (!a.conv && sk == 1 && d.nwv != 8 && !a.gn_stats && d.tiles_n >= 2 && !npw_off) {
+    int groups = cdiv(512, tiles_m);   // ~2 workgroups per CU
     if (groups < 1) groups = 1;
     if (groups > d.tiles_n) groups = d.tiles_n;
     d.npw = cdiv(d.tiles_n, groups);
@@ -1085,31 +1134,28 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   d.groups_n = cdiv(d.tiles_n, d.npw);
   d.tiles_m = tiles_m;
   {
-    static const int forced_nm = [] { const char* v = getenv("GILL_GEMM_NMAJOR"); return v ? atoi(v) : -1; }();
     const int64_t wel = (int64_t)a.N * a.K;
     const int64_t ael = (int64_t)a.M * (a.conv ? a.Cin + a.KX : a.K);
-    d.n_major = (forced_nm >= 0) ? forced_nm : (wel > ael && d.groups_n >= 8 ? 1 : 0);
+    d.n_major = (wel > ael && d.groups_n >= 8) ? 1 : 0;
   }
   dim3 grid(tiles_m * d.groups_n, sk, 1);
-  if (BN == 160 && d.nwv == 8) GILL_REQUIRE(d.npw == 1 && d.kt == 64, "internal: the ping-pong kernel walks one N tile per workgroup");
-  if constexpr (BN == 256) {   // plain, unsplit GEMMs only (big_tile())
-    if (a.act == ACT_GEGLU) GILL_TRY((gemm_launch_stages<BN, 0, 1>(d, grid, stages, s)));
-    else if (a.out_mode == OUT_QKV) GILL_TRY((gemm_launch_stages<BN, 0, 3>(d, grid, stages, s)));
-    else GILL_TRY((gemm_launch_stages<BN, 0, 0>(d, grid, stages, s)));
-    return 0;
-  } else if (a.conv) {
+  if (BN == 160 && d.nwv == 8) GILL_REQUIRE(d.npw == 1, "internal: the ping-pong kernel walks one N tile per workgroup");
+  if (a.conv) {
     if (a.ups) {
-      if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 2, 2>(d, grid, stages, s)));
-      else GILL_TRY((gemm_launch_stages<BN, 2, 0>(d, grid, stages, s)));
+      if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 2, 2>(d, grid, s)));
+      else GILL_TRY((gemm_launch_stages<BN, 2, 0>(d, grid, s)));
     } else {
-      if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 1, 2>(d, grid, stages, s)));
-      else GILL_TRY((gemm_launch_stages<BN, 1, 0>(d, grid, stages, s)));
+      if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 1, 2>(d, grid, s)));
+      else GILL_TRY((gemm_launch_stages<BN, 1, 0>(d, grid, s)));
     }
   } else {
-    if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 0, 2>(d, grid, stages, s)));
-    else if (a.act == ACT_GEGLU) GILL_TRY((gemm_launch_stages<BN, 0, 1>(d, grid, stages, s)));
-    else if (a.out_mode == OUT_QKV) GILL_TRY((gemm_launch_stages<BN, 0, 3>(d, grid, stages, s)));
-    else GILL_TRY((gemm_launch_stages<BN, 0, 0>(d, grid, stages, s)));
+    if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 0, 2>(d, grid, s)));
+    else if (a.act == ACT_GEGLU) {
+      if constexpr (BN == 128) GILL_TRY((gemm_launch_stages<BN, 0, 1>(d, grid, s)));
+      else GILL_REQUIRE(BN == 128, "internal: GEGLU runs on 128-wide tiles");
+    }
+    else if (a.out_mode == OUT_QKV) GILL_TRY((gemm_launch_stages<BN, 0, 3>(d, grid, s)));
+    else GILL_TRY((gemm_launch_stages<BN, 0, 0>(d, grid, s)));
   }
   if (sk > 1) return gemm_splitk_reduce_launch(d.a, s);
   return 0;
@@ -1118,6 +1164,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
 int gemm_launch(const GemmArgs& a, hipStream_t s) {
   GILL_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "empty GEMM");
   GILL_REQUIRE((int64_t)a.M * (a.lda > a.N ? a.lda : a.N) < (int64_t)1 << 31, "GEMM operand too large for 32-bit offsets");
+  GILL_REQUIRE((int64_t)a.M * (a.ldc > a.ldr ? a.ldc : a.ldr) < (int64_t)1 << 31, "GEMM output / residual too large for 32-bit offsets");
   GILL_REQUIRE(a.K % BK == 0, "K must be a multiple of 64");
   GILL_REQUIRE(a.N % 4 == 0, "N must be a multiple of 4");
   GILL_REQUIRE(a.A != nullptr && a.W != nullptr, "null operand");
@@ -1159,12 +1206,10 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   }
   if (a.act == ACT_GEGLU) {
     GILL_REQUIRE(a.N % 128 == 0 && a.out_mode == OUT_BF16, "GEGLU needs N % 128 == 0 and bf16 row-major output");
-    if (tile_width(a) == 256) return gemm_launch_bn<256>(a, s);
     return gemm_launch_bn<128>(a, s);
   }
-  if (a.out_mode == OUT_QKV) GILL_REQUIRE(a.dp % 4 == 0 && a.heads > 0 && a.ntok > 0, "bad QKV scatter geometry");
+  if (a.out_mode == OUT_QKV) GILL_REQUIRE(a.dp % 8 == 0 && a.heads > 0 && a.ntok > 0, "bad QKV scatter geometry (padded head dim must be a multiple of 8)");
   const int bn = tile_width(a);
-  if (bn == 256) return gemm_launch_bn<256>(a, s);
   if (bn == 160) return gemm_launch_bn<160>(a, s);
   return gemm_launch_bn<128>(a, s);
 }

@@ -60,8 +60,6 @@ struct GemmArgs {
   //            ln_rows (0 = M): rows per plane; rows m >= ln_rows read the sums of row m - ln_rows (a batch whose second half
   //            repeats the first: the shared classifier-free-guidance prefix).
   const float* ln_stats = nullptr; int ln_planes = 1; int ln_rows = 0; const float* ln_colsum = nullptr; float ln_eps = 1e-5f;
-  // tuning: LDS ring depth (2|3, 0 = default 2) and tile width (128|160, 0 = by divisibility)
-  int stages = 0; int bn = 0;
 };
 int gemm_launch(const GemmArgs& a, hipStream_t s);
 #define GN_SLAB_ROWS 64        // rows per fused GroupNorm-statistics partial of the in-kernel epilogue
@@ -112,6 +110,26 @@ struct AttnArgs {
   int xcd_map = 1;          // 1: all query tiles of a (sample, head) on one XCD (set by the launcher; GILL_ATT_XCD=0 turns it off)
 };
 int attention_launch(const AttnArgs& a, hipStream_t s);
+
+// The cross-attention sub-block of a UNet transformer block as one kernel (xattn.hip):
+//   out = t' + softmax(LN2(t') Wq^T . K^T) V . Wo2^T + bo2,   t' = t + o1 . Wo1^T + bo1
+// o1 [src_rows][heads*dp] (self-attention output, token-major, padded heads), t [src_rows][C], out [M][C] (must not alias t when
+// src_rows < M); rows m >= src_rows read o1 / t at m - src_rows (the shared prefix of a classifier-free-guidance pair).
+// Kc [B][heads][ctx_pad][dp], Vt [B][heads][roundup(dp,32)][ctx_pad]: the prompt's cached keys / values (GemmArgs OUT_QKV layout).
+// Wq is the LayerNorm-folded projection (ln_fold_rows_launch: q_colsum, q_bias); qscale = log2(e) / sqrt(d).
+// row_stats (optional): [4][M][2] row sums of the bf16-rounded output (planes of a following folded LayerNorm, ln_planes = 4).
+struct XattnArgs {
+  int M = 0, HW = 0, C = 0, heads = 0, dp = 0, src_rows = 0;
+  const bf16_t* o1 = nullptr; const bf16_t* t = nullptr; bf16_t* out = nullptr;
+  const bf16_t* Wo1 = nullptr; const float* bo1 = nullptr;
+  const bf16_t* Wq = nullptr; const float* q_colsum = nullptr; const float* q_bias = nullptr;
+  const bf16_t* Kc = nullptr; const bf16_t* Vt = nullptr; int ctx_len = 0, ctx_pad = 0;
+  const bf16_t* Wo2 = nullptr; const float* bo2 = nullptr;
+  float* row_stats = nullptr;
+  float qscale = 1.f, ln_eps = 1e-5f;
+};
+bool xattn_block_supported(int C, int heads, int dp, int HW, int ctx_pad);
+int xattn_block_launch(const XattnArgs& a, hipStream_t s);
 
 // LayerNorm over the last dim (eps inside sqrt), fp32 or bf16 rows in, bf16 rows out.
 int layernorm_launch(const void* x, int x_f32, const float* gamma, const float* beta, bf16_t* y,

@@ -714,6 +714,30 @@ struct UNetRun {
     Bx = Bpre;
     GILL_TRY(attend(q, k, vt, o, HW, HW, hw_pad, hw_pad, w));
     Bx = Bfull;
+    // --- attn1.to_out + residual, norm2, attn2 (77 cached prompt keys), attn2.to_out + residual: ONE kernel where the geometry has one
+    // (levels 0 / 1: xattn.hip); GILL_UNET_XATTN = 0 keeps the four launches of the reference graph (A/B switch, tests)
+    static const bool xattn_on = [] { const char* e = getenv("GILL_UNET_XATTN"); return !(e && e[0] == '0'); }();
+    const bf16_t* tres = t.p;         // the residual stream after the two attention sub-blocks
+    if (xattn_on && xattn_block_supported(C, nh, w.dp, HW, m->ctx_pad)) {
+      Tensor t2 = talloc(H, Wd, C);
+      if (!dry) {
+        XattnArgs xa;
+        xa.M = M; xa.HW = HW; xa.C = C; xa.heads = nh; xa.dp = w.dp; xa.src_rows = M1;
+        xa.o1 = o; xa.t = t.p; xa.out = t2.p;
+        xa.Wo1 = w.out1.w; xa.bo1 = w.out1.b;
+        xa.Wq = w.wq2; xa.q_colsum = w.s_q2; xa.q_bias = w.c_q2;
+        xa.Kc = m->kcache[w.layer_id]; xa.Vt = m->vcache[w.layer_id]; xa.ctx_len = m->cfg.ctx_len; xa.ctx_pad = m->ctx_pad;
+        xa.Wo2 = w.out2.w; xa.bo2 = w.out2.b;
+        xa.row_stats = st3.p; st3.planes = 4;
+        xa.qscale = 1.4426950408889634f / sqrtf((float)w.d);
+        GILL_TRY(xattn_block_launch(xa, s));
+        if (shared) {     // the block input at full batch (outer residual of the last GEMM)
+          GILL_TRY(copy_bytes_launch(xd.p, x.p, sizeof(bf16_t) * (size_t)M1 * C, s));
+          GILL_TRY(copy_bytes_launch(xd.p + (size_t)M1 * C, x.p, sizeof(bf16_t) * (size_t)M1 * C, s));
+        }
+      }
+      tres = t2.p;
+    } else {
     GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M1, w.out1.w, w.out1.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, &st2));
     if (shared && !dry) {
       // second half of the pair := first half (residual stream, its LayerNorm row sums, the block input)
@@ -734,11 +758,12 @@ struct UNetRun {
     }
     GILL_TRY(attend(q, m->kcache[w.layer_id], m->vcache[w.layer_id], o, HW, m->cfg.ctx_len, hw_pad, m->ctx_pad, w));
     GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M, w.out2.w, w.out2.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, &st3));
+    }
     // --- GEGLU feed-forward
     bf16_t* ffh = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)M * 4 * C);
     {
       GemmArgs g;
-      g.M = M; g.N = 8 * C; g.K = C; g.K1 = C; g.A = t.p; g.lda = C; g.W = w.wff1; g.bias = w.bff1;
+      g.M = M; g.N = 8 * C; g.K = C; g.K1 = C; g.A = tres; g.lda = C; g.W = w.wff1; g.bias = w.bff1;
       g.ln_stats = st3.p; g.ln_planes = st3.planes; g.ln_colsum = w.s_ff1;
       g.act = ACT_GEGLU; g.C = ffh; g.ldc = 4 * C;
       GILL_TRY(gemm(g));
@@ -746,10 +771,10 @@ struct UNetRun {
     // --- feed-forward output, its residual, proj_out and the outer residual: one GEMM over K = [h | t] (see ffo_fuse_kernel)
     static const bool unfused = getenv("GILL_UNET_FFO_UNFUSED") != nullptr;     // A/B switch: the two GEMMs of the reference graph
     if (unfused) {
-      GILL_TRY(linear(ffh, 4 * C, nullptr, 0, 4 * C, M, w.ff2.w, w.ff2.b, C, 4 * C, t.p, ACT_NONE, t.p, C));
+      GILL_TRY(linear(ffh, 4 * C, nullptr, 0, 4 * C, M, w.ff2.w, w.ff2.b, C, 4 * C, tres, ACT_NONE, t.p, C));
       GILL_TRY(linear(t.p, C, nullptr, 0, C, M, w.proj_out.w, w.proj_out.b, C, C, xd.p, ACT_NONE, out->p, C, out));
     } else {
-      GILL_TRY(linear(ffh, 4 * C, t.p, C, 4 * C, M, w.wfo, w.bfo, C, 5 * C, xd.p, ACT_NONE, out->p, C, out));
+      GILL_TRY(linear(ffh, 4 * C, tres, C, 4 * C, M, w.wfo, w.bfo, C, 5 * C, xd.p, ACT_NONE, out->p, C, out));
     }
     m->arena.release(mk);
     return 0;

@@ -55,13 +55,18 @@ def test_c3_per_gpu_share_batch16_vs_oracle(cuda, sd15_pipe16):
   ref = pipeline_ref.denoise(sd, cond, uncond, lat0[pick], 2, 7.5)
   _, rel, cos = _stats("C3 share: 8 prompts (UNet batch 16), 2 steps, prompts 0 and 7", lat8[pick], ref)
   assert rel < 5e-2 and cos > 0.998
-  # 16 prompts: two gen_max_bs = 8 chunks (gill/models.py:724-731).  The second chunk is the same launch sequence on the same
-  # batch size as a call with prompts 8..15 alone, so it must match that call bit for bit; the first chunk matches the run above.
-  lat16 = g.generate_images(ids, num_inference_steps=2, guidance_scale=7.5, latents=lat0.to(cuda), distributed=False)
+  # 16 prompts: two gen_max_bs = 8 chunks (gill/models.py:724-731).  Stages 1-2 run once at batch 16 (their embeddings differ in
+  # the last bf16 bit from a batch-8 pass: split-K factors depend on M), then each chunk is one gill_sd_denoise call at UNet batch
+  # 16 — the same launch sequence as a direct pipeline call on that chunk's embeddings, so the latents must match bit for bit.
+  lat16, emb16 = g.generate_images(ids, num_inference_steps=2, guidance_scale=7.5, latents=lat0.to(cuda), return_embeddings=True,
+                                   distributed=False)
   assert lat16.shape == (16, 4, 64, 64) and bool(torch.isfinite(lat16).all())
-  assert torch.equal(lat16[:8], lat8), "chunk 0 of the 16-prompt call differs from the 8-prompt call"
-  solo = g.generate_images(ids[8:], num_inference_steps=2, guidance_scale=7.5, latents=lat0[8:].to(cuda), distributed=False)
-  assert torch.equal(lat16[8:], solo), "chunk 1 of the 16-prompt call differs from the same prompts alone"
+  for c in (0, 1):
+    sl = slice(8 * c, 8 * c + 8)
+    direct = pipe(prompt_embeds=emb16[sl], latents=lat0[sl], guidance_scale=7.5, num_inference_steps=2, output_type="latent").images
+    assert torch.equal(lat16[sl], direct), f"chunk {c} of the 16-prompt call differs from a direct call on its embeddings"
+  _, rel8, _ = _stats("16-prompt call, chunk 0 vs the 8-prompt call (stage 1-2 batch 16 vs 8)", lat16[:8], lat8)
+  assert rel8 < 5e-2
 
 
 @SLOW
@@ -202,3 +207,35 @@ def test_bench_eight_ranks_uneven_shards_gloo(cuda):
   rec = _run_bench(["--gpus", "8", "--backend", "gloo", "--share-gpu", "--small", "--total-prompts", "5", "--infer-steps", "2",
                     "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-pmc"])
   assert rec["n_gpus"] == 8 and rec["config"]["global_batch"] == 5 and rec["value"] > 0
+
+
+def test_fused_cross_attention_block_matches_the_four_launch_graph(cuda, tmp_path):
+  """csrc/xattn.hip (attn1.to_out + residual, norm2, attn2 over the prompt's 77 keys, attn2.to_out + residual as ONE kernel at UNet
+  levels 0 / 1) against the four launches it replaces (GILL_UNET_XATTN = 0; the switch is read once per process): full-size SD-1.5,
+  one forward of batch 3 (odd: no shared prefix) and a 2-step CFG loop of 2 prompts (shared-prefix path: rows of the second half
+  read the first half's self-attention output).  Same arithmetic up to rounding order: the bar is an order of magnitude below the
+  distance of either to the fp32 oracle (1.1e-2)."""
+  outs = {}
+  for on in ("1", "0"):
+    out = str(tmp_path / f"xattn{on}.pt")
+    code = ("import torch, os\n"
+            "from gill_amd import synth\n"
+            "from gill_amd.sd import GillSDPipeline\n"
+            "cfg = synth.UNetConfig.sd15()\n"
+            "sd = {k: v.bfloat16().float() for k, v in synth.unet_state_dict(cfg, seed=91).items()}\n"
+            "uncond = synth.uncond_context(cfg.ctx_len, cfg.cross_attention_dim, seed=91).bfloat16().float()\n"
+            "pipe = GillSDPipeline(sd, cfg, uncond, 'cuda:0', max_batch=4)\n"
+            "x = synth.initial_latents(3, 4, 64, seed=9191)\n"
+            "ctx = synth.normal('xa_ctx', (3, 77, 768), 92).bfloat16().float()\n"
+            "eps = pipe.unet(x, torch.tensor([901.0, 501.0, 101.0]), ctx).float().cpu()\n"
+            "lat = pipe(prompt_embeds=ctx[:2], latents=x[:2], guidance_scale=7.5, num_inference_steps=2, output_type='latent').images.float().cpu()\n"
+            "torch.save({'eps': eps, 'lat': lat}, os.environ['GILL_TEST_OUT'])\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GILL_UNET_XATTN=on, GILL_TEST_OUT=out, PYTHONPATH=ROOT),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    outs[on] = torch.load(out)
+  for key, bar in (("eps", 3e-3), ("lat", 3e-2)):     # (3 recurrent calls at guidance 7.5 amplify rounding-order noise: tools/chaos_probe.py)
+    a, b = outs["1"][key], outs["0"][key]
+    assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
+    _, rel, cos = _stats(f"fused cross-attention block vs four launches: {key}", a, b)
+    assert rel < bar and cos > 0.999, f"{key}: rel-L2 {rel:.3e}"
