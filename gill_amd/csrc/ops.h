@@ -127,6 +127,7 @@ struct XattnArgs {
   const bf16_t* Wo2 = nullptr; const float* bo2 = nullptr;
   float* row_stats = nullptr;
   float qscale = 1.f, ln_eps = 1e-5f;
+  int debug_stop = 0;   // tools only: 1 / 2 / 3 = return after the first GEMM / the q projection / the attention phase
 };
 bool xattn_block_supported(int C, int heads, int dp, int HW, int ctx_pad);
 int xattn_block_launch(const XattnArgs& a, hipStream_t s);

@@ -500,6 +500,14 @@ struct UNetRun {
   // so everything before the first cross-attention runs once on the first half (gill_sd_denoise sets this)
   bool cfg_pair = false;
 
+  // GILL_DEBUG_SYNC=1 (tools): synchronise after every launch of the forward and say which one it was, to attribute a device fault
+  int dbg_sync(const char* what, int a = 0, int b = 0, int c = 0) {
+    static const bool on = getenv("GILL_DEBUG_SYNC") != nullptr;
+    if (!on || dry) return 0;
+    GILL_CHECK_HIP(hipStreamSynchronize(s));
+    fprintf(stderr, "[unet] ok: %s %d %d %d\n", what, a, b, c);
+    return 0;
+  }
   float* stats_slot(size_t floats) {   // next slot of the per-forward GroupNorm partial-sum pool (the dry run sizes it)
     float* p = dry ? (float*)(uintptr_t)16 : m->gn_stats + m->gn_next;
     m->gn_next += (floats + 3) & ~(size_t)3;
@@ -544,7 +552,8 @@ struct UNetRun {
     pick_sk(g);
     if (rs) { g.row_stats = rs->p; rs->planes = gemm_row_planes(g); }
     if (ys && ys->stats) ys->nslab = ys->H * ys->W / gemm_gn_slab_rows(g);
-    return gemm_launch(g, s);
+    GILL_TRY(gemm_launch(g, s));
+    return dbg_sync(g.conv ? "conv" : (g.act == ACT_GEGLU ? "geglu" : (g.out_mode == OUT_QKV ? "qkv" : "gemm")), g.M, g.N, g.K);
   }
   // y8_scale > 0: y holds fp8(y8_scale * value) instead of bf16 (same shape; the A operand of conv8())
   int gnorm(const Tensor& x1, const Tensor* x2, const NormW& n, float eps, int silu, const Tensor& y, float y8_scale = 0.f) {
@@ -559,6 +568,7 @@ struct UNetRun {
     float* tot = ready ? stats_slot(groupnorm_totals_floats(Bx, x1.C / x1.sbin, x2 ? x2->C / x2->sbin : 0)) : nullptr;
     if (dry) return 0;
     GILL_REQUIRE(m->gn_next <= m->gn_floats, "internal: GroupNorm stats pool exhausted");
+    GILL_TRY(dbg_sync("before groupnorm", x1.C, x2 ? x2->C : 0, HW));
     if (ready)
       return groupnorm_apply_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, HW, m->cfg.norm_num_groups,
                                     n.g, n.b, eps, silu, y.p, x1.stats, x1.sbin, x1.C, x1.nslab,
@@ -714,9 +724,11 @@ struct UNetRun {
     Bx = Bpre;
     GILL_TRY(attend(q, k, vt, o, HW, HW, hw_pad, hw_pad, w));
     Bx = Bfull;
-    // --- attn1.to_out + residual, norm2, attn2 (77 cached prompt keys), attn2.to_out + residual: ONE kernel where the geometry has one
-    // (levels 0 / 1: xattn.hip); GILL_UNET_XATTN = 0 keeps the four launches of the reference graph (A/B switch, tests)
-    static const bool xattn_on = [] { const char* e = getenv("GILL_UNET_XATTN"); return !(e && e[0] == '0'); }();
+    // --- attn1.to_out + residual, norm2, attn2 (77 cached prompt keys), attn2.to_out + residual as ONE kernel (xattn.hip) where the
+    // geometry has one (levels 0 / 1).  OFF by default: measured slower than the four launches it replaces (loop 545.5 -> 549.5 ms;
+    // level 0: 91 us vs 95 us, level 1: 96 us vs 79 us — every phase streams the weights from L2 at ~25-35 GB/s per CU with the
+    // 50-70 KB of LDS-DMA it can keep in flight next to its row tile: profiles/r03_xattn_fused.md).  GILL_UNET_XATTN = 1 turns it on.
+    static const bool xattn_on = [] { const char* e = getenv("GILL_UNET_XATTN"); return e && e[0] == '1'; }();
     const bf16_t* tres = t.p;         // the residual stream after the two attention sub-blocks
     if (xattn_on && xattn_block_supported(C, nh, w.dp, HW, m->ctx_pad)) {
       Tensor t2 = talloc(H, Wd, C);
@@ -730,7 +742,10 @@ struct UNetRun {
         xa.Wo2 = w.out2.w; xa.bo2 = w.out2.b;
         xa.row_stats = st3.p; st3.planes = 4;
         xa.qscale = 1.4426950408889634f / sqrtf((float)w.d);
+        static const bool dbg = getenv("GILL_DEBUG_SYNC") != nullptr;     // tools: fence the launch to attribute a device fault
+        if (dbg) { GILL_CHECK_HIP(hipStreamSynchronize(s)); fprintf(stderr, "[xattn] before: C %d M %d M1 %d HW %d layer %d\n", C, M, M1, HW, w.layer_id); }
         GILL_TRY(xattn_block_launch(xa, s));
+        if (dbg) { GILL_CHECK_HIP(hipStreamSynchronize(s)); fprintf(stderr, "[xattn] after\n"); }
         if (shared) {     // the block input at full batch (outer residual of the last GEMM)
           GILL_TRY(copy_bytes_launch(xd.p, x.p, sizeof(bf16_t) * (size_t)M1 * C, s));
           GILL_TRY(copy_bytes_launch(xd.p + (size_t)M1 * C, x.p, sizeof(bf16_t) * (size_t)M1 * C, s));
@@ -841,7 +856,11 @@ struct UNetRun {
     }
     Tensor n = talloc(L, L, ch[0]);
     GILL_TRY(gnorm(x, nullptr, m->norm_out, 1e-5f, 1, n));
+    GILL_TRY(dbg_sync("last groupnorm"));
     if (!dry) GILL_TRY(conv_out_launch(n.p, m->conv_out_w, m->conv_out_b, Bx, ch[0], L, L, c.out_channels, eps_out, s));
+    GILL_TRY(dbg_sync("conv_out"));
+    // (a real run must never need more than the dry run of unet_plan_and_alloc() counted)
+    GILL_REQUIRE(dry || m->arena.high <= m->arena.cap, "internal: activation arena overflow (the dry run and the real run allocate differently)");
     return 0;
   }
 };
@@ -853,6 +872,7 @@ static int unet_plan_and_alloc(gill_unet* m) {
   const int Bx = c.max_batch;
   const int L = c.sample_size;
   const size_t n_lat = (size_t)c.in_channels * L * L;
+  m->ctx_pad = round_up(c.ctx_len, 32);     // (before the dry run: which blocks take the fused cross-attention kernel depends on it)
   // dry run to size the activation arena
   m->arena.dry = true; m->arena.off = 0; m->arena.high = 0;
   m->kcache.assign(m->n_xf, nullptr); m->vcache.assign(m->n_xf, nullptr);
@@ -875,7 +895,6 @@ static int unet_plan_and_alloc(gill_unet* m) {
   m->splitk_ws_floats = (size_t)48 << 20;   // 192 MiB of fp32 partials
   GILL_TRY(m->pool.alloc(&m->splitk_ws, m->splitk_ws_floats, false));
   // cross-attention K/V caches
-  m->ctx_pad = round_up(c.ctx_len, 32);
   auto alloc_cache = [&](const XfW& w) -> int {
     GILL_TRY(m->pool.alloc(&m->kcache[w.layer_id], (size_t)Bx * w.heads * m->ctx_pad * w.dp, true));
     GILL_TRY(m->pool.alloc(&m->vcache[w.layer_id], (size_t)Bx * w.heads * w.dpv * m->ctx_pad, true));
@@ -1132,5 +1151,52 @@ static int sd_denoise_on(gill_unet* m, const void* cond_bf16, const void* uncond
     }
   }
   GILL_CHECK_HIP(hipMemcpyAsync(latents_out, m->lat, sizeof(float) * n_lat * B, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Operator-level entry for the fused cross-attention sub-block (xattn.hip) on NATURAL operands (unpadded heads, plain LayerNorm
+// parameters, projected prompt keys / values): pads / folds them exactly as the engine's loader does, then launches the kernel.
+// For tests/test_ops_gpu.py and tools; synchronises.
+extern "C" int gill_op_xattn_block(const void* o1, const void* t, const void* Wo1, const float* bo1, const float* ln_g, const float* ln_b,
+                                   const void* Wq, const void* k, const void* v, const void* Wo2, const float* bo2, void* out,
+                                   float* row_stats, int B, int HW, int C, int heads, int ctx_len, int src_rows, int debug_stop,
+                                   void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GILL_REQUIRE(o1 && t && Wo1 && bo1 && ln_g && ln_b && Wq && k && v && Wo2 && bo2 && out, "null argument");
+  GILL_REQUIRE(heads > 0 && C % heads == 0, "heads must divide C");
+  const int d = C / heads, dp = attn_padded_dim(d), dpv = round_up(dp, 32), hdp = heads * dp, M = B * HW;
+  const int ctx_pad = round_up(ctx_len, 32);
+  GILL_REQUIRE(xattn_block_supported(C, heads, dp, HW, ctx_pad), "xattn_block: unsupported geometry");
+  DevBuf o1p, wo1p, wo2p, wqp, cs, cb, kc, vt;
+  GILL_TRY(o1p.alloc_zero(sizeof(bf16_t) * (size_t)src_rows * hdp, s));
+  GILL_TRY(wo1p.alloc_zero(sizeof(bf16_t) * (size_t)C * hdp, s));
+  GILL_TRY(wo2p.alloc_zero(sizeof(bf16_t) * (size_t)C * hdp, s));
+  GILL_TRY(wqp.alloc_zero(sizeof(bf16_t) * (size_t)hdp * C, s));
+  GILL_TRY(cs.alloc_zero(sizeof(float) * (size_t)hdp, s));
+  GILL_TRY(cb.alloc_zero(sizeof(float) * (size_t)hdp, s));
+  GILL_TRY(kc.alloc_zero(sizeof(bf16_t) * (size_t)B * heads * ctx_pad * dp, s));
+  GILL_TRY(vt.alloc_zero(sizeof(bf16_t) * (size_t)B * heads * dpv * ctx_pad, s));
+  hipLaunchKernelGGL(pad_head_cols_kernel, dim3(1024), dim3(256), 0, s, o1, 0, src_rows, heads, d, dp, (bf16_t*)o1p.p);
+  hipLaunchKernelGGL(pad_head_cols_kernel, dim3(1024), dim3(256), 0, s, Wo1, 0, C, heads, d, dp, (bf16_t*)wo1p.p);
+  hipLaunchKernelGGL(pad_head_cols_kernel, dim3(1024), dim3(256), 0, s, Wo2, 0, C, heads, d, dp, (bf16_t*)wo2p.p);
+  hipLaunchKernelGGL(pad_head_rows_kernel, dim3(1024), dim3(256), 0, s, Wq, 0, heads, d, dp, C, (bf16_t*)wqp.p);
+  GILL_CHECK_HIP(hipGetLastError());
+  GILL_TRY(ln_fold_rows_launch((bf16_t*)wqp.p, hdp, C, ln_g, ln_b, (float*)cs.p, (float*)cb.p, s));
+  GILL_TRY(pack_heads_launch((const bf16_t*)k, B, ctx_len, heads, d, ctx_pad, dp, dpv, 0, (bf16_t*)kc.p, s));
+  GILL_TRY(pack_heads_launch((const bf16_t*)v, B, ctx_len, heads, d, ctx_pad, dp, dpv, 1, (bf16_t*)vt.p, s));
+  XattnArgs xa;
+  xa.M = M; xa.HW = HW; xa.C = C; xa.heads = heads; xa.dp = dp; xa.src_rows = src_rows;
+  xa.o1 = (const bf16_t*)o1p.p; xa.t = (const bf16_t*)t; xa.out = (bf16_t*)out;
+  xa.Wo1 = (const bf16_t*)wo1p.p; xa.bo1 = bo1;
+  xa.Wq = (const bf16_t*)wqp.p; xa.q_colsum = (const float*)cs.p; xa.q_bias = (const float*)cb.p;
+  xa.Kc = (const bf16_t*)kc.p; xa.Vt = (const bf16_t*)vt.p; xa.ctx_len = ctx_len; xa.ctx_pad = ctx_pad;
+  xa.Wo2 = (const bf16_t*)wo2p.p; xa.bo2 = bo2;
+  xa.row_stats = row_stats;
+  xa.qscale = 1.4426950408889634f / sqrtf((float)d);
+  xa.debug_stop = debug_stop;
+  const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int r = e ? atoi(e) : 1; return r > 0 ? r : 1; }();
+  for (int r = 0; r < rep; ++r) GILL_TRY(xattn_block_launch(xa, s));
+  GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
 }

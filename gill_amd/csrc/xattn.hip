@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XattnArgs p) 
 
   // in-flight bookkeeping: pc[j] = pieces this wave issued for stage (cur + 1 + j), j < STAGES - 2 ... kept as named scalars
   int gcur = 0;                 // stage being consumed
-  int pend1 = 0, pend2 = 0, pend3 = 0;   // pieces of stages gcur+1, gcur+2, gcur+3 (issued, possibly in flight)
+  int pend1 = 0, pend2 = 0;   // pieces of stages gcur+1, gcur+2 (issued, possibly in flight)
   {
     int c0 = issue(0);
     (void)c0;
@@ -152,6 +152,7 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XattnArgs p) 
   auto consume_begin = [&]() -> const unsigned char* {
     const int allowed = (STAGES >= 4) ? pend1 + pend2 : pend1;     // stages gcur+1 .. gcur+STAGES-2 may stay in flight
     wait_vm_n(allowed);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes (epilogue tiles, statistics) are done before the barrier
     __builtin_amdgcn_s_barrier();
     return ring + (gcur % STAGES) * Cfg::STAGE_BYTES;
   };
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XattnArgs p) 
     rs[i] += __shfl_xor(rs[i], 32, 64); rq[i] += __shfl_xor(rq[i], 32, 64);
     if (fkc == 0) stats[(arow0 + i * 16) * 4 + wn] = make_float2(rs[i], rq[i]);
   }
+  if (p.debug_stop == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
   // (the barrier of GEMM 2's first stage orders these LDS writes — t' tile and statistics — before every wave's reads)
 
   // ---------------------------------------------------------------- GEMM 2: q = LN(t') Wq^T (folded LayerNorm), x qscale
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XattnArgs p) 
     }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (p.debug_stop == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
 
   // ---------------------------------------------------------------- attention over the prompt's keys: one wave per head
   {
@@ -408,6 +411,7 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XattnArgs p) 
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (p.debug_stop == 3) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
   // (GEMM 3's first stage barrier orders the o2 tile writes before the fragment reads)
 
   // ---------------------------------------------------------------- GEMM 3: t'' = t' + o2 Wo2^T + bo2 (+ LayerNorm row sums of t'')

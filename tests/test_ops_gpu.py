@@ -226,3 +226,67 @@ def test_groupnorm(cuda, B, H, W, C1, C2, silu):
   ref = ref.permute(0, 2, 3, 1)
   out = ops.groupnorm(x1.to(cuda), g.to(cuda), b.to(cuda), 32, 1e-5, silu, None if x2 is None else x2.to(cuda))
   assert _report(f"groupnorm B{B} {H}x{W} {C1}+{C2}", out, ref) < 1.5e-2
+
+
+from gill_amd import synth   # noqa: E402
+
+
+def _xattn_reference(o1, t, wo1, bo1, g, b, wq, k, v, wo2, bo2, heads, B):
+  """fp32 torch restatement of the sub-block (oracle/unet_ref.py:_transformer, attn1 output projection .. attn2 residual), with the
+  residual stream rounded to bf16 where the kernel rounds it."""
+  M, C = o1.shape[0], t.shape[1]
+  d = C // heads
+  t1 = (t + o1 @ wo1.T + bo1).bfloat16().float()
+  ln = torch.nn.functional.layer_norm(t1, (C,), g, b, 1e-5)
+  q = (ln @ wq.T).view(B, M // B, heads, d).transpose(1, 2)
+  kk = k.view(B, -1, heads, d).transpose(1, 2)
+  vv = v.view(B, -1, heads, d).transpose(1, 2)
+  a = torch.softmax(q @ kk.transpose(-1, -2) / d ** 0.5, dim=-1) @ vv
+  o2 = a.transpose(1, 2).reshape(M, C)
+  return t1 + o2 @ wo2.T + bo2
+
+
+@pytest.mark.parametrize("C,heads,HW,B", [(320, 8, 128, 3), (640, 8, 64, 2), (320, 5, 64, 2), (640, 10, 96, 2)])
+def test_xattn_block_vs_torch(cuda, C, heads, HW, B):
+  """csrc/xattn.hip at the four supported geometries (SD-1.x levels 0 / 1: 8 heads of 40 / 80; SD-2.x: 5 / 10 heads of 64) against the
+  fp32 restatement; the row sums it leaves for the next folded LayerNorm against sums of its own bf16 output."""
+  from gill_amd import ops
+  M = B * HW
+  r = lambda name, shape, std=1.0: synth.normal(name, shape, 7, std).bfloat16().float()   # noqa: E731
+  o1, t = r("xa_o1", (M, C)), r("xa_t", (M, C))
+  wo1, wq, wo2 = r("xa_wo1", (C, C), C ** -0.5), r("xa_wq", (C, C), C ** -0.5), r("xa_wo2", (C, C), C ** -0.5)
+  bo1, bo2 = synth.normal("xa_bo1", (C,), 7, 0.1), synth.normal("xa_bo2", (C,), 7, 0.1)
+  g, b = 1.0 + synth.normal("xa_g", (C,), 7, 0.1), synth.normal("xa_b", (C,), 7, 0.1)
+  k, v = r("xa_k", (B, 77, C)), r("xa_v", (B, 77, C))
+  ref = _xattn_reference(o1, t, wo1, bo1, g, b, wq, k, v, wo2, bo2, heads, B)
+  dev = lambda x: x.to(cuda).bfloat16()   # noqa: E731
+  got, rs = ops.xattn_block(dev(o1), dev(t), dev(wo1), bo1.to(cuda), g.to(cuda), b.to(cuda), dev(wq), dev(k), dev(v), dev(wo2),
+                            bo2.to(cuda), heads, B, want_row_stats=True)
+  torch.cuda.synchronize()
+  gf = got.float().cpu()
+  rel = ((gf - ref).norm() / ref.norm()).item()
+  print(f"[xattn block C={C} heads={heads} HW={HW} B={B}] rel-L2 {rel:.3e}, max abs {(gf - ref).abs().max().item():.3e}")
+  assert rel < 1e-2
+  sums = rs.sum(0).cpu()
+  assert torch.allclose(sums[:, 0], gf.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(sums[:, 1], (gf * gf).sum(1), rtol=1e-4, atol=1e-2)
+
+
+def test_xattn_block_shared_prefix_rows(cuda):
+  """src_rows < M: rows of the second half of a classifier-free-guidance pair read the first half's o1 / t and their OWN sample's keys."""
+  from gill_amd import ops
+  C, heads, HW, B = 320, 8, 64, 4
+  M1 = (B // 2) * HW
+  r = lambda name, shape, std=1.0: synth.normal(name, shape, 9, std).bfloat16().float()   # noqa: E731
+  o1, t = r("xs_o1", (M1, C)), r("xs_t", (M1, C))
+  wo1, wq, wo2 = r("xs_wo1", (C, C), C ** -0.5), r("xs_wq", (C, C), C ** -0.5), r("xs_wo2", (C, C), C ** -0.5)
+  bo1, bo2 = synth.normal("xs_bo1", (C,), 9, 0.1), synth.normal("xs_bo2", (C,), 9, 0.1)
+  g, b = 1.0 + synth.normal("xs_g", (C,), 9, 0.1), synth.normal("xs_b", (C,), 9, 0.1)
+  k, v = r("xs_k", (B, 77, C)), r("xs_v", (B, 77, C))
+  ref = _xattn_reference(torch.cat([o1, o1]), torch.cat([t, t]), wo1, bo1, g, b, wq, k, v, wo2, bo2, heads, B)
+  dev = lambda x: x.to(cuda).bfloat16()   # noqa: E731
+  got = ops.xattn_block_shared(dev(o1), dev(t), dev(wo1), bo1.to(cuda), g.to(cuda), b.to(cuda), dev(wq), dev(k), dev(v), dev(wo2),
+                               bo2.to(cuda), heads, B)
+  torch.cuda.synchronize()
+  rel = ((got.float().cpu() - ref).norm() / ref.norm()).item()
+  print(f"[xattn block, shared prefix] rel-L2 {rel:.3e}")
+  assert rel < 1e-2
