@@ -100,6 +100,46 @@ extern "C" int gill_op_conv3x3(const void* x1, int C1, const void* x2, int C2, c
   return 0;
 }
 
+// ResnetBlock2D's conv2 with the 1x1 conv_shortcut of the raw block input fused as extra K channels (the engine's c2f weights):
+// y = conv3x3(x1 ++ x2) + bias + conv1x1(xs1 ++ xs2), one implicit GEMM with K = 9 (C1 + C2) + CS1 + CS2.  For the operator tests.
+extern "C" int gill_op_conv3x3_shortcut(const void* x1, int C1, const void* x2, int C2, const float* w_oihw, const float* bias,
+                                        const void* xs1, int CS1, const void* xs2, int CS2, const float* w_sc, void* y, int B, int IH,
+                                        int IW, int Cout, int splitk, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int Cin = C1 + C2, CS = CS1 + CS2, kf = 9 * Cin + CS;
+  GILL_REQUIRE(x1 && w_oihw && xs1 && w_sc && y && CS % 64 == 0 && CS1 % 64 == 0, "bad argument");
+  DevBuf wr, wsb, wf, idx, ws;
+  GILL_TRY(wr.alloc(sizeof(bf16_t) * (size_t)Cout * 9 * Cin));
+  GILL_TRY(wsb.alloc(sizeof(bf16_t) * (size_t)Cout * CS));
+  GILL_TRY(wf.alloc(sizeof(bf16_t) * (size_t)Cout * kf));
+  GILL_TRY(idx.alloc(sizeof(int32_t) * (size_t)Cout));
+  const int chunked = conv_k_chunked(IH * IW, Cin, Cout) ? 1 : 0;
+  if (chunked) GILL_TRY(conv_weight_relayout_chunked_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wr.p, s));
+  else GILL_TRY(conv_weight_relayout_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wr.p, s));
+  GILL_TRY(convert_to_bf16_launch(w_sc, GILL_DTYPE_F32, (int64_t)Cout * CS, (bf16_t*)wsb.p, s));
+  std::vector<int32_t> ident(Cout);
+  for (int i = 0; i < Cout; ++i) ident[i] = i;
+  GILL_CHECK_HIP(hipMemcpyAsync(idx.p, ident.data(), sizeof(int32_t) * Cout, hipMemcpyHostToDevice, s));
+  GILL_TRY(scatter_rows_bf16_launch((const bf16_t*)wr.p, Cout, 9 * Cin, (const int32_t*)idx.p, (bf16_t*)wf.p, kf, s));
+  GILL_TRY(scatter_rows_bf16_launch((const bf16_t*)wsb.p, Cout, CS, (const int32_t*)idx.p, (bf16_t*)wf.p + 9 * Cin, kf, s));
+  GemmArgs g;
+  g.conv = 1; g.IH = IH; g.IW = IW; g.OH = IH; g.OW = IW; g.Cin = Cin; g.stride = 1; g.ups = 0;
+  g.M = B * IH * IW; g.N = Cout; g.K = kf;
+  g.A = (const bf16_t*)x1; g.A2 = (const bf16_t*)x2; g.K1 = C1;
+  g.X1 = (const bf16_t*)xs1; g.X2 = (const bf16_t*)xs2; g.KX = CS; g.KX1 = CS1;
+  g.W = (const bf16_t*)wf.p; g.k_chunked = chunked; g.bias = bias;
+  g.rows_per_batch = IH * IW;
+  g.C = y; g.ldc = Cout;
+  g.splitk = splitk > 0 ? splitk : gemm_pick_splitk(g.M, g.N, g.K, 0);
+  if (g.splitk > 1) {
+    GILL_TRY(ws.alloc(sizeof(float) * (size_t)g.splitk * g.M * g.N));
+    g.ws = (float*)ws.p;
+  }
+  for (int r = 0; r < op_repeat(); ++r) GILL_TRY(gemm_launch(g, s));
+  GILL_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 extern "C" int gill_op_attention(const void* q, const void* k, const void* v, void* o, int B, int H, int nq, int nkv, int d,
                                  float scale, int causal, void* stream) {
   hipStream_t s = (hipStream_t)stream;

@@ -76,6 +76,28 @@ def conv3x3(x1: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor]
   return y
 
 
+def conv3x3_shortcut(x1: torch.Tensor, w_oihw: torch.Tensor, xs1: torch.Tensor, w_sc: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                     x2: Optional[torch.Tensor] = None, xs2: Optional[torch.Tensor] = None, splitk: int = 0) -> torch.Tensor:
+  """conv3x3(x1 ++ x2, w_oihw) + bias + conv1x1(xs1 ++ xs2, w_sc) as one implicit GEMM (ResnetBlock2D conv2 + conv_shortcut)."""
+  x1, xs1 = _bf(x1), _bf(xs1)
+  B, IH, IW, C1 = x1.shape
+  C2 = CS2 = 0
+  if x2 is not None:
+    x2 = _bf(x2); C2 = x2.shape[-1]
+  if xs2 is not None:
+    xs2 = _bf(xs2); CS2 = xs2.shape[-1]
+  CS1 = xs1.shape[-1]
+  w, wsc = w_oihw.float().contiguous(), w_sc.float().contiguous()
+  Cout = w.shape[0]
+  assert w.shape[1] == C1 + C2 and tuple(wsc.shape) == (Cout, CS1 + CS2)
+  y = torch.empty((B, IH, IW, Cout), device=x1.device, dtype=torch.bfloat16)
+  if bias is not None:
+    bias = bias.float().contiguous()
+  N.check(N.lib().gill_op_conv3x3_shortcut(N.ptr(x1), C1, N.ptr(x2), C2, N.ptr(w), N.ptr(bias), N.ptr(xs1), CS1, N.ptr(xs2), CS2,
+                                           N.ptr(wsc), N.ptr(y), B, IH, IW, Cout, splitk, N.current_stream()))
+  return y
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None,
               causal: bool = False) -> torch.Tensor:
   """q (B,nq,H*d), k/v (B,nkv,H*d) bf16 -> (B,nq,H*d) bf16."""

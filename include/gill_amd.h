@@ -221,6 +221,11 @@ int gill_op_conv3x3(const void* x1, int C1, const void* x2, int C2, const float*
                     const float* rowvec, const void* resid, void* y, int B, int IH, int IW, int Cout, int stride, int ups,
                     int splitk, void* stream);
 /* softmax(scale * q k^T [+causal]) v over token-major q (B,nq,H*d), k/v (B,nkv,H*d) -> o (B,nq,H*d) */
+/* conv3x3 (stride 1, pad 1) of x1 ++ x2 plus a fused 1x1 convolution of xs1 ++ xs2 (ResnetBlock2D.conv2 + conv_shortcut as one
+ * implicit GEMM): y (B,IH,IW,Cout) bf16 NHWC; w_oihw (Cout, C1+C2, 3, 3) fp32, w_sc (Cout, CS1+CS2) fp32.  Synchronises. */
+int gill_op_conv3x3_shortcut(const void* x1, int C1, const void* x2, int C2, const float* w_oihw, const float* bias,
+                             const void* xs1, int CS1, const void* xs2, int CS2, const float* w_sc, void* y, int B, int IH, int IW,
+                             int Cout, int splitk, void* stream);
 int gill_op_attention(const void* q, const void* k, const void* v, void* o, int B, int H, int nq, int nkv, int d,
                       float scale, int causal, void* stream);
 int gill_op_layernorm(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, int rows, int C,

@@ -105,6 +105,10 @@ def _conv_ref(x1, x2, w, bias, rowvec, resid, stride, ups):
   (2, 16, 16, 128, 64, 160, 1, 0),     # two-source concat
   (4, 32, 32, 128, 0, 160, 2, 0),      # stride 2
   (2, 8, 8, 128, 0, 320, 1, 1),        # fused nearest-2x upsample
+  # full-width maps on the ping-pong tiles
+  (8, 64, 64, 128, 0, 320, 1, 0),      # 256-row tiles, 64-wide rows
+  (16, 32, 32, 64, 64, 640, 1, 0),     # 256-row tiles, 32-wide rows, two sources
+  (2, 32, 32, 192, 0, 160, 1, 0),      # 128-row tiles, three chunks
 ])
 def test_conv3x3(cuda, B, H, W, C1, C2, Cout, stride, ups):
   from gill_amd import ops
@@ -120,6 +124,30 @@ def test_conv3x3(cuda, B, H, W, C1, C2, Cout, stride, ups):
                       rowvec=rowvec.to(cuda), resid=resid.to(cuda), stride=stride, upsample=bool(ups), splitk=sk)
     assert tuple(out.shape) == tuple(ref.shape)
     assert _report(f"conv B{B} {H}x{W} {C1}+{C2}->{Cout} s{stride} u{ups} sk{sk}", out, ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,CS1,CS2,Cout", [
+  (2, 32, 32, 128, 0, 192, 64, 160),     # 128-row ping-pong tiles; shortcut over two sources (an up block's conv2)
+  (8, 64, 64, 64, 0, 128, 0, 320),       # 256-row ping-pong tiles
+  (16, 32, 32, 128, 0, 64, 0, 640),
+  (2, 16, 16, 128, 0, 64, 0, 128),       # not a ping-pong shape: the 128-row kernel's shortcut segment
+])
+def test_conv3x3_fused_shortcut(cuda, B, H, W, C1, C2, CS1, CS2, Cout):
+  """ResnetBlock2D conv2 + conv_shortcut as one implicit GEMM (K = 9 Cin taps, then the raw input's channels at the centre pixel)."""
+  from gill_amd import ops
+  x1 = _bf(_rnd((B, H, W, C1), 40))
+  x2 = _bf(_rnd((B, H, W, C2), 41)) if C2 else None
+  xs1 = _bf(_rnd((B, H, W, CS1), 42))
+  xs2 = _bf(_rnd((B, H, W, CS2), 43)) if CS2 else None
+  w = _rnd((Cout, C1 + C2, 3, 3), 44, 0.05)
+  wsc = _rnd((Cout, CS1 + CS2), 45, 0.05)
+  bias = _rnd((Cout,), 46)
+  xs = xs1.float() if xs2 is None else torch.cat([xs1.float(), xs2.float()], -1)
+  ref = _conv_ref(x1, x2, w, bias, None, None, 1, 0) + xs @ wsc.bfloat16().float().T
+  for sk in (1, 2):
+    out = ops.conv3x3_shortcut(x1.to(cuda), w.to(cuda), xs1.to(cuda), wsc.to(cuda), bias.to(cuda), x2=None if x2 is None else x2.to(cuda),
+                               xs2=None if xs2 is None else xs2.to(cuda), splitk=sk)
+    assert _report(f"conv+shortcut B{B} {H}x{W} {C1}+{C2} (+{CS1}+{CS2}) -> {Cout} sk{sk}", out, ref) < 1.5e-2
 
 
 def test_conv3x3_pingpong_short_k_and_bit_identity(cuda):
