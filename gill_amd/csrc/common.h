@@ -37,6 +37,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Sum over the 16 lanes of a DPP row (lanes 16k .. 16k + 15), result in every lane, on the VALU (v_add_f32 with a DPP operand: quad
+// permutes, then the row's half-mirror and mirror) instead of four ds_bpermute round trips through the LDS crossbar.  Fixed order.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_mov(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_row_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_row_mov<0x4E>(v);    // quad_perm [2,3,0,1]: every lane of a quad holds the quad's sum
+  v += dpp_row_mov<0x141>(v);   // row_half_mirror: lane i <-> 7 - i inside each 8 lanes
+  v += dpp_row_mov<0x140>(v);   // row_mirror: lane i <-> 15 - i
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -205,9 +205,7 @@ __global__ __launch_bounds__(F8_THREADS, 2) void conv3x3_fp8_kernel(const ConvF8
       if (p.gn_stats) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float a = gs[e], q = gq[e];
-#pragma unroll
-          for (int off = 1; off < 16; off <<= 1) { a += __shfl_xor(a, off, 64); q += __shfl_xor(q, off, 64); }
+          const float a = row16_sum(gs[e]), q = row16_sum(gq[e]);     // over the 16 row lanes (DPP)
           if (frow == 0) {
             const int c = wn * (BN / 2) + j * 16 + fkb * 4 + e;
             red[wm * BN + c] = a;

@@ -750,7 +750,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
           }
         }
         if (p.resid) {
-          if (p.resid_f32) {
+          if (CONV == 0 && p.resid_f32) {
             const float4 r0 = *reinterpret_cast<const float4*>((const float*)p.resid + rrow[i] + n);
             v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
             if (hi) {
@@ -769,18 +769,19 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
             v[2] += bf2f((bf16_t)(r.y & 0xffff)); v[3] += bf2f((bf16_t)(r.y >> 16));
           }
         }
-        if (p.act != ACT_NONE) {
+        // (convolutions: no activation, bf16 output, no LayerNorm row sums — gemm_launch() checks — so their kernels carry none of it)
+        if (CONV == 0 && p.act != ACT_NONE) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
         }
-        if (p.out_mode == OUT_F32) {
+        if (CONV == 0 && p.out_mode == OUT_F32) {
           *reinterpret_cast<float4*>((float*)p.C + crow[i] + n) = make_float4(v[0], v[1], v[2], v[3]);
           if (hi) *reinterpret_cast<float4*>((float*)p.C + crow[i] + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
           uint4 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
           if (hi) *reinterpret_cast<uint4*>((bf16_t*)p.C + crow[i] + n) = o;
           else *reinterpret_cast<uint2*>((bf16_t*)p.C + crow[i] + n) = make_uint2(o.x, o.y);
-          if (p.row_stats) {   // statistics of what the consumer will read: the rounded values
+          if (CONV == 0 && p.row_stats) {   // statistics of what the consumer will read: the rounded values
             const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
             const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
             rws[i] += (r0 + r1) + (r2 + r3);
@@ -800,14 +801,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           if (e >= 4 && !pair) break;
-          float a = gs[e], q = gq[e];
-#pragma unroll
-          for (int off = 1; off < 16; off <<= 1) { a += __shfl_xor(a, off, 64); q += __shfl_xor(q, off, 64); }
+          const float a = row16_sum(gs[e]), q = row16_sum(gq[e]);     // over the 16 row lanes (DPP: no LDS traffic)
           if (frow == 0) red_lane[cl + e] = make_float2(a, q);
         }
       }
     }
-    if (p.row_stats) {
+    if (CONV == 0 && p.row_stats) {
       // a row's BN/2 columns of this wave sit in the 4 lanes {frow, frow+16, frow+32, frow+48}; plane = (N tile, wave column)
       float* plane = p.row_stats + (size_t)((n0 / BN) * 2 + wn) * p.M * 2;
 #pragma unroll
@@ -1179,7 +1178,8 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
     GILL_REQUIRE(a.Cin / BK <= ZERO_PAGE_STEPS, "conv: Cin too large for the zero page");
     GILL_REQUIRE(a.K1 == a.Cin || a.A2 != nullptr, "conv: second source missing");
     GILL_REQUIRE(!(a.ups && a.stride != 1), "conv: upsample needs stride 1");
-    GILL_REQUIRE(a.out_mode != OUT_QKV && a.act != ACT_GEGLU, "conv: row-major epilogue only");
+    GILL_REQUIRE(a.out_mode == OUT_BF16 && a.act == ACT_NONE && !a.resid_f32 && !a.row_stats,
+                 "conv: bf16 row-major epilogue without activation / fp32 residual / row statistics only");
     GILL_REQUIRE((int64_t)(a.M / (a.OH * a.OW)) * a.IH * a.IW * a.Cin < (int64_t)1 << 31, "conv input too large for 32-bit offsets");
   } else {
     GILL_REQUIRE(a.K1 % BK == 0 && a.K1 <= a.K, "K split must be a multiple of 64");
