@@ -125,23 +125,29 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0
 }
 
 // CONV: 0 plain GEMM, 1 conv3x3, 2 conv3x3 with fused nearest-2x upsample
-// EPI : 0 row-major (bf16 / fp32) epilogue, 1 GEGLU, 2 raw fp32 split-K partials, 3 QKV head-major scatter
+// EPI : 0 row-major (bf16 / fp32) epilogue, 1 GEGLU, 2 raw fp32 split-K partials, 3 QKV head-major scatter,
+//       4 = 0 without activation / fp32 output / fp32 residual (the UNet's plain GEMMs: half the epilogue's code and branches)
 // STAGES: depth of the LDS ring.  2: two workgroups per CU hide each other's DMA waits.  3: one workgroup per CU,
 //         the DMA of K steps i+1 AND i+2 is in flight while step i is multiplied (counted s_waitcnt vmcnt(N), raw
 //         s_barrier) — for grids of ~one workgroup per CU where co-residency cannot do the hiding.
 // folded LayerNorm: rstd and mean*rstd of A's row m from the producer's {sum, sum of squares}
 __device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& rr, float& rm) {
-  // the producer's per-plane partial sums of this row, added in plane order (fixed order: bit-reproducible); the loads are
-  // issued together (predicated up to LN_MAX_PLANES), not one L2 round trip per plane
+  // the producer's per-plane partial sums of this row, added in plane order (fixed order: bit-reproducible); the loads go out four
+  // planes at a time (predicated), not one L2 round trip per plane — and not LN_MAX_PLANES predicated loads per row: a level-0
+  // consumer reads 4 planes (the prologue of the GEGLU / QKV kernels was 80 load slots per lane for them)
   const int R = p.ln_rows ? p.ln_rows : p.M;
   if (m >= R) m -= R;
-  float2 v[LN_MAX_PLANES];
+  const float* base = p.ln_stats + (size_t)m * 2;
+  const size_t pstride = (size_t)R * 2;
+  float2 st = make_float2(0.f, 0.f);
+  for (int pl = 0; pl < p.ln_planes; pl += 4) {      // (wave-uniform trip count)
+    float2 v[4];
 #pragma unroll
-  for (int pl = 0; pl < LN_MAX_PLANES; ++pl)
-    v[pl] = (pl < p.ln_planes) ? *reinterpret_cast<const float2*>(p.ln_stats + ((size_t)pl * R + m) * 2) : make_float2(0.f, 0.f);
-  float2 st = v[0];
+    for (int u = 0; u < 4; ++u)
+      v[u] = (pl + u < p.ln_planes) ? *reinterpret_cast<const float2*>(base + (size_t)(pl + u) * pstride) : make_float2(0.f, 0.f);
 #pragma unroll
-  for (int pl = 1; pl < LN_MAX_PLANES; ++pl) { st.x += v[pl].x; st.y += v[pl].y; }
+    for (int u = 0; u < 4; ++u) { st.x += v[u].x; st.y += v[u].y; }
+  }
   const float invk = 1.f / (float)p.K;
   const float mean = st.x * invk;
   const float var = fmaxf(st.y * invk - mean * mean, 0.f);
@@ -750,7 +756,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
           }
         }
         if (p.resid) {
-          if (CONV == 0 && p.resid_f32) {
+          if (CONV == 0 && EPI != 4 && p.resid_f32) {
             const float4 r0 = *reinterpret_cast<const float4*>((const float*)p.resid + rrow[i] + n);
             v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
             if (hi) {
@@ -770,11 +776,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
           }
         }
         // (convolutions: no activation, bf16 output, no LayerNorm row sums — gemm_launch() checks — so their kernels carry none of it)
-        if (CONV == 0 && p.act != ACT_NONE) {
+        if (CONV == 0 && EPI != 4 && p.act != ACT_NONE) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
         }
-        if (CONV == 0 && p.out_mode == OUT_F32) {
+        if (CONV == 0 && EPI != 4 && p.out_mode == OUT_F32) {
           *reinterpret_cast<float4*>((float*)p.C + crow[i] + n) = make_float4(v[0], v[1], v[2], v[3]);
           if (hi) *reinterpret_cast<float4*>((float*)p.C + crow[i] + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
@@ -949,6 +955,11 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
   }
 }
 
+static int env_int(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+}
+
 // width of the split-K reducer's blocks: 80 when the fused GroupNorm bins do not divide 64 (UNet: 5 / 10 / 20 / 40 channels)
 // (160 where N allows: a block row is then 640 B = five whole 128-B lines of a partial slice; 80-wide blocks read 320-B pieces, every
 // other one straddling a line: loop 568.3 -> 562.5 ms, profiles/r02_big_tile.md)
@@ -957,6 +968,7 @@ static inline int reduce_width(const GemmArgs& a) {
   return 64;
 }
 // rows per block of the reducer: 64 for large outputs, 16 when there would be too few blocks to pull the partials
+// (32-row blocks where they would still give every CU two blocks: measured equal, 536.2 vs 536.3 ms on the loop — not kept)
 static inline int reduce_rows(const GemmArgs& a) {
   return ((int64_t)cdiv(a.N, reduce_width(a)) * cdiv(a.M, 64) >= 1024) ? 64 : 16;
 }
@@ -988,10 +1000,6 @@ bool gemm_fused_gn_ok(int N, int cg) {
   return bn % cg == 0 && (64 % cg == 0 || (80 % cg == 0 && N % 80 == 0));
 }
 
-static int env_int(const char* name) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : 0;
-}
 
 // 3x3 convolutions whose row count is a multiple of 256 and whose width tiles by 160 run on the 256 x 160 ping-pong kernel
 // (GILL_GEMM_PP = 0: two co-resident 128 x 160 workgroups instead, the round-1 structure)
@@ -1074,7 +1082,7 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
   if constexpr (CONV == 0 && EPI != 2) {
     if (d.nwv == 2) return gemm_launch_inst<2, BN, CONV, EPI, 2>(d, grid, s);
   }
-  if constexpr (CONV == 0 && (EPI == 0 || EPI == 3) && BN == 128) {
+  if constexpr (CONV == 0 && (EPI == 0 || EPI == 3 || EPI == 4) && BN == 128) {
     if (d.nwv == 4 && d.mi == 2) return gemm_launch_inst<4, BN, CONV, EPI, 2, BK, 2>(d, grid, s);   // 64-row tile on four waves
   }
   if constexpr (BN == 160 && CONV != 0) {
@@ -1154,6 +1162,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
       else GILL_REQUIRE(BN == 128, "internal: GEGLU runs on 128-wide tiles");
     }
     else if (a.out_mode == OUT_QKV) GILL_TRY((gemm_launch_stages<BN, 0, 3>(d, grid, s)));
+    else if (a.act == ACT_NONE && a.out_mode == OUT_BF16 && !a.resid_f32) GILL_TRY((gemm_launch_stages<BN, 0, 4>(d, grid, s)));
     else GILL_TRY((gemm_launch_stages<BN, 0, 0>(d, grid, s)));
   }
   if (sk > 1) return gemm_splitk_reduce_launch(d.a, s);
