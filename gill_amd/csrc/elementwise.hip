@@ -329,8 +329,8 @@ __global__ __launch_bounds__(256) void conv_out_mfma_kernel(const bf16_t* __rest
 int conv_out_launch(const bf16_t* x, const bf16_t* w, const float* bias, int B, int Cin, int H, int W, int Cout, float* y,
                     hipStream_t s) {
   const size_t wbytes = (size_t)Cout * 9 * Cin * sizeof(bf16_t);
-  static const bool direct = getenv("GILL_CONV_OUT_DIRECT") != nullptr;      // A/B switch: the VALU kernel
-  if (!direct && Cout <= 16 && Cin % 32 == 0 && W % 16 == 0 && wbytes <= 64 * 1024 && (((uintptr_t)w | (uintptr_t)x) & 15) == 0) {
+  // matrix-pipe kernel where its geometry holds; the one-wave-per-pixel kernel is the general path (rows not a multiple of 16 wide, ...)
+  if (Cout <= 16 && Cin % 32 == 0 && W % 16 == 0 && wbytes <= 64 * 1024 && (((uintptr_t)w | (uintptr_t)x) & 15) == 0) {
     const int64_t groups = (int64_t)B * H * (W / 16);
     const dim3 grid((unsigned)cdiv64(groups, 4));
     if (Cin == 320) hipLaunchKernelGGL(conv_out_mfma_kernel<10>, grid, dim3(256), wbytes, s, x, w, bias, B, Cin, H, W, Cout, y);

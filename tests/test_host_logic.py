@@ -138,3 +138,19 @@ def test_gill_construction_and_reference_error_behaviour():
   from PIL import Image
   with pytest.raises((NotImplementedError, RuntimeError)):
     g.generate_for_images_and_texts([Image.new("RGB", (40, 30)), "x"], num_words=2)
+
+
+def test_install_as_gill_aliases_the_reference_import_names():
+  """`from gill import models` resolves to the MI355X package after gill_amd.install_as_gill()."""
+  import subprocess
+  import sys
+  code = ("import gill_amd; gill_amd.install_as_gill()\n"
+          "from gill import models, layers, utils\n"
+          "import gill.models as m2\n"
+          "assert models is gill_amd.models and m2 is models and layers.TextFcLayer is gill_amd.layers.TextFcLayer\n"
+          "assert hasattr(models, 'load_gill') and hasattr(models, 'GILL') and hasattr(models, 'GILLArgs')\n"
+          "print('ok')\n")
+  import os
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=300)
+  assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
