@@ -324,38 +324,56 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
   const int p0 = blockIdx.x * rows;
   int p1 = p0 + rows;
   if (p1 > HW) p1 = HW;
-  const int nwork = (p1 - p0) * vec_per_row;
-  for (int i = threadIdx.x; i < nwork; i += blockDim.x) {
-    const int pr = i / vec_per_row;
-    const int c = c0 + (i - pr * vec_per_row) * 8;
-    const int64_t row = (int64_t)b * HW + p0 + pr;
-    const bf16_t* src;
-    if (c < C1) src = x1 + row * C1 + c; else src = x2 + row * C2 + (c - C1);
-    const gn_u32x4 u = *reinterpret_cast<const gn_u32x4*>(src);
+  // Phase 2.  A thread keeps ONE 8-channel vector column (its scale / shift live in registers) and walks the slab's rows with a
+  // stride of 256 / vec_per_row rows, four rows in flight per pass: no per-element division, no LDS reads in the loop
+  // (vec_per_row = cc / 8 <= 32; the 256 % vec_per_row threads left over — 16 of 256 for the UNet's 160-channel chunks — idle).
+  {
+    const int rstride = 256 / vec_per_row;
+    const int vcol = threadIdx.x % vec_per_row, rlane = threadIdx.x / vec_per_row;
+    if (rlane >= rstride) return;
+    const int c = c0 + vcol * 8;
     const float4 s0 = *reinterpret_cast<const float4*>(scale + c), s1 = *reinterpret_cast<const float4*>(scale + c + 4);
     const float4 h0 = *reinterpret_cast<const float4*>(shift + c), h1 = *reinterpret_cast<const float4*>(shift + c + 4);
-    float o[8];
-    o[0] = fmaf(bf2f((bf16_t)(u[0] & 0xffff)), s0.x, h0.x); o[1] = fmaf(bf2f((bf16_t)(u[0] >> 16)), s0.y, h0.y);
-    o[2] = fmaf(bf2f((bf16_t)(u[1] & 0xffff)), s0.z, h0.z); o[3] = fmaf(bf2f((bf16_t)(u[1] >> 16)), s0.w, h0.w);
-    o[4] = fmaf(bf2f((bf16_t)(u[2] & 0xffff)), s1.x, h1.x); o[5] = fmaf(bf2f((bf16_t)(u[2] >> 16)), s1.y, h1.y);
-    o[6] = fmaf(bf2f((bf16_t)(u[3] & 0xffff)), s1.z, h1.z); o[7] = fmaf(bf2f((bf16_t)(u[3] >> 16)), s1.w, h1.w);
-    if (silu) {
+    const bool from1 = c < C1;
+    const bf16_t* src = from1 ? x1 + c : x2 + (c - C1);
+    const int cs = from1 ? C1 : C2;
+    const int64_t rbase = (int64_t)b * HW;
+    for (int pr = p0 + rlane; pr < p1; pr += 4 * rstride) {
+      gn_u32x4 u[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = silu_f(o[e]);
-    }
-    if (out8_scale > 0.f) {     // fp8 (e4m3) output: the A operand of the fp8 convolution (conv_fp8.hip), 8 bytes per thread
+      for (int k = 0; k < 4; ++k) {
+        const int r = pr + k * rstride;
+        u[k] = (r < p1) ? *reinterpret_cast<const gn_u32x4*>(src + (rbase + r) * cs) : gn_u32x4{0u, 0u, 0u, 0u};
+      }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = clamp_fp8_keep_nan(o[e] * out8_scale);
-      int lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], 0, false);
-      lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], lo, true);
-      int hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[4], o[5], 0, false);
-      hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[6], o[7], hi, true);
-      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(y) + row * C + c) = make_uint2((unsigned)lo, (unsigned)hi);
-      continue;
+      for (int k = 0; k < 4; ++k) {
+        const int r = pr + k * rstride;
+        if (r >= p1) break;
+        float o[8];
+        o[0] = fmaf(bf2f((bf16_t)(u[k][0] & 0xffff)), s0.x, h0.x); o[1] = fmaf(bf2f((bf16_t)(u[k][0] >> 16)), s0.y, h0.y);
+        o[2] = fmaf(bf2f((bf16_t)(u[k][1] & 0xffff)), s0.z, h0.z); o[3] = fmaf(bf2f((bf16_t)(u[k][1] >> 16)), s0.w, h0.w);
+        o[4] = fmaf(bf2f((bf16_t)(u[k][2] & 0xffff)), s1.x, h1.x); o[5] = fmaf(bf2f((bf16_t)(u[k][2] >> 16)), s1.y, h1.y);
+        o[6] = fmaf(bf2f((bf16_t)(u[k][3] & 0xffff)), s1.z, h1.z); o[7] = fmaf(bf2f((bf16_t)(u[k][3] >> 16)), s1.w, h1.w);
+        if (silu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = silu_f(o[e]);
+        }
+        const int64_t row = rbase + r;
+        if (out8_scale > 0.f) {     // fp8 (e4m3) output: the A operand of the fp8 convolution (conv_fp8.hip), 8 bytes per thread
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = clamp_fp8_keep_nan(o[e] * out8_scale);
+          int lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], 0, false);
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], lo, true);
+          int hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[4], o[5], 0, false);
+          hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[6], o[7], hi, true);
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(y) + row * C + c) = make_uint2((unsigned)lo, (unsigned)hi);
+        } else {
+          gn_u32x4 wv;
+          wv[0] = pack_bf2(o[0], o[1]); wv[1] = pack_bf2(o[2], o[3]); wv[2] = pack_bf2(o[4], o[5]); wv[3] = pack_bf2(o[6], o[7]);
+          *reinterpret_cast<gn_u32x4*>(y + row * C + c) = wv;
+        }
+      }
     }
-    gn_u32x4 w;
-    w[0] = pack_bf2(o[0], o[1]); w[1] = pack_bf2(o[2], o[3]); w[2] = pack_bf2(o[4], o[5]); w[3] = pack_bf2(o[6], o[7]);
-    *reinterpret_cast<gn_u32x4*>(y + row * C + c) = w;
   }
 }
 
