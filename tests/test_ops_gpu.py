@@ -41,6 +41,18 @@ def test_gemm_plain(cuda, M, N, K):
   assert _report(f"gemm f32out {M}x{N}x{K}", out32, ref) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(4096, 320, 1600, 1), (1024, 640, 3200, 1), (512, 1280, 6400, 2), (384, 320, 1600, 3)])
+def test_gemm_long_k_with_residual(cuda, M, N, K, sk):
+  """The shapes of the UNet's fused feed-forward output GEMMs (N = 320 .. 1280, K = 5 N), with residual, unsplit and split-K.
+  (Running them on the convolutions' ping-pong tiles was measured: 541.5 vs 542.7 ms on the loop, inside the noise — not kept.)"""
+  from gill_amd import ops
+  a, w = _bf(_rnd((M, K), 11)), _bf(_rnd((N, K), 12, 0.05))
+  bias, resid = _rnd((N,), 13), _bf(_rnd((M, N), 14))
+  ref = a.float() @ w.float().T + bias + resid.float()
+  out = ops.gemm(a.to(cuda), w.to(cuda), bias.to(cuda), resid=resid.to(cuda), splitk=sk)
+  assert _report(f"gemm long-K {M}x{N}x{K} sk{sk}", out, ref) < 1e-2
+
+
 @pytest.mark.parametrize("act", ["relu", "silu", "gelu"])
 def test_gemm_epilogue(cuda, act):
   from gill_amd import ops
