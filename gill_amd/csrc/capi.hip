@@ -73,17 +73,22 @@ extern "C" int gill_op_conv3x3(const void* x1, int C1, const void* x2, int C2, c
   hipStream_t s = (hipStream_t)stream;
   const int Cin = C1 + C2;
   DevBuf wr, ws;
-  GILL_TRY(wr.alloc(sizeof(bf16_t) * (size_t)Cout * 9 * Cin));
+  GILL_TRY(wr.alloc(sizeof(bf16_t) * (size_t)Cout * 16 * Cin));     // 9 taps, or 4 classes x 4 taps
   // K order as the engines choose it (GILL_CONV_KORDER = 0 | 1 forces tap-major / chunk-major for tests and tools)
-  const int chunked = conv_k_chunked(IH * IW, Cin, Cout) ? 1 : 0;
-  if (chunked) GILL_TRY(conv_weight_relayout_chunked_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wr.p, s));
+  int chunked = conv_k_chunked(IH * IW, Cin, Cout) ? 1 : 0;
+  // ups = 1: the engines' form — four pre-summed 2x2-tap kernels on the source grid (GILL_CONV_UPS4 = 0, or a residual / row
+  // vector, which that form does not take: the 9-tap gather over the upsampled grid)
+  const char* u4 = getenv("GILL_CONV_UPS4");
+  const bool ups4 = ups && stride == 1 && !rowvec && !resid && !(u4 && atoi(u4) == 0);
+  if (ups4) { chunked = 0; GILL_TRY(conv_weight_relayout_ups4_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wr.p, s)); }
+  else if (chunked) GILL_TRY(conv_weight_relayout_chunked_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wr.p, s));
   else GILL_TRY(conv_weight_relayout_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wr.p, s));
   GemmArgs g;
   g.conv = 1;
-  g.IH = IH; g.IW = IW; g.Cin = Cin; g.stride = stride; g.ups = ups;
+  g.IH = IH; g.IW = IW; g.Cin = Cin; g.stride = stride; g.ups = ups4 ? 2 : ups;
   if (ups) { g.OH = 2 * IH; g.OW = 2 * IW; }
   else { g.OH = (IH + 2 - 3) / stride + 1; g.OW = (IW + 2 - 3) / stride + 1; }
-  g.M = B * g.OH * g.OW; g.N = Cout; g.K = 9 * Cin;
+  g.M = B * g.OH * g.OW; g.N = Cout; g.K = (ups4 ? 4 : 9) * Cin;
   g.A = (const bf16_t*)x1; g.A2 = (const bf16_t*)x2; g.K1 = C1;
   g.W = (const bf16_t*)wr.p; g.k_chunked = chunked;
   g.bias = bias;

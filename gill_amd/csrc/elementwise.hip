@@ -523,6 +523,33 @@ __global__ __launch_bounds__(256) void conv_w_relayout_chunked_kernel(const void
     out[i] = f2bf(load_as_f32(w, dtype, ((int64_t)o * Cin + c) * 9 + tap));
   }
 }
+// OIHW (3x3) of a convolution that follows a nearest-2x upsample -> [class = py*2+px][O][a*2+b][I]: the four 2x2-tap kernels on the
+// SOURCE grid (gemm.hip, "UPS4").  Output pixel (2y+py, 2x+px), tap ky reads upsampled row 2y+py+ky-1 = source row
+// y + floor((py+ky-1)/2): py = 0: ky 0 -> y-1 (a = 0), ky 1, 2 -> y (a = 1); py = 1: ky 0, 1 -> y (a = 0), ky 2 -> y+1 (a = 1).  The taps
+// that share a source pixel are summed in fp32 (ascending ky, then kx) and rounded to bf16 once.
+__global__ __launch_bounds__(256) void conv_w_relayout_ups4_kernel(const void* w, int dtype, int Cout, int Cin, bf16_t* out) {
+  const int64_t n = (int64_t)4 * Cout * 4 * Cin;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cin);
+    const int t4 = (int)((i / Cin) % 4);
+    const int o = (int)((i / ((int64_t)Cin * 4)) % Cout);
+    const int cls = (int)(i / ((int64_t)Cin * 4 * Cout));
+    const int py = cls >> 1, px = cls & 1, a = t4 >> 1, b = t4 & 1;
+    const int ky0 = (py == 0) ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), ky1 = (py == 0) ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+    const int kx0 = (px == 0) ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), kx1 = (px == 0) ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+    float acc = 0.f;
+    for (int ky = ky0; ky <= ky1; ++ky)
+      for (int kx = kx0; kx <= kx1; ++kx) acc += load_as_f32(w, dtype, ((int64_t)o * Cin + c) * 9 + ky * 3 + kx);
+    out[i] = f2bf(acc);
+  }
+}
+int conv_weight_relayout_ups4_launch(const void* w, int dtype, int Cout, int Cin, bf16_t* out, hipStream_t s) {
+  GILL_REQUIRE(dtype >= 0 && dtype <= 2, "unsupported source dtype");
+  GILL_REQUIRE(Cin % 64 == 0, "implicit-GEMM conv: input channels must be a multiple of 64");
+  hipLaunchKernelGGL(conv_w_relayout_ups4_kernel, dim3(grid_for((int64_t)16 * Cout * Cin)), dim3(256), 0, s, w, dtype, Cout, Cin, out);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 int conv_weight_relayout_chunked_launch(const void* w, int dtype, int Cout, int Cin, bf16_t* out, hipStream_t s) {
   GILL_REQUIRE(dtype >= 0 && dtype <= 2, "unsupported source dtype");
   GILL_REQUIRE(Cin % 64 == 0, "implicit-GEMM conv: input channels must be a multiple of 64");

@@ -124,7 +124,8 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0
   }
 }
 
-// CONV: 0 plain GEMM, 1 conv3x3, 2 conv3x3 with fused nearest-2x upsample
+// CONV: 0 plain GEMM, 1 conv3x3, 2 conv3x3 with fused nearest-2x upsample (9 taps gathered from the source grid),
+//       3 nearest-2x upsample + conv3x3 as FOUR 2x2-tap convolutions of the source grid, one per output parity (see "UPS4")
 // EPI : 0 row-major (bf16 / fp32) epilogue, 1 GEGLU, 2 raw fp32 split-K partials, 3 QKV head-major scatter,
 //       4 = 0 without activation / fp32 output / fp32 residual (the UNet's plain GEMMs: half the epilogue's code and branches)
 // STAGES: depth of the LDS ring.  2: two workgroups per CU hide each other's DMA waits.  3: one workgroup per CU,
@@ -215,6 +216,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
   int kt_end = kt_beg + d.ksteps_per_split;
   if (kt_end > d.ksteps) kt_end = d.ksteps;
   const int nsteps = kt_end - kt_beg;
+  // UPS4 (CONV = 3).  conv3x3(nearest_2x(x)) reads, for the output pixel (2y + py, 2x + px), only the 2 x 2 source pixels
+  // (y + py - 1 + a, x + px - 1 + b), a, b in {0, 1}: the 9 taps fall onto them in groups whose weights can be summed once at load
+  // (conv_weight_relayout_ups4_launch: W4[class][n][a*2+b][c]; a summed group is always in or out of the image as a whole).  So the
+  // layer is four stride-1 2x2-tap convolutions of the SOURCE grid — K = 4 Cin instead of 9 Cin, the same linear map with 2.25x
+  // fewer multiply-adds.  blockIdx.z = parity class; p.M = source pixels (rows of one class); output row of source row m:
+  // (b * OH + 2y + py) * OW + 2x + px.
+  const int cls = (CONV == 3) ? blockIdx.z : 0;
+  const int ups_py = cls >> 1, ups_px = cls & 1;
 
   // ---- per-lane staging geometry: instruction i of wave w fills tile rows (i*NWV+w)*RPI .. +RPI
   const int srow = lane / LPR;                            // row within the instruction's row group
@@ -241,7 +250,15 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       const int oy = r / p.OW;
       const int ox = r - oy * p.OW;
       int fl = 0, pc;
-      if constexpr (CONV == 2) {
+      if constexpr (CONV == 3) {      // rows are SOURCE pixels: a stride-1 walk of the source grid
+        const int shw = p.IH * p.IW;
+        const int sb = m / shw;
+        const int sr = m - sb * shw;
+        const int sy = sr / p.IW, sx = sr - sy * p.IW;
+        pc = m;
+        fl |= (sy - 1 >= 0) ? 1 : 0; fl |= (sy + 1 < p.IH) ? 2 : 0;
+        fl |= (sx - 1 >= 0) ? 4 : 0; fl |= (sx + 1 < p.IW) ? 8 : 0;
+      } else if constexpr (CONV == 2) {
         pc = (b * p.IH + (oy >> 1)) * p.IW + (ox >> 1);
         fl |= (oy - 1 >= 0) ? 1 : 0; fl |= (oy + 1 < p.OH) ? 2 : 0;
         fl |= (ox - 1 >= 0) ? 4 : 0; fl |= (ox + 1 < p.OW) ? 8 : 0;
@@ -293,7 +310,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       int row = tile_col((i * NWV + w) * RPI + srow);
       int n = n_issue + row;
       if (n > p.N - 1) n = p.N - 1;
-      w_ptr[i] = p.W + (size_t)n * p.K + schunk * 8 + kt_beg * KT;
+      w_ptr[i] = p.W + ((size_t)cls * p.N + n) * p.K + schunk * 8 + kt_beg * KT;
     }
   };
   w_setup();
@@ -337,7 +354,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
           c0 = k0 - tap * p.Cin;
         }
         const int ty = tap / 3;
-        const int dy = ty - 1, dx = tap - ty * 3 - 1;
+        int dy = ty - 1, dx = tap - ty * 3 - 1;
+        if constexpr (CONV == 3) { dy = ups_py - 1 + (tap >> 1); dx = ups_px - 1 + (tap & 1); }    // tap = a * 2 + b of the 2 x 2 window
         const int need = (dy < 0 ? 1 : (dy > 0 ? 2 : 0)) | (dx < 0 ? 4 : (dx > 0 ? 8 : 0));
         const bool first = (c0 < p.K1);
         const bf16_t* src = first ? p.A : p.A2;
@@ -587,12 +605,24 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
   const int mrow = m0 + wm * (MI * 16) + frow;
   const int nbase = n0 + wn * (BN / 2);
   constexpr int NG = (NT + 1) / 2;      // column groups per lane
+  // UPS4: output row of source row m (divisions once per row, here only)
+  auto out_row = [&](int m) -> int {
+    if constexpr (CONV == 3) {
+      const int shw = p.IH * p.IW;
+      const int sb = m / shw;
+      const int sr = m - sb * shw;
+      const int sy = sr / p.IW, sx = sr - sy * p.IW;
+      return (sb * p.OH + 2 * sy + ups_py) * p.OW + 2 * sx + ups_px;
+    } else {
+      return m;
+    }
+  };
   if constexpr (EPI == 2) {
-    float* ws = p.ws + (size_t)z * p.M * p.N;
+    float* ws = p.ws + (size_t)z * (CONV == 3 ? 4 : 1) * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      const int m = mrow + i * 16;
-      if (m >= p.M) continue;
+      if (mrow + i * 16 >= p.M) continue;
+      const int m = out_row(mrow + i * 16);
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const bool pair = (2 * g + 1 < NT);
@@ -716,7 +746,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
     for (int i = 0; i < MI; ++i) {
       const int m = mrow + i * 16;
       mok[i] = m < p.M;
-      crow[i] = m * p.ldc;
+      crow[i] = out_row(m) * p.ldc;
       rrow[i] = m * p.ldr;
       vrow[i] = p.rowvec ? (m / p.rows_per_batch) * p.rowvec_bstride : 0;
     }
@@ -839,9 +869,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
             const float* src = reinterpret_cast<const float*>(red + (half * GPS + g) * BN + lb * p.gn_cg) + which;
             for (int c = 0; c < p.gn_cg; ++c) a += src[2 * c];
           }
+          // (UPS4: rows_per_batch = SOURCE pixels per sample; a slab = 64 source rows of one class — any fixed partition of a
+          // sample's output pixels into 64-row slabs serves the consumer, which only adds the slabs up in index order)
           const int b = mfirst / p.rows_per_batch;
-          const int slab = (mfirst - b * p.rows_per_batch) / GN_SLAB_ROWS;
-          const int nslab = p.rows_per_batch / GN_SLAB_ROWS;
+          const int slab = (mfirst - b * p.rows_per_batch) / GN_SLAB_ROWS + (CONV == 3 ? cls * (p.rows_per_batch / GN_SLAB_ROWS) : 0);
+          const int nslab = (CONV == 3 ? 4 : 1) * (p.rows_per_batch / GN_SLAB_ROWS);
           p.gn_stats[(((size_t)b * nslab + slab) * p.gn_groups + bin) * 2 + which] = a;
         }
       }
@@ -1100,6 +1132,12 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   GILL_REQUIRE(d.zero != nullptr, "zero page unavailable");
   const int sk = a.splitk > 1 ? a.splitk : 1;
   d.a.splitk = sk;
+  GemmArgs red = d.a;       // what the split-K reducer sees: the output tensor, whatever the conv kernel's row space is
+  // UPS4 (a.ups == 2): the kernel's rows are the SOURCE pixels of one parity class, blockIdx.z the class
+  const int ncls = (a.conv && a.ups == 2) ? 4 : 1;
+  const int Mk = a.M / ncls;
+  d.a.M = Mk;
+  d.a.rows_per_batch = a.rows_per_batch / ncls;
   d.tiles_n = cdiv(a.N, BN);
   // 64-row tiles for plain GEMMs whose 128-row tiling leaves CUs without a tile (GILL_GEMM_BM = 64 | 128 forces it: tools/soak.py)
   static const int forced_bm = env_int("GILL_GEMM_BM");
@@ -1115,18 +1153,18 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   if (forced_bm == 64 && !a.conv && sk == 1) { d.nwv = 2; d.mi = 4; }
   // 3x3 convolutions: 256 x 160 tile with the ping-pong main loop, one workgroup per CU (GILL_GEMM_PP = 0 keeps the two
   // co-resident 128 x 160 workgroups)
-  if (BN == 160 && a.conv && gemm_conv_pingpong(a.M, a.N) && forced_bm == 0) {
+  if (BN == 160 && a.conv && gemm_conv_pingpong(Mk, a.N) && forced_bm == 0) {
     d.nwv = 8;
     // Where the 256-row tiling x split-K gives at most 128 workgroups (UNet levels 1-3 at the 8-sample batch), run
     // 128 x 160 ping-pong tiles (eight waves of 32 x 80); gemm_pick_splitk() then aims at 256 workgroups of those, i.e. half the
     // split factor: half the fp32 partials (none at level 1)
     // (loop 561.1 -> 558.0 ms; GILL_GEMM_PP128 = 0 keeps the 256-row tile with twice the split)
-    if (pp128_on() && (int64_t)cdiv(a.M, 256) * d.tiles_n * sk <= 128 && a.M % 128 == 0) d.mi = 2;
+    if (pp128_on() && (int64_t)cdiv(Mk, 256) * ncls * d.tiles_n * sk <= 128 && Mk % 128 == 0) d.mi = 2;
   }
   d.kt = 64;
   d.ksteps = a.K / d.kt;
   d.ksteps_per_split = cdiv(d.ksteps, sk);
-  const int tiles_m = cdiv(a.M, (d.nwv / 2) * d.mi * 16);
+  const int tiles_m = cdiv(Mk, (d.nwv / 2) * d.mi * 16);
   // Short-K GEMMs with many N tiles (GEGLU, QKV: K = 320..1280, 6..80 N tiles) spend most of a tile's life in the first-load
   // latency and the epilogue.  Let one workgroup walk `npw` N tiles back to back instead: the ring is staged across tile
   // boundaries, so the loads of tile t+1 fly during the epilogue of tile t.  Keep ~2 workgroups per CU.
@@ -1145,10 +1183,13 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     const int64_t ael = (int64_t)a.M * (a.conv ? a.Cin + a.KX : a.K);
     d.n_major = (wel > ael && d.groups_n >= 8) ? 1 : 0;
   }
-  dim3 grid(tiles_m * d.groups_n, sk, 1);
+  dim3 grid(tiles_m * d.groups_n, sk, ncls);
   if (BN == 160 && d.nwv == 8) GILL_REQUIRE(d.npw == 1, "internal: the ping-pong kernel walks one N tile per workgroup");
   if (a.conv) {
-    if (a.ups) {
+    if (a.ups == 2) {
+      if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 3, 2>(d, grid, s)));
+      else GILL_TRY((gemm_launch_stages<BN, 3, 0>(d, grid, s)));
+    } else if (a.ups) {
       if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 2, 2>(d, grid, s)));
       else GILL_TRY((gemm_launch_stages<BN, 2, 0>(d, grid, s)));
     } else {
@@ -1165,7 +1206,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     else if (a.act == ACT_NONE && a.out_mode == OUT_BF16 && !a.resid_f32) GILL_TRY((gemm_launch_stages<BN, 0, 4>(d, grid, s)));
     else GILL_TRY((gemm_launch_stages<BN, 0, 0>(d, grid, s)));
   }
-  if (sk > 1) return gemm_splitk_reduce_launch(d.a, s);
+  if (sk > 1) return gemm_splitk_reduce_launch(red, s);
   return 0;
 }
 
@@ -1177,7 +1218,14 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   GILL_REQUIRE(a.N % 4 == 0, "N must be a multiple of 4");
   GILL_REQUIRE(a.A != nullptr && a.W != nullptr, "null operand");
   if (a.conv) {
-    GILL_REQUIRE(a.Cin % BK == 0 && a.K == 9 * a.Cin + a.KX, "conv: Cin must be a multiple of 64 and K == 9*Cin + KX");
+    if (a.ups == 2) {
+      GILL_REQUIRE(a.Cin % BK == 0 && a.K == 4 * a.Cin && a.KX == 0, "upsample conv (4-tap form): Cin must be a multiple of 64 and K == 4*Cin");
+      GILL_REQUIRE(!a.k_chunked && !a.resid && !a.rowvec && a.M % 4 == 0 && a.OH == 2 * a.IH && a.OW == 2 * a.IW,
+                   "upsample conv (4-tap form): tap-major weights, no residual / row vector, output = 2x the source grid");
+      GILL_REQUIRE(!a.gn_stats || a.rows_per_batch % 256 == 0, "upsample conv (4-tap form): fused GroupNorm statistics need whole 64-row slabs per class");
+    } else {
+      GILL_REQUIRE(a.Cin % BK == 0 && a.K == 9 * a.Cin + a.KX, "conv: Cin must be a multiple of 64 and K == 9*Cin + KX");
+    }
     if (a.KX) {
       GILL_REQUIRE(a.stride == 1 && !a.ups && a.X1 != nullptr, "conv: the fused 1x1 segment needs stride 1, no upsample");
       GILL_REQUIRE(a.KX % BK == 0 && a.KX1 % BK == 0 && a.KX1 <= a.KX && (a.KX1 == a.KX || a.X2 != nullptr),

@@ -223,6 +223,7 @@ int conv_weight_relayout_launch(const void* w, int dtype, int Cout, int Cin, bf1
 // step lengthens the memory phase, measured 155 us chunk-major against 126 us tap-major for 64 x 64 x 640 -> 320)
 bool gemm_conv_pingpong(int rows_multiple_of, int Cout);     // true: gemm_launch runs this conv's 3x3 GEMM on the ping-pong kernel
 bool conv_k_chunked(int HW, int Cin, int Cout);   // (GILL_CONV_KORDER = 0 | 1 forces tap-major / chunk-major: tests and tools)
+int conv_weight_relayout_ups4_launch(const void* w, int dtype, int Cout, int Cin, bf16_t* out /*[4][Cout][4][Cin]*/, hipStream_t s);   // GemmArgs::ups == 2
 int conv_weight_relayout_chunked_launch(const void* w, int dtype, int Cout, int Cin, bf16_t* out /*[Cout][Cin/64][9][64]*/, hipStream_t s);   // GemmArgs::conv
 int convert_to_bf16_launch(const void* src, int dtype, int64_t n, bf16_t* dst, hipStream_t s);
 int convert_to_f32_launch(const void* src, int dtype, int64_t n, float* dst, hipStream_t s);

@@ -28,7 +28,7 @@
 namespace {
 
 struct ConvW {
-  bf16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; int chunked = 0; /* K order: GemmArgs::k_chunked */
+  bf16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; int chunked = 0; /* K order: GemmArgs::k_chunked */ int ups4 = 0; /* w = the 4-tap parity-class form (GemmArgs::ups == 2) */
   // gill_unet_config.fp8_convs: e4m3 weights [cout][kpad] in conv_fp8.hip's K order + per-output-channel de-quantisation scale
   unsigned char* w8 = nullptr; float* cs = nullptr; int kpad = 0;
 };
@@ -226,10 +226,19 @@ struct Loader {
     return load_f32(wt, pool, p + ".bias", c, &n->b, s);
   }
   // hw: pixels per sample of the conv's INPUT (decides the K order, see GemmArgs::k_chunked)
-  int conv3(const std::string& p, int cin, int cout, int hw, ConvW* c, bool f8 = false) {
+  // ups4: the conv follows a nearest-2x upsample — store the four pre-summed 2x2-tap kernels instead (gemm.hip "UPS4";
+  // GILL_CONV_UPS4 = 0 keeps the 9-tap gather over the upsampled grid)
+  int conv3(const std::string& p, int cin, int cout, int hw, ConvW* c, bool f8 = false, bool ups4 = false) {
     c->cin = cin; c->cout = cout; c->chunked = conv_k_chunked(hw, cin, cout) ? 1 : 0;
     const gill_tensor* t;
     GILL_TRY(wt.get(p + ".weight", (int64_t)cout * cin * 9, &t));
+    static const int ups4_on = [] { const char* v = getenv("GILL_CONV_UPS4"); return v ? atoi(v) : 1; }();
+    if (ups4 && ups4_on && !f8) {
+      c->ups4 = 1; c->chunked = 0;
+      GILL_TRY(pool.alloc(&c->w, (size_t)16 * cout * cin, false));
+      GILL_TRY(conv_weight_relayout_ups4_launch(t->data, t->dtype, cout, cin, c->w, s));
+      return load_f32(wt, pool, p + ".bias", cout, &c->b, s);
+    }
     if (f8) {
       c->kpad = conv_fp8_kpad(cin);
       GILL_TRY(pool.alloc(&c->w8, (size_t)cout * c->kpad, false));
@@ -473,7 +482,7 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
         if ((rc = L.xf(p + ".attentions." + std::to_string(j), outc, Hl[3 - i], ctxd, layer_id++, &m->up_xf[i][j]))) return fail(rc);
     }
     if (i < 3)
-      if ((rc = L.conv3(p + ".upsamplers.0.conv", outc, outc, hw_of(3 - i), &m->up_us[i]))) return fail(rc);
+      if ((rc = L.conv3(p + ".upsamplers.0.conv", outc, outc, hw_of(3 - i), &m->up_us[i], false, true))) return fail(rc);
   }
   m->n_xf = layer_id;
   if (temb_off != temb_total) { gill_set_error("internal: temb table width mismatch"); return fail(-4); }
@@ -609,6 +618,7 @@ struct UNetRun {
     g.M = Bx * y.H * y.W; g.N = w.cout; g.K = 9 * w.cin;
     g.A = x1.p; g.A2 = x2 ? x2->p : nullptr; g.K1 = x1.C;
     g.W = w.w; g.bias = w.b; g.k_chunked = w.chunked;
+    if (ups && w.ups4) { g.ups = 2; g.K = 4 * w.cin; }
     g.rowvec = rowvec; g.rows_per_batch = y.H * y.W; g.rowvec_bstride = rv_bstride;
     g.resid = resid; g.ldr = w.cout;
     g.C = y.p; g.ldc = w.cout;
@@ -849,7 +859,8 @@ struct UNetRun {
         if (i > 0) { Tensor z; GILL_TRY(xf(x, m->up_xf[i][j], &z, true)); x = z; }
       }
       if (i < 3) {
-        Tensor y = talloc(x.H * 2, x.W * 2, x.C, true);
+        // (4-tap form: the epilogue's GroupNorm slabs are 64 SOURCE rows of one parity class — tiny grids leave the sums to the consumer)
+        Tensor y = talloc(x.H * 2, x.W * 2, x.C, !m->up_us[i].ups4 || (x.H * x.W) % GN_SLAB_ROWS == 0);
         GILL_TRY(conv(x, nullptr, m->up_us[i], 1, 1, nullptr, 0, nullptr, y));
         x = y;
       }

@@ -18,7 +18,7 @@
 
 namespace {
 
-struct ConvW { bf16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; };
+struct ConvW { bf16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; int ups4 = 0; };
 struct NormW { float* g = nullptr; float* b = nullptr; };
 struct VResW {
   NormW n1, n2;
@@ -145,10 +145,18 @@ struct VLoader {
     GILL_TRY(load_f32(wt, pool, p + ".weight", c, &n->g, s));
     return load_f32(wt, pool, p + ".bias", c, &n->b, s);
   }
-  int conv3(const std::string& p, int cin, int cout, ConvW* c) {
+  // ups4: the conv follows a nearest-2x upsample — store the four pre-summed 2x2-tap kernels (gemm.hip "UPS4"; GILL_CONV_UPS4 = 0: off)
+  int conv3(const std::string& p, int cin, int cout, ConvW* c, bool ups4 = false) {
     c->cin = cin; c->cout = cout;
     const gill_tensor* t;
     GILL_TRY(wt.get(p + ".weight", (int64_t)cout * cin * 9, &t));
+    static const int ups4_on = [] { const char* v = getenv("GILL_CONV_UPS4"); return v ? atoi(v) : 1; }();
+    if (ups4 && ups4_on) {
+      c->ups4 = 1;
+      GILL_TRY(pool.alloc(&c->w, (size_t)16 * cout * cin, false));
+      GILL_TRY(conv_weight_relayout_ups4_launch(t->data, t->dtype, cout, cin, c->w, s));
+      return load_f32(wt, pool, p + ".bias", cout, &c->b, s);
+    }
     GILL_TRY(pool.alloc(&c->w, (size_t)cout * cin * 9, false));
     GILL_TRY(conv_weight_relayout_launch(t->data, t->dtype, cout, cin, c->w, s));   // tap-major K order (k_chunked = 0)
     return load_f32(wt, pool, p + ".bias", cout, &c->b, s);
@@ -239,6 +247,7 @@ struct VRun {
     g.conv = 1; g.IH = x.H; g.IW = x.W; g.OH = y.H; g.OW = y.W; g.Cin = w.cin; g.stride = 1; g.ups = ups;
     g.M = B * y.H * y.W; g.N = w.cout; g.K = 9 * w.cin;
     g.A = x.p; g.K1 = x.C; g.W = w.w; g.bias = w.b;
+    if (ups && w.ups4) { g.ups = 2; g.K = 4 * w.cin; }
     g.rows_per_batch = y.H * y.W;
     g.resid = resid; g.ldr = w.cout;
     g.C = y.p; g.ldc = w.cout;
@@ -351,7 +360,8 @@ struct VRun {
         x = y;
       }
       if (i < 3) {
-        VTensor y = talloc(x.H * 2, x.W * 2, x.C, true);
+        // (4-tap form: the epilogue's GroupNorm slabs are 64 SOURCE rows of one parity class — tiny grids leave the sums to the consumer)
+        VTensor y = talloc(x.H * 2, x.W * 2, x.C, !m->up_us[i].ups4 || (x.H * x.W) % GN_SLAB_ROWS == 0);
         GILL_TRY(conv(x, m->up_us[i], 1, nullptr, y));
         x = y;
       }
@@ -421,7 +431,7 @@ extern "C" int gill_vae_create(gill_vae** out, const gill_vae_config* cfg, const
       if ((rc = L.resnet(p, j == 0 ? prev : outc, outc, &m->up_res[i][j]))) return fail(rc);
     }
     if (i < 3)
-      if ((rc = L.conv3("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", outc, outc, &m->up_us[i]))) return fail(rc);
+      if ((rc = L.conv3("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", outc, outc, &m->up_us[i], true))) return fail(rc);
     prev = outc;
   }
   if ((rc = L.norm("decoder.conv_norm_out", ch[0], &m->norm_out))) return fail(rc);

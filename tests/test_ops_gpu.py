@@ -138,6 +138,34 @@ def test_conv3x3(cuda, B, H, W, C1, C2, Cout, stride, ups):
     assert _report(f"conv B{B} {H}x{W} {C1}+{C2}->{Cout} s{stride} u{ups} sk{sk}", out, ref) < 1.5e-2
 
 
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout", [
+  (2, 8, 8, 128, 0, 128),        # 128 source rows per class: the four-wave 128 x 128 tile
+  (2, 8, 8, 128, 0, 320),        # ... 128 x 160
+  (1, 6, 10, 64, 64, 160),       # non-square, two sources, ragged last tile (60 source rows)
+  (4, 16, 16, 64, 0, 160),       # 1024 source rows: 128-row ping-pong tiles
+  (16, 32, 32, 64, 0, 320),      # 256-row ping-pong tiles (the level-1 -> level-0 upsampler's grid)
+  (16, 8, 8, 640, 0, 640),       # long K, short rows (level 3 -> 2 geometry at half width)
+])
+def test_conv3x3_upsample_four_tap_form(cuda, B, H, W, C1, C2, Cout):
+  """conv3x3(nearest_2x(x)) as the engines run it: four 2x2-tap convolutions of the source grid with pre-summed weights (gemm.hip
+  "UPS4"; Upsample2D of the UNet / VAE decoder).  Checked against interpolate + conv2d, and — same rounding of the inputs, a
+  different but equally exact association of the taps — against the 9-tap gather kernel."""
+  from gill_amd import ops
+  x1 = _bf(_rnd((B, H, W, C1), 50))
+  x2 = _bf(_rnd((B, H, W, C2), 51)) if C2 else None
+  w = _rnd((Cout, C1 + C2, 3, 3), 52, 0.05)
+  bias = _rnd((Cout,), 53)
+  ref = _conv_ref(x1, x2, w, bias, None, None, 1, 1)
+  for sk in (1, 2):
+    out = ops.conv3x3(x1.to(cuda), w.to(cuda), bias.to(cuda), x2=None if x2 is None else x2.to(cuda), upsample=True, splitk=sk)
+    assert tuple(out.shape) == (B, 2 * H, 2 * W, Cout)
+    assert _report(f"ups4 conv B{B} {H}x{W} {C1}+{C2}->{Cout} sk{sk}", out, ref) < 1.5e-2
+  # with a residual the op falls back to the 9-tap gather: both forms must agree to bf16 rounding
+  zero = torch.zeros((B, 2 * H, 2 * W, Cout), dtype=torch.bfloat16)
+  nine = ops.conv3x3(x1.to(cuda), w.to(cuda), bias.to(cuda), x2=None if x2 is None else x2.to(cuda), resid=zero.to(cuda), upsample=True, splitk=1)
+  assert _report("ups4 vs 9-tap gather", out, nine.float().cpu()) < 1e-2
+
+
 @pytest.mark.parametrize("B,H,W,C1,C2,CS1,CS2,Cout", [
   (2, 32, 32, 128, 0, 192, 64, 160),     # 128-row ping-pong tiles; shortcut over two sources (an up block's conv2)
   (8, 64, 64, 64, 0, 128, 0, 320),       # 256-row ping-pong tiles
