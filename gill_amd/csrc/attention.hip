@@ -7,8 +7,8 @@
 // Workgroup = 8 waves = 256 queries of one (batch, head); each wave owns 32 query rows.  K/V are walked in tiles
 // of 64 keys that all 8 waves share through LDS (coalesced 16-B global loads -> registers -> padded LDS rows,
 // register-staged double buffer: the next tile's global loads are in flight while the current one is consumed;
-// one barrier per tile).  Row strides are padded (+16 B for K rows, +8 B for Vt rows) so every ds_read lane
-// group hits distinct banks.
+// one barrier per tile).  Row strides are padded (+16 B for K and Vt rows: an odd number of 16-B units) so every
+// ds_read_b128 lane group hits distinct banks.
 //
 // Everything is computed transposed so each lane owns ONE query column of the 32x32 tiles:
 //   S^T[kv][q] = sum_d K[kv][d] Q[q][d]          (A = K fragment, B = Q fragment held in registers)
@@ -16,7 +16,10 @@
 // so the running max / sum / rescale are lane-local (one xor-32 shuffle joins the two half waves that share a
 // query).  P never leaves registers: the S^T accumulator registers r=0..7 / 8..15 of a lane are, as they are, the
 // k-slots of the B operand of the PV MFMAs, provided the Vt fragment is gathered with the same kv permutation
-//   kv(h, hi, j) = 16*h + 8*(j>>2) + 4*hi + (j&3)          (two 8-byte LDS reads per fragment).
+//   kv(h, hi, j) = 16*h + 8*(j>>2) + 4*hi + (j&3)
+// — and the Vt tile is stored in LDS in exactly that order (within every 16 keys the 4-key blocks sit as [0-3][8-11][4-7][12-15]:
+// the staging store splits each 16-B chunk into its two 8-B halves anyway), so a fragment is ONE 16-B LDS read (256 B/clk; the two
+// 8-B reads it replaces ran at half that, and at d = 40 the LDS pipe was as busy as the matrix pipe).
 //
 // Softmax cost (the bound at d = 40: one exp per 80 MACs): Q is pre-scaled by scale*log2(e) and the S accumulator is
 // initialised to -m_run, so p = exp2(mfma result); the running max only moves when a row grows past m_run + 8 (rare,
@@ -36,7 +39,7 @@ struct AttCfg {
   static constexpr int NDT = (DP + 31) / 32;      // 32-row d tiles of O^T
   static constexpr int DPV = NDT * 32;
   static constexpr int KSTR = DP + 8;             // K row stride in elements (+16 B)
-  static constexpr int VSTR = ATT_KVT + 4;        // Vt row stride in elements (+8 B)
+  static constexpr int VSTR = ATT_KVT + 8;        // Vt row stride in elements (+16 B)
   static constexpr bool HAS_ONES = (DP % 32) != 0; // a spare Vt row (index DP) of ones carries the softmax row sum
   static constexpr int K_CHUNKS = ATT_KVT * DP / 8;       // 16-B chunks of a K tile
   static constexpr int V_CHUNKS = DPV * ATT_KVT / 8;      // 16-B chunks of a Vt tile
@@ -158,9 +161,10 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
       const int c = tid + i * ATT_THREADS;
       const int row = c >> 3;
       const int col = (c & 7) * 8;
-      uint2* d = reinterpret_cast<uint2*>(Vs + row * VSTR + col);   // rows are 8-B aligned (VSTR*2 = 136 B)
-      d[0] = make_uint2(vreg[i][0], vreg[i][1]);
-      d[1] = make_uint2(vreg[i][2], vreg[i][3]);
+      // keys col .. col+7 -> their fragment positions (see the header): [0-3] -> 0, [4-7] -> 8, [8-11] -> 4, [12-15] -> 12 of the 16-key group
+      bf16_t* d = Vs + row * VSTR + (col & ~15) + ((col & 8) >> 1);
+      *reinterpret_cast<uint2*>(d) = make_uint2(vreg[i][0], vreg[i][1]);
+      *reinterpret_cast<uint2*>(d + 8) = make_uint2(vreg[i][2], vreg[i][3]);
     }
   };
 
@@ -263,13 +267,11 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
       }
 #pragma unroll
       for (int t = 0; t < NDT; ++t) {
-        const bf16_t* vrow = Vs + (t * 32 + lq) * VSTR + 4 * hi;
+        const bf16_t* vrow = Vs + (t * 32 + lq) * VSTR + 8 * hi;
 #pragma unroll
         for (int h4 = 0; h4 < 4; ++h4) {
-          union { bf16x8 v; uint2 u[2]; } vf;
-          vf.u[0] = *reinterpret_cast<const uint2*>(vrow + 16 * h4);
-          vf.u[1] = *reinterpret_cast<const uint2*>(vrow + 16 * h4 + 8);
-          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pa[h4], oacc[t], 0, 0, 0);
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vrow + 16 * h4);
+          oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pa[h4], oacc[t], 0, 0, 0);
         }
       }
     }

@@ -17,6 +17,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def main():
@@ -25,7 +26,9 @@ def main():
   ap.add_argument("--infer-steps", type=int, default=2)
   ap.add_argument("--out", default=None)
   ap.add_argument("--top", type=int, default=60)
+  ap.add_argument("--all", action="store_true", help="keep the model-construction kernels (weight conversion, OPT, mapper) in the table")
   a = ap.parse_args()
+  from bench import SETUP_KERNELS
   rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
   d = tempfile.mkdtemp(prefix="gill_pmc_k_", dir=os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "/tmp")
   env = dict(os.environ, GILL_NO_GRAPH="1", TMPDIR="/tmp")
@@ -39,7 +42,7 @@ def main():
   for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     with open(f) as fh:
       for row in csv.DictReader(fh):
-        if row["Counter_Name"] != a.counter:
+        if row["Counter_Name"] != a.counter or (not a.all and (any(t in row["Kernel_Name"] for t in SETUP_KERNELS) or "at::native" in row["Kernel_Name"])):
           continue
         name = row["Kernel_Name"].split("(")[0].replace("void ", "")
         key = (name, row.get("Grid_Size", "?"), row.get("Workgroup_Size", "?"))
