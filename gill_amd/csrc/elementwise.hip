@@ -392,6 +392,23 @@ __global__ __launch_bounds__(256) void zero_bytes_kernel(uint4* dst, int64_t n16
 __global__ __launch_bounds__(256) void copy_bytes_kernel(uint4* dst, const uint4* src, int64_t n16) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
+// the CFG pair's shared prefix ends: a[n16 ..] := a[0 .. n16) and b2[0 .. n16) = b2[n16 ..] := b[0 .. n16) in one launch (unet.hip)
+__global__ __launch_bounds__(256) void dup_pair_kernel(uint4* a, const uint4* b, uint4* b2, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 va = a[i], vb = b[i];
+    a[i + n16] = va;
+    b2[i] = vb;
+    b2[i + n16] = vb;
+  }
+}
+int dup_pair_launch(void* a, const void* b, void* b2, size_t bytes, hipStream_t s) {
+  GILL_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)b2) & 15) == 0 && (bytes & 15) == 0, "dup_pair: 16-byte alignment required");
+  if (bytes == 0) return 0;
+  hipLaunchKernelGGL(dup_pair_kernel, dim3(grid_for((int64_t)(bytes / 16))), dim3(256), 0, s, (uint4*)a, (const uint4*)b, (uint4*)b2,
+                     (int64_t)(bytes / 16));
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 int zero_bytes_launch(void* dst, size_t bytes, hipStream_t s) {
   GILL_REQUIRE(((uintptr_t)dst & 15) == 0 && (bytes & 15) == 0, "zero_bytes: 16-byte alignment required");
   if (bytes == 0) return 0;

@@ -72,6 +72,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // Generic epilogue for 4 consecutive columns n..n+3 of row m (n % 4 == 0, n + 3 < N): used by the split-K reducer.
+// (Loading bias / row vector / residual up front, in flight with the partials, measured SLOWER: loop 518.3 -> 520.1 ms.)
 __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0, float v1, float v2, float v3,
                                        float* fin = nullptr) {
   float v[4] = {v0 * p.alpha, v1 * p.alpha, v2 * p.alpha, v3 * p.alpha};
@@ -209,7 +210,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
   const int tm = d.n_major ? tile % d.tiles_m : tile / d.groups_n;
   const int m0 = tm * BM;
   const int tn_first = gn * d.npw;
-  const int ntl = (d.tiles_n - tn_first < d.npw) ? d.tiles_n - tn_first : d.npw;   // N tiles of this workgroup
+  // (convolutions and split-K partials: one N tile per workgroup — gemm_launch_bn() — known at compile time, so that the K walk's
+  // state is dead by the epilogue instead of being carried around it for a next tile that never comes)
+  const int ntl = (CONV != 0 || EPI == 2) ? 1 : ((d.tiles_n - tn_first < d.npw) ? d.tiles_n - tn_first : d.npw);   // N tiles of this workgroup
   int n0 = tn_first * BN;
   const int z = blockIdx.y;
   const int kt_beg = z * d.ksteps_per_split;
@@ -465,6 +468,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
   }
   int buf = 0, buf_issue = STAGES - 1;
   int flat = 0;          // K steps consumed over all N tiles of this workgroup
+  // GEGLU / QKV GEMMs walk several N tiles per workgroup with a 2-deep ring: see DEFER in the main loop
+  constexpr bool DEFER = (CONV == 0 && STAGES == 2 && !PP && (EPI == 1 || EPI == 3));
+  int deferred_buf = -1;
   for (int t = 0; t < ntl; ++t, n0 += BN) {
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -582,7 +588,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
     };
     frag_load(0);
     // stage the next tile while the first fragments are in flight from LDS (its ~30 instructions cover that latency)
-    if (flat + STAGES - 1 < total_steps) issue(buf_issue);
+    // (DEFER: the first stage of the NEXT N tile is issued from this tile's epilogue instead, after the epilogue's own parameter
+    // loads — vmcnt returns in order, so loads issued behind a 1-KiB-per-lane-group DMA stage wait for the whole stage to land, and
+    // the compiler fences the epilogue's first load with vmcnt(0) anyway: 1-1.5 us per tile with nothing to do)
+    if (flat + STAGES - 1 < total_steps) {
+      if (DEFER && it == nsteps - 1) deferred_buf = buf_issue;
+      else issue(buf_issue);
+    }
     buf_issue = (buf_issue + 1 == STAGES) ? 0 : buf_issue + 1;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
@@ -653,10 +665,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
         sv[h] = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + pv + 4 * h) : make_float4(0, 0, 0, 0);
         sg[h] = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + pv + 16 + 4 * h) : make_float4(0, 0, 0, 0);
       }
+      // (no branch between these loads and their uses, one explicit wait the compiler's counter tracking sees, stores predicated:
+      // see the row-major epilogue)
+      __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
+      if (DEFER && qd == NT / 4 - 1 && deferred_buf >= 0) { issue(deferred_buf); deferred_buf = -1; }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int m = mrow + i * 16;
-        if (m >= p.M) continue;
         float o[8];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -667,7 +682,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
           o[4 * h + 3] = (av[3] * rr[i] - rm[i] * sv[h].w + bv[h].w) * gelu_erf(ag[3] * rr[i] - rm[i] * sg[h].w + bg[h].w);
         }
         uint4 ov; ov.x = pack_bf2(o[0], o[1]); ov.y = pack_bf2(o[2], o[3]); ov.z = pack_bf2(o[4], o[5]); ov.w = pack_bf2(o[6], o[7]);
-        *reinterpret_cast<uint4*>((bf16_t*)p.C + (size_t)m * p.ldc + no) = ov;
+        if (m < p.M) *reinterpret_cast<uint4*>((bf16_t*)p.C + (size_t)m * p.ldc + no) = ov;
       }
     }
   } else if constexpr (EPI == 3) {
@@ -686,6 +701,22 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       rv[i] = b * p.heads * p.dpv * p.ntok_pad_kv + t + p.kv_tok_offset;
     }
     const int hd = p.heads * p.dp;
+    // epilogue parameters of every column group first (then the deferred stage of the next N tile: see DEFER)
+    float4 bzs[NG][2], css[NG][2];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const bool pair = (2 * g + 1 < NT);
+      const int n = nbase + (pair ? g * 32 + fkc * 8 : (2 * g) * 16 + fkc * 4);
+      const bool hi = pair && (n + 4 < p.N);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bool ok = (n < p.N) && ((e == 0) || hi);
+        bzs[g][e] = (p.bias && ok) ? *reinterpret_cast<const float4*>(p.bias + n + 4 * e) : make_float4(0, 0, 0, 0);
+        css[g][e] = (p.ln_stats && ok) ? *reinterpret_cast<const float4*>(p.ln_colsum + n + 4 * e) : make_float4(0, 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): see the row-major epilogue
+    if (DEFER && deferred_buf >= 0) { issue(deferred_buf); deferred_buf = -1; }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const bool pair = (2 * g + 1 < NT);
@@ -697,13 +728,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       const int within = n - segl * hd;
       const int h = within / p.dp, dd = within - h * p.dp;
       const int seg = p.seg_base + segl;
-      float4 bz[2], cs[2];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const bool ok = (e == 0) || hi;
-        bz[e] = (p.bias && ok) ? *reinterpret_cast<const float4*>(p.bias + n + 4 * e) : make_float4(0, 0, 0, 0);
-        cs[e] = (p.ln_stats && ok) ? *reinterpret_cast<const float4*>(p.ln_colsum + n + 4 * e) : make_float4(0, 0, 0, 0);
-      }
+      const float4* bz = bzs[g]; const float4* cs = css[g];
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         if (!mok[i]) continue;
@@ -741,14 +766,19 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
   } else {
     // row-major epilogue; per-row offsets (incl. the batch index of the row vector) hoisted out of the column loop
     // (32-bit element offsets: gemm_launch() checks M * max(ldc, ldr) < 2^31)
-    int crow[MI], rrow[MI], vrow[MI]; bool mok[MI];
+    // The epilogue is written WITHOUT branches between its loads and their uses: all of a column group's loads (bias, row vector,
+    // residual, for every row) are issued back to back from addresses clamped into the tensors, then everything is computed, and only
+    // the stores are predicated.  With a `continue` per row the compiler has to re-fence every row's block with s_waitcnt vmcnt(0) —
+    // and on gfx9 that counter also holds the stores, so every row waited for the previous row's store round trip: 12 serialised
+    // round trips made the 256 x 160 conv tile's epilogue 4.1 us (tools/conv_ksweep.py with stamps), 3.4 us per GEGLU tile.
+    int crow[MI], rrow[MI]; bool mok[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = mrow + i * 16;
       mok[i] = m < p.M;
-      crow[i] = out_row(m) * p.ldc;
-      rrow[i] = m * p.ldr;
-      vrow[i] = p.rowvec ? (m / p.rows_per_batch) * p.rowvec_bstride : 0;
+      const int mc = mok[i] ? m : p.M - 1;
+      crow[i] = out_row(mc) * p.ldc;
+      rrow[i] = mc * p.ldr;
     }
     // fused GroupNorm statistics of the OUTPUT tensor (consumed by the next GroupNorm: saves its whole stats pass).
     // The 64 rows of a wave belong to one slab of one sample (rows_per_batch % 64 == 0).  Fixed-order reduction: 4 rows in the
@@ -759,79 +789,142 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
     float2* red_lane = red + wm * BN + wn * (BN / 2);
     if (p.gn_stats) __syncthreads();                 // every wave is done reading the ring
     float rws[4] = {0.f, 0.f, 0.f, 0.f}, rwq[4] = {0.f, 0.f, 0.f, 0.f};   // row sums for a following (folded) LayerNorm
+    constexpr bool F32_PATHS = (CONV == 0 && EPI != 4);     // fp32 residual / fp32 output / activation: plain GEMMs on EPI 0 only
+    // phase A: the loads.  Column vector cv = bias (+ the row vector, a per-sample bias — ResnetBlock2D's time embedding — which is the
+    // same for all rows of the wave when they lie in one sample: the case in the engines); a wave that straddles samples, and the
+    // fp32 residual (32 B per lane and row), take the slow path: loads inside the row loop.
+    // The bf16-only kernels (convs, EPI 4) issue the loads of all NG column groups up front (at most 24 + 48 registers next to the
+    // 80 accumulators) and wait once: one round trip per tile, and no load ever queues behind a store.  The generic EPI 0 kernel, which
+    // also carries the fp32 / activation paths, goes group by group (loads, wait, compute, store: NG round trips).
+    constexpr bool ALL_UPFRONT = !F32_PATHS;
+    constexpr int NSLOT = ALL_UPFRONT ? NG : 1;
+    const int wrow0 = m0 + wm * (MI * 16);
+    const int wrow1 = (wrow0 + MI * 16 - 1 < p.M) ? wrow0 + MI * 16 - 1 : p.M - 1;
+    const bool rv_pre = p.rowvec && wrow0 < p.M && (wrow0 / p.rows_per_batch == wrow1 / p.rows_per_batch);   // wave-uniform
+    const bool rv_slow = p.rowvec && !rv_pre;
+    const bool rf_slow = F32_PATHS && p.resid && p.resid_f32;
+    const bool rb_pre = p.resid && !rf_slow;
+    const float* colvec = rv_pre ? p.rowvec + (wrow0 / p.rows_per_batch) * p.rowvec_bstride : p.bias;    // first (or only) column vector
+    const float* colvec2 = rv_pre ? p.bias : nullptr;                                                      // bias on top of a row vector
+    float4 cv[NSLOT][2];
+    uint2 rb[NSLOT][MI][2];
+    auto load_group = [&](int g, int sl) {
+      const bool pair = (2 * g + 1 < NT);
+      const int n = nbase + (pair ? g * 32 + fkc * 8 : (2 * g) * 16 + fkc * 4);
+      const bool hi = pair && (n + 4 < p.N);
+      const int nl = (n < p.N) ? n : 0;      // columns the loads use: always inside the row (lanes beyond N are never stored)
+      const int nh = hi ? n + 4 : nl;
+      cv[sl][0] = cv[sl][1] = make_float4(0, 0, 0, 0);
+      if (colvec) {
+        cv[sl][0] = *reinterpret_cast<const float4*>(colvec + nl);
+        cv[sl][1] = *reinterpret_cast<const float4*>(colvec + nh);
+      }
+      if (colvec2) {
+        const float4 t0 = *reinterpret_cast<const float4*>(colvec2 + nl);
+        const float4 t1 = *reinterpret_cast<const float4*>(colvec2 + nh);
+        cv[sl][0].x += t0.x; cv[sl][0].y += t0.y; cv[sl][0].z += t0.z; cv[sl][0].w += t0.w;
+        cv[sl][1].x += t1.x; cv[sl][1].y += t1.y; cv[sl][1].z += t1.z; cv[sl][1].w += t1.w;
+      }
+    };
+    auto load_group_resid = [&](int g, int sl) {
+      const bool pair = (2 * g + 1 < NT);
+      const int n = nbase + (pair ? g * 32 + fkc * 8 : (2 * g) * 16 + fkc * 4);
+      const bool hi = pair && (n + 4 < p.N);
+      const int nl = (n < p.N) ? n : 0;
+      const int nh = hi ? n + 4 : nl;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        rb[sl][i][0] = *reinterpret_cast<const uint2*>((const bf16_t*)p.resid + rrow[i] + nl);
+        rb[sl][i][1] = *reinterpret_cast<const uint2*>((const bf16_t*)p.resid + rrow[i] + nh);
+      }
+    };
+    if constexpr (ALL_UPFRONT) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) load_group(g, g);
+      if (rb_pre) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) load_group_resid(g, g);
+      }
+      // phase B: an explicit s_waitcnt, which the compiler's own counter tracking sees — nothing is pending behind it, so the
+      // predicated stores below (branches, i.e. control-flow joins) cannot draw conservative vmcnt(0) fences
+      __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
+    }
+    // phase C: compute and store
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
+      const int sl = ALL_UPFRONT ? g : 0;
+      const int rs = sl;
+      if constexpr (!ALL_UPFRONT) {
+        load_group(g, 0);
+        if (rb_pre) load_group_resid(g, 0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+      }
       const bool pair = (2 * g + 1 < NT);
       const int j1 = pair ? 2 * g + 1 : 2 * g;
       const int cl = pair ? g * 32 + fkc * 8 : (2 * g) * 16 + fkc * 4;    // first column of the group within the wave's half
       const int n = nbase + cl;
-      if (n >= p.N) continue;
+      const bool nok = n < p.N;
       const bool hi = pair && (n + 4 < p.N);
-      float4 bz[2];
-      bz[0] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
-      bz[1] = (p.bias && hi) ? *reinterpret_cast<const float4*>(p.bias + n + 4) : make_float4(0, 0, 0, 0);
       float gs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        if (!mok[i]) continue;
         const f32x4 a0 = acc[i][2 * g], a1 = acc[i][j1];
-        float v[8] = {a0[0] * p.alpha + bz[0].x, a0[1] * p.alpha + bz[0].y, a0[2] * p.alpha + bz[0].z, a0[3] * p.alpha + bz[0].w,
-                      a1[0] * p.alpha + bz[1].x, a1[1] * p.alpha + bz[1].y, a1[2] * p.alpha + bz[1].z, a1[3] * p.alpha + bz[1].w};
-        if (p.rowvec) {
-          const float4 b0 = *reinterpret_cast<const float4*>(p.rowvec + vrow[i] + n);
+        float v[8] = {a0[0] * p.alpha + cv[sl][0].x, a0[1] * p.alpha + cv[sl][0].y, a0[2] * p.alpha + cv[sl][0].z, a0[3] * p.alpha + cv[sl][0].w,
+                      a1[0] * p.alpha + cv[sl][1].x, a1[1] * p.alpha + cv[sl][1].y, a1[2] * p.alpha + cv[sl][1].z, a1[3] * p.alpha + cv[sl][1].w};
+        // (slow paths: guarded by wave-uniform flags ONLY and loading from clamped columns, so that they compile to scalar branches —
+        // under a lane predicate a never-taken load still executes its s_waitcnt vmcnt(0), which queues behind the previous row's store)
+        if (rv_slow) {
+          const int vr = (min(mrow + i * 16, p.M - 1) / p.rows_per_batch) * p.rowvec_bstride;
+          const int nl = nok ? n : 0, nh = hi ? n + 4 : nl;
+          const float4 b0 = *reinterpret_cast<const float4*>(p.rowvec + vr + nl);
+          const float4 b1 = *reinterpret_cast<const float4*>(p.rowvec + vr + nh);
           v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-          if (hi) {
-            const float4 b1 = *reinterpret_cast<const float4*>(p.rowvec + vrow[i] + n + 4);
-            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-          }
+          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         }
-        if (p.resid) {
-          if (CONV == 0 && EPI != 4 && p.resid_f32) {
-            const float4 r0 = *reinterpret_cast<const float4*>((const float*)p.resid + rrow[i] + n);
-            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-            if (hi) {
-              const float4 r1 = *reinterpret_cast<const float4*>((const float*)p.resid + rrow[i] + n + 4);
-              v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-            }
-          } else if (hi) {
-            const uint4 r = *reinterpret_cast<const uint4*>((const bf16_t*)p.resid + rrow[i] + n);
-            v[0] += bf2f((bf16_t)(r.x & 0xffff)); v[1] += bf2f((bf16_t)(r.x >> 16));
-            v[2] += bf2f((bf16_t)(r.y & 0xffff)); v[3] += bf2f((bf16_t)(r.y >> 16));
-            v[4] += bf2f((bf16_t)(r.z & 0xffff)); v[5] += bf2f((bf16_t)(r.z >> 16));
-            v[6] += bf2f((bf16_t)(r.w & 0xffff)); v[7] += bf2f((bf16_t)(r.w >> 16));
-          } else {
-            const uint2 r = *reinterpret_cast<const uint2*>((const bf16_t*)p.resid + rrow[i] + n);
-            v[0] += bf2f((bf16_t)(r.x & 0xffff)); v[1] += bf2f((bf16_t)(r.x >> 16));
-            v[2] += bf2f((bf16_t)(r.y & 0xffff)); v[3] += bf2f((bf16_t)(r.y >> 16));
-          }
+        if (rb_pre) {
+          v[0] += bf2f((bf16_t)(rb[rs][i][0].x & 0xffff)); v[1] += bf2f((bf16_t)(rb[rs][i][0].x >> 16));
+          v[2] += bf2f((bf16_t)(rb[rs][i][0].y & 0xffff)); v[3] += bf2f((bf16_t)(rb[rs][i][0].y >> 16));
+          v[4] += bf2f((bf16_t)(rb[rs][i][1].x & 0xffff)); v[5] += bf2f((bf16_t)(rb[rs][i][1].x >> 16));
+          v[6] += bf2f((bf16_t)(rb[rs][i][1].y & 0xffff)); v[7] += bf2f((bf16_t)(rb[rs][i][1].y >> 16));
+        }
+        if (F32_PATHS && rf_slow) {
+          const int nl = nok ? n : 0, nh = hi ? n + 4 : nl;
+          const float4 r0 = *reinterpret_cast<const float4*>((const float*)p.resid + rrow[i] + nl);
+          const float4 r1 = *reinterpret_cast<const float4*>((const float*)p.resid + rrow[i] + nh);
+          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+          v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
         }
         // (convolutions: no activation, bf16 output, no LayerNorm row sums — gemm_launch() checks — so their kernels carry none of it)
-        if (CONV == 0 && EPI != 4 && p.act != ACT_NONE) {
+        if (F32_PATHS && p.act != ACT_NONE) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
         }
-        if (CONV == 0 && EPI != 4 && p.out_mode == OUT_F32) {
-          *reinterpret_cast<float4*>((float*)p.C + crow[i] + n) = make_float4(v[0], v[1], v[2], v[3]);
-          if (hi) *reinterpret_cast<float4*>((float*)p.C + crow[i] + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        const bool st = mok[i] && nok;
+        if (F32_PATHS && p.out_mode == OUT_F32) {
+          if (st) *reinterpret_cast<float4*>((float*)p.C + crow[i] + n) = make_float4(v[0], v[1], v[2], v[3]);
+          if (st && hi) *reinterpret_cast<float4*>((float*)p.C + crow[i] + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
           uint4 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
-          if (hi) *reinterpret_cast<uint4*>((bf16_t*)p.C + crow[i] + n) = o;
-          else *reinterpret_cast<uint2*>((bf16_t*)p.C + crow[i] + n) = make_uint2(o.x, o.y);
-          if (CONV == 0 && p.row_stats) {   // statistics of what the consumer will read: the rounded values
+          if (st && hi) *reinterpret_cast<uint4*>((bf16_t*)p.C + crow[i] + n) = o;
+          else if (st) *reinterpret_cast<uint2*>((bf16_t*)p.C + crow[i] + n) = make_uint2(o.x, o.y);
+          if (CONV == 0 && p.row_stats) {   // statistics of what the consumer will read: the rounded values (columns beyond N: none)
             const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
             const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
-            rws[i] += (r0 + r1) + (r2 + r3);
-            rwq[i] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
-            if (hi) {
-              const float r4 = __uint_as_float(o.z << 16), r5 = __uint_as_float(o.z & 0xffff0000u);
-              const float r6 = __uint_as_float(o.w << 16), r7 = __uint_as_float(o.w & 0xffff0000u);
-              rws[i] += (r4 + r5) + (r6 + r7);
-              rwq[i] += (r4 * r4 + r5 * r5) + (r6 * r6 + r7 * r7);
-            }
+            const float r4 = __uint_as_float(o.z << 16), r5 = __uint_as_float(o.z & 0xffff0000u);
+            const float r6 = __uint_as_float(o.w << 16), r7 = __uint_as_float(o.w & 0xffff0000u);
+            const float slo = (r0 + r1) + (r2 + r3), qlo = (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+            const float shi = (r4 + r5) + (r6 + r7), qhi = (r4 * r4 + r5 * r5) + (r6 * r6 + r7 * r7);
+            rws[i] += nok ? slo : 0.f;
+            rwq[i] += nok ? qlo : 0.f;
+            rws[i] += hi ? shi : 0.f;      // (two separate additions, low half first: the order the sums have always been formed in)
+            rwq[i] += hi ? qhi : 0.f;
           }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
+        for (int e = 0; e < 8; ++e) {       // (rows beyond M hold the clamped row's values: they must not reach the statistics)
+          const float ve = mok[i] ? v[e] : 0.f;
+          gs[e] += ve; gq[e] += ve * ve;
+        }
       }
       if (p.gn_stats) {
 #pragma unroll

@@ -210,6 +210,7 @@ struct SdLoopArgs {
 // memcpy graph nodes, whose replay was not reliable (profiles/r02_soak_bisect.md).  16-byte aligned pointers and sizes.
 int zero_bytes_launch(void* dst, size_t bytes, hipStream_t s);
 int copy_bytes_launch(void* dst, const void* src, size_t bytes, hipStream_t s);
+int dup_pair_launch(void* a, const void* b, void* b2, size_t bytes, hipStream_t s);   // a[bytes..] := a[0..bytes); b2[0..bytes) = b2[bytes..] := b[0..bytes)
 // first kernel of a step: latents -> UNet input (both CFG halves), time-embedding row of the current step -> temb_cur
 int sd_stage_launch(const SdLoopArgs& a, hipStream_t s);
 // last kernel of a step: CFG combine + PLMS update of the latents (custom_sd.py:641-646), then step counter + 1

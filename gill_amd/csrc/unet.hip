@@ -766,10 +766,8 @@ struct UNetRun {
     GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M1, w.out1.w, w.out1.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, &st2));
     if (shared && !dry) {
       // second half of the pair := first half (residual stream, its LayerNorm row sums, the block input)
-      GILL_TRY(copy_bytes_launch(t.p + (size_t)M1 * C, t.p, sizeof(bf16_t) * (size_t)M1 * C, s));
       // (out1 ran on M1 rows: its row-sum planes are [planes][M1][2]; the consumer below wraps rows >= M1 onto them)
-      GILL_TRY(copy_bytes_launch(xd.p, x.p, sizeof(bf16_t) * (size_t)M1 * C, s));
-      GILL_TRY(copy_bytes_launch(xd.p + (size_t)M1 * C, x.p, sizeof(bf16_t) * (size_t)M1 * C, s));
+      GILL_TRY(dup_pair_launch(t.p, x.p, xd.p, sizeof(bf16_t) * (size_t)M1 * C, s));
     }
     // --- cross attention (K/V cached per prompt)
     {
