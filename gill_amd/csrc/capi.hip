@@ -62,7 +62,7 @@ extern "C" int gill_op_geglu(const void* A, const void* W, const float* bias, vo
   g.bias = bias ? (const float*)bperm.p : nullptr;
   g.act = ACT_GEGLU; g.out_mode = OUT_BF16;
   g.C = C; g.ldc = inner;
-  GILL_TRY(gemm_launch(g, s));
+  for (int r = 0; r < op_repeat(); ++r) GILL_TRY(gemm_launch(g, s));
   GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
 }
