@@ -215,6 +215,29 @@ def test_conv3x3_pingpong_short_k_and_bit_identity(cuda):
   assert digests[0] == digests[1], digests
 
 
+def test_upsample_conv_switch_both_forms_in_the_unet(cuda):
+  """GILL_CONV_UPS4 (read once per process): a tiny UNet forward with the upsamplers in the four-tap form and with the 9-tap gather, in two
+  subprocesses on the same seeded weights — the two must agree to bf16 rounding of the summed weights (and both have their oracle tests)."""
+  import os, subprocess, sys
+  code = ("import torch, sys; sys.path.insert(0, %r); from gill_amd import synth; from gill_amd.sd import GillSDPipeline\n"
+          "cfg = synth.UNetConfig.tiny(16)\n"
+          "sd = {k: v.bfloat16() for k, v in synth.unet_state_dict(cfg, seed=91).items()}\n"
+          "pipe = GillSDPipeline(sd, cfg, synth.uncond_context(cfg.ctx_len, cfg.cross_attention_dim, seed=91), 'cuda:0', max_batch=2)\n"
+          "x = synth.normal('u4_x', (2, 4, 16, 16), 92); ctx = synth.normal('u4_c', (2, cfg.ctx_len, cfg.cross_attention_dim), 93)\n"
+          "y = pipe.unet(x, torch.tensor([801.0, 21.0]), ctx).float().cpu()\n"
+          "torch.save(y, sys.argv[1])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  import tempfile
+  outs = []
+  with tempfile.TemporaryDirectory() as d:
+    for sw in ("0", "1"):
+      f = os.path.join(d, f"y{sw}.pt")
+      r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, GILL_CONV_UPS4=sw), capture_output=True, text=True, timeout=600)
+      assert r.returncode == 0, r.stderr[-2000:]
+      outs.append(torch.load(f))
+  assert torch.isfinite(outs[0]).all() and not torch.equal(outs[0], outs[1])       # (the switch did switch: different roundings)
+  assert _report("tiny UNet forward: 9-tap gather vs four-tap upsamplers", outs[1], outs[0]) < 2e-2
+
+
 # ---------------------------------------------------------------- attention
 def _attn_ref(q, k, v, H, scale, causal):
   B, nq, hd = q.shape

@@ -5,7 +5,7 @@ tag=$1; shift
 out=$PWD/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/prof -o bench --output-format rocpd -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc "$@" > $out/bench_under_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/prof -o bench --output-format rocpd -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-scale-origin "$@" > $out/bench_under_prof.log 2>&1
 cd $OLDPWD
 db=$(find $out/prof -name "*.db" | head -1)
 python tools/rocpd_summary.py $db $out/kernel_stats.md --per-shape > /dev/null
