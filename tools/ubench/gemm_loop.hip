@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 typedef unsigned short bf16_t;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256, OCC) void k_gemm(const bf16_t* __restrict__ A,
           for (int i = 0; i < 4; ++i) a_ptr[i] -= KW; }
       }
       if (++patch_step == 9) patch_step = 0;
-    } else {
+    } else if (LOADS != 3) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[i],
@@ -96,20 +97,41 @@ __global__ __launch_bounds__(256, OCC) void k_gemm(const bf16_t* __restrict__ A,
     bf16x8 af[4], bfr[5];
     for (int i = 0; i < 4; ++i) af[i] = (bf16x8)(short)(0x3c00 + lane);
     for (int j = 0; j < 5; ++j) bfr[j] = (bf16x8)(short)(0x3c10 + lane);
+    // LOADS == 3: the A fragments come straight from global memory into registers (the MFMA fragment layout IS a 16-B-per-lane
+    // row-major read), one K step ahead; only W goes through LDS-DMA
+    bf16x8 aq[2][2][4];
+    const bf16_t* arow[4];
+    for (int i = 0; i < 4; ++i) arow[i] = A + (size_t)(m0 + wm * 64 + i * 16 + frow) * KW + fkc * 8;
+    auto load_a = [&](int step, int slot) {
+      const int kc = (step * BK) % KW;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aq[slot][kk][i] = *reinterpret_cast<const bf16x8*>(arow[i] + kc + kk * 32);
+    };
     issue(0);
+    if (LOADS == 3) load_a(0, 0);
     int buf = 0;
-    for (int it = 0; it < nsteps; ++it) {
+    auto body = [&](int it, auto slot_tag) {
+      constexpr int SLOT = decltype(slot_tag)::value;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (BARR) __builtin_amdgcn_s_barrier();
       const bf16_t* As = LOADS == 2 ? smem + 2 * B_ELEMS + ((it % 9) / 3) * 66 * BK + ((it % 9) % 3) * BK : smem + buf * BUF;
       const bf16_t* Bs = LOADS == 2 ? smem + buf * B_ELEMS : As + A_ELEMS;
+      if (LOADS == 3 && it + 1 < nsteps) load_a(it + 1, SLOT ^ 1);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        if (LDSR) {
+        if (LOADS == 3) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int row = wm * 64 + i * 16 + frow;
-            af[i] = *reinterpret_cast<const bf16x8*>(As + row * BK + (((kk * 4 + fkc) ^ (row & 7)) * 8));
+          for (int i = 0; i < 4; ++i) af[i] = aq[SLOT][kk][i];
+        }
+        if (LDSR) {
+          if (LOADS != 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int row = wm * 64 + i * 16 + frow;
+              af[i] = *reinterpret_cast<const bf16x8*>(As + row * BK + (((kk * 4 + fkc) ^ (row & 7)) * 8));
+            }
           }
 #pragma unroll
           for (int j = 0; j < 5; ++j) {
@@ -124,6 +146,10 @@ __global__ __launch_bounds__(256, OCC) void k_gemm(const bf16_t* __restrict__ A,
           for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
       buf ^= 1;
+    };
+    for (int it = 0; it < nsteps; it += 2) {
+      body(it, std::integral_constant<int, 0>{});
+      if (it + 1 < nsteps) body(it + 1, std::integral_constant<int, 1>{});
     }
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) result += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
   } else {
@@ -854,6 +880,7 @@ int main(int argc, char** argv) {
   }
   printf("M=%d N=%d K=%d, %d tiles\n", M, N, K, (M / BM) * (N / BN));
   run<0, 1, 1, 1, 2>(A, W, C, M, N, K, "16x16x32 full");
+  run<0, 3, 1, 1, 2>(A, W, C, M, N, K, "16x16x32 A fragments direct to registers, W via LDS-DMA");
   run<0, 2, 1, 1, 2>(A, W, C, M, N, K, "16x16x32 A patch once per 9 steps");
   run<0, 0, 1, 1, 2>(A, W, C, M, N, K, "16x16x32 no global loads");
   run<0, 0, 1, 0, 2>(A, W, C, M, N, K, "16x16x32 no loads, no barrier");
