@@ -39,7 +39,8 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 __device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
-__device__ __forceinline__ float gelu_f(float x) {      // erf by Abramowitz-Stegun 7.1.26 (the engine's form)
+__device__ __forceinline__ float gelu_f(float x) {
+#ifdef GELU_EXACT_FORM      // erf by Abramowitz-Stegun 7.1.26 (the engine's form): 14 VALU + exp + rcp
   const float z = x * 0.70710678118654752f, a = fabsf(z);
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
   float p = fmaf(1.061405429f, t, -1.453152027f);
@@ -47,6 +48,13 @@ __device__ __forceinline__ float gelu_f(float x) {      // erf by Abramowitz-Ste
   const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * a * a);
   const float r = copysignf(fmaf(-p * t, e, 1.0f), z);
   return 0.5f * x * (1.0f + r);
+#else                       // x * Phi(x), Phi as a logistic of an odd quintic (|error| <= 2.7e-5): 8 VALU + exp + rcp
+  const float xc = __builtin_amdgcn_fmed3f(x, -7.0f, 7.0f);
+  const float x2 = xc * xc;
+  float p = fmaf(0.0010187963489443064f, x2, -0.10680364072322845f);
+  p = fmaf(p, x2, -2.301090717315674f);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(p * xc));
+#endif
 }
 
 template <int N> __device__ __forceinline__ void wait_vm_imm() {
@@ -68,6 +76,7 @@ __device__ __forceinline__ void wait_vm(int n) {
 // (row half u, k slab j) of Wp.
 struct Stage { const bf16_t* src; int ld; int rows; };   // slab = rows x 64 k starting at src, row stride ld
 
+__device__ long long g_stamp[8];
 template <bool DO_GELU, int ABL>      // ABL: 0 full, 1 no MFMA work (DMA + waits + barriers only), 2 no LDS-DMA (MFMAs on stale LDS)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void ffn_fused_kernel(const bf16_t* __restrict__ T, const bf16_t* __restrict__ W1c, const bf16_t* __restrict__ W2p,
@@ -135,30 +144,40 @@ void ffn_fused_kernel(const bf16_t* __restrict__ T, const bf16_t* __restrict__ W
   // the compiler then places exact lgkmcnt waits per fragment, and sched_group_barrier can interleave the step's LDS reads, its LDS-DMA
   // piece and their address arithmetic INTO the gaps between its MFMAs (one wave per SIMD: whatever is not issued between two MFMAs
   // runs with the matrix pipe idle).
-  auto run_stage = [&](auto ntile_tag, auto wait_tag, auto nxp_tag, int slot_idx, const Stage& nx, int nx_slot, auto&& mma) {
+  // The fragment prefetch runs ACROSS the stage boundary: the counted wait + barrier for stage g+1 sit in front of step 3 of stage g, whose
+  // MFMAs then cover the first reads of stage g+1 (NTN = its tiles; WAITN = pieces behind stage g+1 at that point: those of stages
+  // g+2..g+5 plus the three of stage g+6 already issued).  The fragments of step 0 are in wf[0] when a stage starts.
+  bf16x8 wf[2][5];
+  auto run_stage = [&](auto ntile_tag, auto ntile_next_tag, auto wait_tag, auto nxp_tag, int slot_idx, int next_slot_idx,
+                       const Stage& nx, int nx_slot, auto&& mma) {
     constexpr int NTL = decltype(ntile_tag)::value;        // 4 (S1: 128 rows) | 5 (S2 / final: 160 rows)
+    constexpr int NTN = decltype(ntile_next_tag)::value;   // tiles of the next stage (0: this is the last stage)
     constexpr int WAITN = decltype(wait_tag)::value;
     constexpr int NXP = decltype(nxp_tag)::value;
-    if (ABL != 2) wait_vm_imm<WAITN>();
-    __builtin_amdgcn_s_barrier();
     const unsigned char* slot = smem + slot_idx * SLOT_BYTES;
-    bf16x8 wf[2][NTL];
-#pragma unroll
-    for (int q = 0; q < NTL; ++q) wf[0][q] = wfrag(slot, q, 0);
+    const unsigned char* nslot = smem + next_slot_idx * SLOT_BYTES;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       __builtin_amdgcn_sched_barrier(0);      // a step is one scheduling region: its groups pair MFMAs of step s with reads of step s + 1
+      if (s == 3 && NTN > 0) {
+        if (ABL != 2) wait_vm_imm<WAITN>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      constexpr int NRD = 5;
       if (s + 1 < 4) {
 #pragma unroll
         for (int q = 0; q < NTL; ++q) wf[(s + 1) & 1][q] = wfrag(slot, q, s + 1);
+      } else if (NTN > 0) {
+#pragma unroll
+        for (int q = 0; q < NTN; ++q) wf[0][q] = wfrag(nslot, q, 0);
       }
       if (NXP > 0) { issue_piece(nx, nx_slot, s); if (s == 3 && NXP == 5) issue_piece(nx, nx_slot, 4); }
       if (ABL != 1) mma(s, wf[s & 1]);
-      // interleave: MFMA, one LDS read, a little address arithmetic; the LDS-DMA piece after the second MFMA
 #pragma unroll
       for (int q = 0; q < NTL; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // 1 MFMA
-        if (s + 1 < 4 && q == 0) __builtin_amdgcn_sched_group_barrier(0x100, NTL, 0);   // ALL of the next step's reads behind the first MFMA
+        if (q == 0 && (s + 1 < 4 || NTN > 0)) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);   // the next step's reads behind the first MFMA
         __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                      // up to 3 VALU / SALU
         if (q == 2 && NXP > 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                 // VMEM read (the LDS-DMA piece)
         if (q == 3 && NXP == 5 && s == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // (the fifth piece)
@@ -167,28 +186,36 @@ void ffn_fused_kernel(const bf16_t* __restrict__ T, const bf16_t* __restrict__ W
   };
   using I0 = std::integral_constant<int, 0>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
 
+  // prologue of the stream: stage 0 has landed (the full wait above); barrier; its first fragments
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wf[0][q] = wfrag(smem, q, 0);
+
   // one chunk; LAST (compile-time): the stages six ahead are the final segment's
   auto run_chunk = [&](int c, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
+    const bool stamp = (c == 10 && blockIdx.x == 7 && tid == 0);
+    if (stamp) g_stamp[0] = clock64();
     f32x16 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    // ---- S1: [value | gate] chunk = W1 chunk . t   (pieces of the five stages behind positions 0..6: 21 22 22 22 22 21 20; in the
-    // last chunk the stages behind are 5-piece final stages: the same immediates then wait for at most two pieces too many)
+    // ---- S1: [value | gate] chunk = W1 chunk . t.  WAITN by position 0..6: 20 21 21 21 20 19 19 (in the last chunk the stages behind are
+    // 5-piece final stages: the same immediates then wait for a few pieces too many)
 #define S1_STAGE(J, N)                                                                                                          \
     {                                                                                                                            \
-      auto mma = [&](int s, const bf16x8* wf) {                                                                                  \
+      auto mma = [&](int s, const bf16x8* wfp) {                                                                                 \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                        \
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], tf[4 * (J) + s], acc[nt], 0, 0, 0);                          \
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfp[nt], tf[4 * (J) + s], acc[nt], 0, 0, 0);                         \
       };                                                                                                                         \
       const Stage nx = (J) == 0 ? slab(c, 6) : (LAST ? slab(0, 7 + (J) - 1) : slab(c + 1, (J) - 1));                             \
-      run_stage(I4{}, std::integral_constant<int, N>{}, std::integral_constant<int, ((J) == 0 || LAST) ? 5 : 4>{}, (J), nx,      \
-                (J) == 0 ? 6 : (J) - 1, mma);                                                                                    \
+      run_stage(I4{}, std::integral_constant<int, (J) == 4 ? 5 : 4>{}, std::integral_constant<int, N>{},                         \
+                std::integral_constant<int, ((J) == 0 || LAST) ? 5 : 4>{}, (J), (J) + 1, nx, (J) == 0 ? 6 : (J) - 1, mma);       \
     }
-    S1_STAGE(0, 21) S1_STAGE(1, 22) S1_STAGE(2, 22) S1_STAGE(3, 22) S1_STAGE(4, 22)
+    S1_STAGE(0, 20) S1_STAGE(1, 21) S1_STAGE(2, 21) S1_STAGE(3, 21) S1_STAGE(4, 20)
 #undef S1_STAGE
+    if (stamp) g_stamp[1] = clock64();
     // ---- GEGLU in registers: tiles 0, 1 = value of hidden tiles 0, 1; tiles 2, 3 = their gates
     bf16x8 pf[4];          // B fragments of the 4 k16 steps (tt, hh) of S2
 #pragma unroll
@@ -205,35 +232,37 @@ void ffn_fused_kernel(const bf16_t* __restrict__ T, const bf16_t* __restrict__ W
         }
         pf[2 * tt + hh] = pk.v;
       }
+    if (stamp) g_stamp[2] = clock64();
     // ---- S2: out += W2p chunk . p
 #define S2_STAGE(U, N)                                                                                                          \
     {                                                                                                                            \
-      auto mma = [&](int s, const bf16x8* wf) {                                                                                  \
+      auto mma = [&](int s, const bf16x8* wfp) {                                                                                 \
         _Pragma("unroll") for (int q = 0; q < 5; ++q)                                                                           \
-          out[5 * (U) + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q], pf[s], out[5 * (U) + q], 0, 0, 0);                   \
+          out[5 * (U) + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfp[q], pf[s], out[5 * (U) + q], 0, 0, 0);                  \
       };                                                                                                                         \
       const Stage nx = LAST ? slab(0, 7 + 4 + (U)) : slab(c + 1, 4 + (U));                                                       \
-      run_stage(I5{}, std::integral_constant<int, N>{}, std::integral_constant<int, (LAST || (U) == 1) ? 5 : 4>{}, 5 + (U), nx,  \
-                4 + (U), mma);                                                                                                   \
+      run_stage(I5{}, std::integral_constant<int, ((U) == 0 || LAST) ? 5 : 4>{}, std::integral_constant<int, N>{},               \
+                std::integral_constant<int, (LAST || (U) == 1) ? 5 : 4>{}, 5 + (U), (U) == 0 ? 6 : 0, nx, 4 + (U), mma);         \
     }
-    S2_STAGE(0, 21) S2_STAGE(1, 20)
+    S2_STAGE(0, 19) S2_STAGE(1, 19)
 #undef S2_STAGE
+    if (stamp) g_stamp[3] = clock64();
   };
   for (int c = 0; c + 1 < NCH; ++c) run_chunk(c, std::false_type{});
   run_chunk(NCH - 1, std::true_type{});
-  // ---- final segment: out += Wp . t   (stage 140 + f sits in slot f mod 7; pieces behind it: 25, 25, 25, 25, 25, 20, 15, 10, 5, 0)
+  // ---- final segment: out += Wp . t   (stage 140 + f sits in slot f mod 7; WAITN for f = 0..8: 23 23 23 23 20 15 10 5 0)
 #define F_STAGE(F, N)                                                                                                            \
   {                                                                                                                              \
-    auto mma = [&](int s, const bf16x8* wf) {                                                                                    \
+    auto mma = [&](int s, const bf16x8* wfp) {                                                                                   \
       _Pragma("unroll") for (int q = 0; q < 5; ++q)                                                                             \
-        out[5 * ((F) / 5) + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q], tf[4 * ((F) % 5) + s], out[5 * ((F) / 5) + q], 0, 0, 0); \
+        out[5 * ((F) / 5) + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfp[q], tf[4 * ((F) % 5) + s], out[5 * ((F) / 5) + q], 0, 0, 0); \
     };                                                                                                                           \
     const Stage nx = slab(0, 7 + ((F) + 6 < 10 ? (F) + 6 : 0));                                                                  \
-    run_stage(I5{}, std::integral_constant<int, N>{}, std::integral_constant<int, ((F) + 6 < 10) ? 5 : 0>{}, (F) % 7, nx,        \
-              ((F) + 6) % 7, mma);                                                                                               \
+    run_stage(I5{}, std::integral_constant<int, (F) + 1 < 10 ? 5 : 0>{}, std::integral_constant<int, N>{},                       \
+              std::integral_constant<int, ((F) + 6 < 10) ? 5 : 0>{}, (F) % 7, ((F) + 1) % 7, nx, ((F) + 6) % 7, mma);            \
   }
-  F_STAGE(0, 25) F_STAGE(1, 25) F_STAGE(2, 25) F_STAGE(3, 25) F_STAGE(4, 25)
-  F_STAGE(5, 20) F_STAGE(6, 15) F_STAGE(7, 10) F_STAGE(8, 5) F_STAGE(9, 0)
+  F_STAGE(0, 23) F_STAGE(1, 23) F_STAGE(2, 23) F_STAGE(3, 23) F_STAGE(4, 20)
+  F_STAGE(5, 15) F_STAGE(6, 10) F_STAGE(7, 5) F_STAGE(8, 0) F_STAGE(9, 0)
 #undef F_STAGE
   // ---- store: lane (m, hi) holds n = tile * 32 + (r & 3) + 8 (r >> 2) + 4 hi
   if (m < M) {
@@ -319,6 +348,7 @@ int main() {
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / Rn;
+    { long long st[8]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamp), sizeof(st)); printf("   chunk 10 of block 7, wave 0 (s_memtime ticks): S1 5 stages %lld, GEGLU %lld, S2 2 stages %lld\n", st[1] - st[0], st[2] - st[1], st[3] - st[2]); }
     printf("fused FFN (C 320, hidden 1280, M %d, %s): %7.1f us per launch, %6.0f TFLOP/s; rel-L2 vs naive (256 rows) %.3e\n", M,
            variant == 0 ? "GEGLU" : variant == 1 ? "no GELU (value + gate)" : variant == 2 ? "ABLATION: no MFMAs" : "ABLATION: no LDS-DMA", us, flop / us / 1e6, sqrt(num / den));
   }
