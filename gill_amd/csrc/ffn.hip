@@ -1,0 +1,363 @@
+// The feed-forward sub-block of a BasicTransformerBlock (diffusers: norm3 -> GEGLU -> ff.net.2 -> + residual, followed in the UNet by
+// proj_out + the outer residual) as ONE kernel per 128-row tile, for C = 320 (hidden 1280: SD-1.5 / SD-2.1 level 0):
+//   out[m] = [Wp.W2 | Wp] . [ value(m) * gelu(gate(m)) | t(m) ] + b + x_in(m),     [value | gate](m) = W1' . LN(t(m)) + b1'
+// (W1' / b1' carry norm3's gain / shift: ln_fold_rows_launch; [Wp.W2 | Wp], b: ffo_fuse_kernel in unet.hip.)
+// It replaces the GEGLU GEMM (97 us at M = 32768) and the two-source ffo GEMM (50 us) and the 84 MB tensor between them.
+//
+// Structure (prototype and measurements: tools/ubench/ffn_fused.hip, profiles/r03_ffn_fused_prototype.md).  Inside the 256-register
+// budget of two waves per SIMD this tile does not fit, so:
+//   * FOUR waves per workgroup, ONE per SIMD (amdgpu_waves_per_eu(1,1): the whole 512-register file), one workgroup per CU.  A wave owns
+//     32 rows of the tile through the whole block; nothing is exchanged between waves.
+//       t fragments (32 rows x 320) are loaded once, straight from global memory, as the B operand of 32x32x16 MFMAs (80 registers);
+//       first  out = Wp . t  on the RAW rows (10 stages), then the fragments are LayerNorm-ed in place (mean / rstd from the row-sum
+//       planes their producer wrote: GemmArgs::row_stats) and serve the 20 hidden chunks of 64:
+//       S1: acc[2 value + 2 gate tiles] = W1' chunk . LN(t)  (5 stages) -> bias, GEGLU in registers -> the products ARE the B operand of
+//       S2 (the accumulator registers 8hh .. 8hh+7 of a lane are the k slots of a 32x32x16 B fragment once the A operand's hidden order
+//       is permuted [0-3][8-11][4-7][12-15] within every 16: ffn_relayout_launch does that to [Wp.W2], as attention.hip does for V)
+//       S2: out += [Wp.W2] chunk . p  (2 stages of 160 output rows).
+//   * only WEIGHTS go through LDS: a ring of 7 slots x 20 KiB filled by LDS-DMA six stages ahead; a stage = a [128 | 160 rows][64 k] slab
+//     (1-KiB pieces of 8 rows, XOR-swizzled 16-B chunks); one s_barrier per stage; every counted s_waitcnt vmcnt is an immediate, because
+//     the stage sequence is a compile-time function of the position in the chunk.  The wait + barrier for stage g+1 sit in front of the
+//     last k16 step of stage g, whose MFMAs cover the first fragment reads of stage g+1.  A k16 step is one scheduling region:
+//     sched_group_barrier puts the next step's LDS reads behind its first MFMA and the LDS-DMA piece + address arithmetic in the gaps.
+// The output's GroupNorm partial sums (bins of 5 channels, 64-row slabs: what fuse_stats() files for C = 320) come out of the epilogue.
+#include "ops.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int FC = 320;            // channels
+constexpr int FH = 1280;           // hidden
+constexpr int FTM = 128;           // rows per workgroup
+constexpr int FSLOT = 20 * 1024;   // ring slot
+constexpr int FNSLOT = 7;
+constexpr int FNCH = FH / 64;
+constexpr int FBIAS_OFF = FNSLOT * FSLOT;                 // b1 table [20][128] fp32 behind the ring
+constexpr int FSMEM = FBIAS_OFF + FNCH * 128 * 4;
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int N> __device__ __forceinline__ void ffn_wait_vm() {
+  // gfx9 s_waitcnt: vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14; expcnt / lgkmcnt left open
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+
+struct Slab { const bf16_t* src; int ld; };   // rows x 64 k starting at src, row stride ld (elements)
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_fused_kernel(const FfnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int m = blockIdx.x * FTM + w * 32 + l31;            // this lane's row (M % 128 == 0: always valid)
+
+  // ---- t fragments (B operand): k16 step s -> t[m][16 s + 8 hi .. +8]
+  bf16x8 tf[20];
+#pragma unroll
+  for (int s = 0; s < 20; ++s) tf[s] = *reinterpret_cast<const bf16x8*>(p.T + (size_t)m * FC + 16 * s + 8 * hi);
+  // LayerNorm factors of the row (as ln_row_factors() in gemm.hip: planes added in plane order)
+  float ln_mean, ln_rstd;
+  {
+    const int R = p.ln_rows ? p.ln_rows : p.M;
+    const int mr = m >= R ? m - R : m;
+    const float* base = p.ln_stats + (size_t)mr * 2;
+    const size_t pstride = (size_t)R * 2;
+    float2 st = make_float2(0.f, 0.f);
+    for (int pl = 0; pl < p.ln_planes; ++pl) {
+      const float2 v = *reinterpret_cast<const float2*>(base + (size_t)pl * pstride);
+      st.x += v.x; st.y += v.y;
+    }
+    ln_mean = st.x * (1.f / FC);
+    const float var = fmaxf(st.y * (1.f / FC) - ln_mean * ln_mean, 0.f);
+    ln_rstd = rsqrtf(var + p.ln_eps);
+  }
+  // b1' table -> LDS
+  {
+    float* bt = reinterpret_cast<float*>(smem + FBIAS_OFF);
+    for (int i = tid; i < FNCH * 128; i += 256) bt[i] = p.b1c[i];
+  }
+
+  // ---- LDS-DMA staging: piece pc of a stage covers slab rows 8pc .. 8pc+7 (1 KiB); lane: row 8pc + (lane >> 3), physical 16-B chunk
+  // lane & 7 holds logical chunk (lane & 7) ^ (row & 7).  Wave w issues pieces w, w+4, w+8, ... (4 per wave for 128 rows, 5 for 160).
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  // stage sequence: g = 0..9 final stages F f (row half f / 5, k slab f % 5 of Wp); then g = 10 + 7c + q: chunk c, q = 0..4 S1 (k slab q of
+  // W1c's 128 chunk rows), q = 5, 6 S2 (row half q - 5 of W2p's 64 hidden columns of the chunk).  Ring slot = g mod 7.
+  auto slab_f = [&](int f) -> Slab { return Slab{p.Wfo + (size_t)(f / 5) * 160 * (5 * FC) + 4 * FC + 64 * (f % 5), 5 * FC}; };
+  auto slab_c = [&](int c, int q) -> Slab {
+    if (q < 5) return Slab{p.W1c + (size_t)c * 128 * FC + 64 * q, FC};
+    return Slab{p.W2p + (size_t)(q - 5) * 160 * FH + 64 * c, FH};
+  };
+  auto issue_piece = [&](const Slab& st, int slot, int i) {      // piece i (0..) of this wave's share; no branch: see the prototype's note
+    const int pc = w + 4 * i;
+    const bf16_t* src = st.src + (size_t)(8 * pc + srow) * st.ld + schunk * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(smem + slot * FSLOT + pc * 1024), 16, 0, 0);
+  };
+  // A fragment of n-tile `tile` (32 rows) at k16 step s of the staged slab: row = tile * 32 + l31, logical chunk 2 s + hi
+  auto wfrag = [&](const unsigned char* slot, int tile, int s) -> bf16x8 {
+    const int row = tile * 32 + l31;
+    return *reinterpret_cast<const bf16x8*>(slot + row * 128 + (((2 * s + hi) ^ (row & 7)) * 16));
+  };
+
+  f32x16 out[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[i][r] = 0.f;
+
+#pragma unroll
+  for (int f = 0; f < 6; ++f) {
+    const Slab st = slab_f(f);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) issue_piece(st, f, i);
+  }
+  // one explicit full wait: it also covers the t fragments and the row sums (without it the compiler cannot prove inside the loop that
+  // those registers have landed and fences the first MFMA of EVERY stage with vmcnt(0))
+  ffn_wait_vm<0>();
+
+  bf16x8 wf[2][5];
+  // NTL / NTN: 32-row tiles of this / the next stage (4 | 5; NTN = 0: last stage); WAITN: pieces that may stay outstanding when the next
+  // stage must have landed (those of stages g+2..g+5 plus the three of stage g+6 issued by then); NXP: pieces per wave of stage g+6 (0: none)
+  auto run_stage = [&](auto ntile_tag, auto ntile_next_tag, auto wait_tag, auto nxp_tag, int slot_idx, int next_slot_idx, const Slab& nx,
+                       int nx_slot, auto&& mma) {
+    constexpr int NTL = decltype(ntile_tag)::value;
+    constexpr int NTN = decltype(ntile_next_tag)::value;
+    constexpr int WAITN = decltype(wait_tag)::value;
+    constexpr int NXP = decltype(nxp_tag)::value;
+    const unsigned char* slot = smem + slot_idx * FSLOT;
+    const unsigned char* nslot = smem + next_slot_idx * FSLOT;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (s == 3 && NTN > 0) {
+        ffn_wait_vm<WAITN>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (s + 1 < 4) {
+#pragma unroll
+        for (int q = 0; q < NTL; ++q) wf[(s + 1) & 1][q] = wfrag(slot, q, s + 1);
+      } else if (NTN > 0) {
+#pragma unroll
+        for (int q = 0; q < NTN; ++q) wf[0][q] = wfrag(nslot, q, 0);
+      }
+      if (NXP > 0) { issue_piece(nx, nx_slot, s); if (s == 3 && NXP == 5) issue_piece(nx, nx_slot, 4); }
+      mma(s, wf[s & 1]);
+#pragma unroll
+      for (int q = 0; q < NTL; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        // 1 MFMA
+        if (q == 0 && (s + 1 < 4 || NTN > 0)) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);   // the next step's reads behind the first MFMA
+        __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                                        // up to 3 VALU / SALU
+        if (q == 2 && NXP > 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                 // the LDS-DMA piece
+        if (q == 3 && NXP == 5 && s == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // (the fifth piece)
+      }
+    }
+  };
+  using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+
+  // prologue of the stream: stage 0 has landed; barrier (also: the bias table is in LDS); its first fragments
+  __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the bias table's ds_writes
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int q = 0; q < 5; ++q) wf[0][q] = wfrag(smem, q, 0);
+
+  // ---- final segment first: out = Wp . t on the raw rows.  WAITN for f = 0..9: 23 23 23 23 23 22 21 20 19 19
+#define F_STAGE(F, N)                                                                                                            \
+  {                                                                                                                              \
+    auto mma = [&](int s, const bf16x8* wfp) {                                                                                   \
+      _Pragma("unroll") for (int q = 0; q < 5; ++q)                                                                             \
+        out[5 * ((F) / 5) + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfp[q], tf[4 * ((F) % 5) + s], out[5 * ((F) / 5) + q], 0, 0, 0); \
+    };                                                                                                                           \
+    const Slab nx = (F) + 6 < 10 ? slab_f(((F) + 6) % 10) : slab_c(0, ((F) + 6 - 10) % 7);                                       \
+    run_stage(I5{}, std::integral_constant<int, (F) + 1 < 10 ? 5 : 4>{}, std::integral_constant<int, N>{},                       \
+              std::integral_constant<int, ((F) + 6 < 10 || (F) + 6 - 10 >= 5) ? 5 : 4>{}, (F) % 7, ((F) + 1) % 7, nx,            \
+              ((F) + 6) % 7, mma);                                                                                               \
+  }
+  F_STAGE(0, 23) F_STAGE(1, 23) F_STAGE(2, 23) F_STAGE(3, 23) F_STAGE(4, 23)
+  F_STAGE(5, 22) F_STAGE(6, 21) F_STAGE(7, 20) F_STAGE(8, 19) F_STAGE(9, 19)
+#undef F_STAGE
+
+  // ---- LayerNorm the resident fragments in place: t -> (t - mean) * rstd, rounded to bf16 (gain / shift live in W1' / b1')
+#pragma unroll
+  for (int s = 0; s < 20; ++s) {
+    union { bf16x8 v; unsigned u[4]; } x;
+    x.v = tf[s];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = (__uint_as_float(x.u[j] << 16) - ln_mean) * ln_rstd;
+      const float b = (__uint_as_float(x.u[j] & 0xffff0000u) - ln_mean) * ln_rstd;
+      x.u[j] = pack_bf2(a, b);
+    }
+    tf[s] = x.v;
+  }
+  const float* btab = reinterpret_cast<const float*>(smem + FBIAS_OFF);
+
+  // one chunk; LAST (compile-time): nothing is left to prefetch behind position 0
+  auto run_chunk = [&](int c, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // slot of position q: (3 + q) mod 7.  WAITN by position: 20 21 21 21 20 19 19; last chunk: 20 18 14 10 5 0 -
+#define S1_STAGE(J, N, NL)                                                                                                      \
+    {                                                                                                                            \
+      auto mma = [&](int s, const bf16x8* wfp) {                                                                                 \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                        \
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfp[nt], tf[4 * (J) + s], acc[nt], 0, 0, 0);                         \
+      };                                                                                                                         \
+      const Slab nx = (J) == 0 ? slab_c(c, 6) : slab_c(LAST ? c : c + 1, (J) - 1);                                               \
+      run_stage(I4{}, std::integral_constant<int, (J) == 4 ? 5 : 4>{}, std::integral_constant<int, LAST ? NL : N>{},             \
+                std::integral_constant<int, (J) == 0 ? 5 : (LAST ? 0 : 4)>{}, (3 + (J)) % 7, (4 + (J)) % 7, nx,                  \
+                (J) == 0 ? 2 : (2 + (J)) % 7, mma);                                                                              \
+    }
+    S1_STAGE(0, 20, 20) S1_STAGE(1, 21, 18) S1_STAGE(2, 21, 14) S1_STAGE(3, 21, 10) S1_STAGE(4, 20, 5)
+#undef S1_STAGE
+    // ---- bias, GEGLU in registers: tiles 0, 1 = value of hidden tiles 0, 1; tiles 2, 3 = their gates.  Lane (m, hi) holds of a tile the
+    // rows n = (r & 3) + 8 (r >> 2) + 4 hi: four runs of 4 consecutive
+    bf16x8 pf[4];          // B fragments of the 4 k16 steps (tt, hh) of S2
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        union { bf16x8 v; unsigned u[4]; } pk;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {      // register run r = 8 hh + 4 g2 .. +3  <->  rows 16 hh + 8 g2 + 4 hi .. +3
+          const float4 bv = *reinterpret_cast<const float4*>(btab + c * 128 + tt * 32 + 16 * hh + 8 * g2 + 4 * hi);
+          const float4 bg = *reinterpret_cast<const float4*>(btab + c * 128 + 64 + tt * 32 + 16 * hh + 8 * g2 + 4 * hi);
+          const int r = 8 * hh + 4 * g2;
+          const float o0 = (acc[tt][r] + bv.x) * gelu_erf(acc[2 + tt][r] + bg.x);
+          const float o1 = (acc[tt][r + 1] + bv.y) * gelu_erf(acc[2 + tt][r + 1] + bg.y);
+          const float o2 = (acc[tt][r + 2] + bv.z) * gelu_erf(acc[2 + tt][r + 2] + bg.z);
+          const float o3 = (acc[tt][r + 3] + bv.w) * gelu_erf(acc[2 + tt][r + 3] + bg.w);
+          pk.u[2 * g2] = pack_bf2(o0, o1);
+          pk.u[2 * g2 + 1] = pack_bf2(o2, o3);
+        }
+        pf[2 * tt + hh] = pk.v;
+      }
+    // ---- S2: out += [Wp.W2] chunk . p
+#define S2_STAGE(U, N, NL)                                                                                                      \
+    {                                                                                                                            \
+      auto mma = [&](int s, const bf16x8* wfp) {                                                                                 \
+        _Pragma("unroll") for (int q = 0; q < 5; ++q)                                                                           \
+          out[5 * (U) + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfp[q], pf[s], out[5 * (U) + q], 0, 0, 0);                  \
+      };                                                                                                                         \
+      const Slab nx = slab_c(LAST ? c : c + 1, 4 + (U));                                                                         \
+      run_stage(I5{}, std::integral_constant<int, (U) == 0 ? 5 : (LAST ? 0 : 4)>{}, std::integral_constant<int, LAST ? NL : N>{},\
+                std::integral_constant<int, LAST ? 0 : ((U) == 1 ? 5 : 4)>{}, (3 + 5 + (U)) % 7, (U) == 0 ? 2 : 3, nx,           \
+                (2 + 5 + (U)) % 7, mma);                                                                                         \
+    }
+    S2_STAGE(0, 19, 0) S2_STAGE(1, 19, 0)
+#undef S2_STAGE
+  };
+  for (int c = 0; c + 1 < FNCH; ++c) run_chunk(c, std::false_type{});
+  run_chunk(FNCH - 1, std::true_type{});
+
+  // ---- epilogue: + bias + outer residual, bf16.  Lane (m, hi) holds columns n = tile * 32 + 8 q4 + 4 hi .. +3 of its row.  With gn_stats
+  // the rounded values also go to an LDS tile (the ring is dead; rows 648 B apart: the 32 row lanes of an 8-byte ds_write then hit distinct
+  // banks) from which the GroupNorm partial sums of the output are formed: per (64-row slab, column) over the rows, then per bin of
+  // 5 columns — every sum in a fixed order, written once: the layout fuse_stats() consumers read (GemmArgs::gn_stats).
+  constexpr int OSTR = 648;
+  bf16_t* orow = p.out + (size_t)m * FC;
+  const bf16_t* rrow = p.resid + (size_t)m * FC;
+  if (p.gn_stats) __syncthreads();          // every wave is done with the ring
+  unsigned char* otile = smem + (size_t)(w * 32 + l31) * OSTR;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    uint2 rv[4]; float4 bo[4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int n = i * 32 + 8 * q4 + 4 * hi;
+      rv[q4] = *reinterpret_cast<const uint2*>(rrow + n);
+      bo[q4] = *reinterpret_cast<const float4*>(p.bo + n);
+    }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int n = i * 32 + 8 * q4 + 4 * hi;
+      const float v0 = out[i][4 * q4] + bo[q4].x + __uint_as_float(rv[q4].x << 16);
+      const float v1 = out[i][4 * q4 + 1] + bo[q4].y + __uint_as_float(rv[q4].x & 0xffff0000u);
+      const float v2 = out[i][4 * q4 + 2] + bo[q4].z + __uint_as_float(rv[q4].y << 16);
+      const float v3 = out[i][4 * q4 + 3] + bo[q4].w + __uint_as_float(rv[q4].y & 0xffff0000u);
+      const uint2 o = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+      *reinterpret_cast<uint2*>(orow + n) = o;
+      if (p.gn_stats) *reinterpret_cast<uint2*>(otile + n * 2) = o;
+    }
+  }
+  if (p.gn_stats) {
+    __syncthreads();
+    float2* colsum = reinterpret_cast<float2*>(smem + 128 * OSTR);        // [2 slabs][320 columns] {sum, sum of squares}
+    for (int idx = tid; idx < 2 * FC; idx += 256) {
+      const int slab = idx / FC, col = idx - slab * FC;
+      const unsigned char* src = smem + (size_t)(slab * 64) * OSTR + col * 2;
+      float a = 0.f, q = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 64; ++r) {
+        const float v = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(src + (size_t)r * OSTR) << 16);
+        a += v; q += v * v;
+      }
+      colsum[idx] = make_float2(a, q);
+    }
+    __syncthreads();
+    {
+      // 2 slabs x 64 bins x 2 moments = 256 sums, one per thread; bin = 5 columns (C / 64: the bins fuse_stats() files for C = 320)
+      const int which = tid & 1, bin = (tid >> 1) & 63, slab = tid >> 7;
+      const float* cs = reinterpret_cast<const float*>(colsum + slab * FC + bin * 5) + which;
+      const float a = (((cs[0] + cs[2]) + cs[4]) + cs[6]) + cs[8];
+      const int m0 = blockIdx.x * FTM + slab * 64;
+      const int b = m0 / p.rows_per_batch;
+      const int sl = (m0 - b * p.rows_per_batch) / 64;
+      const int nslab = p.rows_per_batch / 64;
+      p.gn_stats[(((size_t)b * nslab + sl) * 64 + bin) * 2 + which] = a;
+    }
+  }
+}
+
+// W1c[c][0..63 | 64..127][k] := the value | gate rows of hidden 64c .. 64c+63 of wff1 (16-row interleaved GEGLU layout, LayerNorm-folded);
+// b1c likewise; W2p[n][pos] := wfo[n][perm(pos)], position 16 g + 8 hi + j <- hidden 16 g + 8 (j >> 2) + 4 hi + (j & 3)
+__global__ __launch_bounds__(256) void ffn_relayout_kernel(const bf16_t* __restrict__ wff1, const float* __restrict__ bff1,
+                                                           const bf16_t* __restrict__ wfo, bf16_t* __restrict__ W1c,
+                                                           float* __restrict__ b1c, bf16_t* __restrict__ W2p) {
+  const int64_t n1 = (int64_t)2 * FH * FC, n2 = (int64_t)FC * FH;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < n1) {
+      const int k = (int)(i % FC);
+      const int row = (int)(i / FC);                 // destination row: c * 128 + (gate ? 64 : 0) + j
+      const int c = row / 128, rr = row % 128, gate = rr / 64, j = rr % 64;
+      const int h = c * 64 + j;
+      const int src = (h / 16) * 32 + gate * 16 + (h % 16);
+      W1c[i] = wff1[(size_t)src * FC + k];
+      if (k == 0) b1c[row] = bff1[src];
+    } else {
+      const int64_t t = i - n1;
+      const int pos = (int)(t % FH), n = (int)(t / FH);
+      const int g16 = pos / 16, r = pos % 16, hi = r / 8, j = r % 8;
+      W2p[t] = wfo[(size_t)n * (5 * FC) + 16 * g16 + 8 * (j >> 2) + 4 * hi + (j & 3)];
+    }
+  }
+}
+
+}  // namespace
+
+bool ffn_fused_supported(int C, int M) { return C == FC && M % FTM == 0 && M > 0; }
+
+int ffn_relayout_launch(const bf16_t* wff1, const float* bff1, const bf16_t* wfo, bf16_t* W1c, float* b1c, bf16_t* W2p, hipStream_t s) {
+  hipLaunchKernelGGL(ffn_relayout_kernel, dim3(1024), dim3(256), 0, s, wff1, bff1, wfo, W1c, b1c, W2p);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int ffn_fused_launch(const FfnArgs& a, hipStream_t s) {
+  GILL_REQUIRE(ffn_fused_supported(FC, a.M), "fused feed-forward block: M must be a multiple of 128");
+  GILL_REQUIRE(a.T && a.ln_stats && a.W1c && a.b1c && a.W2p && a.Wfo && a.bo && a.resid && a.out, "fused feed-forward block: null operand");
+  GILL_REQUIRE(a.ln_planes >= 1, "fused feed-forward block: LayerNorm row-sum planes missing");
+  GILL_REQUIRE(!a.gn_stats || (a.rows_per_batch > 0 && a.rows_per_batch % 128 == 0), "fused feed-forward block: GroupNorm partials need whole 64-row slabs per sample");
+  static bool attr_set = false;
+  if (!attr_set) {
+    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FSMEM));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ffn_fused_kernel, dim3(a.M / FTM), dim3(256), FSMEM, s, a);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}

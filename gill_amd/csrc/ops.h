@@ -132,6 +132,24 @@ struct XattnArgs {
 bool xattn_block_supported(int C, int heads, int dp, int HW, int ctx_pad);
 int xattn_block_launch(const XattnArgs& a, hipStream_t s);
 
+// The feed-forward sub-block + proj_out + outer residual of a level-0 transformer block (C = 320) as one kernel (ffn.hip):
+//   out = [Wp.W2 | Wp] . [ value * gelu(gate) | t ] + bo + resid,  [value | gate] = W1' . LN(t) + b1'  (LN from the row-sum planes).
+// W1c / b1c / W2p: ffn_relayout_launch() of the engine's wff1 / bff1 (LayerNorm-folded GEGLU rows) and wfo ([Wp.W2 | Wp], [C][5C]).
+struct FfnArgs {
+  int M = 0;
+  const bf16_t* T = nullptr;                                           // [M][320] residual stream (raw)
+  const float* ln_stats = nullptr; int ln_planes = 0, ln_rows = 0; float ln_eps = 1e-5f;
+  const bf16_t* W1c = nullptr; const float* b1c = nullptr;             // [20][128][320], [20][128]
+  const bf16_t* W2p = nullptr;                                         // [320][1280], hidden order permuted within every 16
+  const bf16_t* Wfo = nullptr; const float* bo = nullptr;              // [320][1600] (its last 320 columns = Wp), [320]
+  const bf16_t* resid = nullptr; bf16_t* out = nullptr;                // [M][320]
+  float* gn_stats = nullptr; int rows_per_batch = 0;                   // optional: GroupNorm partials of the output, bins of 5 channels,
+                                                                       // [(b * rows_per_batch / 64 + slab) * 64 + bin][2] (GemmArgs::gn_stats layout)
+};
+bool ffn_fused_supported(int C, int M);
+int ffn_relayout_launch(const bf16_t* wff1, const float* bff1, const bf16_t* wfo, bf16_t* W1c, float* b1c, bf16_t* W2p, hipStream_t s);
+int ffn_fused_launch(const FfnArgs& a, hipStream_t s);
+
 // LayerNorm over the last dim (eps inside sqrt), fp32 or bf16 rows in, bf16 rows out.
 int layernorm_launch(const void* x, int x_f32, const float* gamma, const float* beta, bf16_t* y,
                      int rows, int C, float eps, hipStream_t s);

@@ -56,6 +56,7 @@ struct XfW {  // Transformer2DModel with one BasicTransformerBlock
   bf16_t* wkv2 = nullptr;     // [2*H*dp][ctx_dim]
   LinW out2;
   bf16_t* wff1 = nullptr; float* bff1 = nullptr;   // GEGLU-permuted [8C][C]
+  bf16_t* w1c = nullptr; float* b1c = nullptr; bf16_t* w2p = nullptr;   // the same weights as the fused feed-forward kernel reads them (ffn.hip; C = 320 only)
   // norm1/2/3 are folded into wqkv1 / wq2 / wff1 at load (GemmArgs::ln_stats): column sums of g*W and beta.W^T (+ bias)
   float *s_qkv1 = nullptr, *c_qkv1 = nullptr, *s_q2 = nullptr, *c_q2 = nullptr, *s_ff1 = nullptr;
   LinW ff2;                   // [C][4C]
@@ -214,6 +215,13 @@ __global__ __launch_bounds__(256) void ffo_fuse_kernel(const void* wp, int dt_p,
   }
 }
 
+// The feed-forward sub-blocks at C = 320 (level 0) run as one kernel (ffn.hip) instead of GEGLU + the two-source ffo GEMM: loop
+// 528.9 -> 522.8 ms.  GILL_UNET_FFN_FUSED = 0 restores the two GEMMs.
+static bool ffn_fused_on() {
+  static const bool on = [] { const char* e = getenv("GILL_UNET_FFN_FUSED"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 namespace {
 
 struct Loader {
@@ -366,6 +374,12 @@ struct Loader {
     GILL_TRY(ln_fold_rows_launch(x->wqkv1, 3 * hdp, C, x->ln1.g, x->ln1.b, x->s_qkv1, x->c_qkv1, s));
     GILL_TRY(ln_fold_rows_launch(x->wq2, hdp, C, x->ln2.g, x->ln2.b, x->s_q2, x->c_q2, s));
     GILL_TRY(ln_fold_rows_launch(x->wff1, 8 * C, C, x->ln3.g, x->ln3.b, x->s_ff1, x->bff1, s));
+    if (ffn_fused_on() && ffn_fused_supported(C, 128)) {
+      GILL_TRY(pool.alloc(&x->w1c, (size_t)8 * C * C, false));
+      GILL_TRY(pool.alloc(&x->b1c, (size_t)8 * C, false));
+      GILL_TRY(pool.alloc(&x->w2p, (size_t)4 * C * C, false));
+      GILL_TRY(ffn_relayout_launch(x->wff1, x->bff1, x->wfo, x->w1c, x->b1c, x->w2p, s));
+    }
     return 0;
   }
 };
@@ -703,6 +717,7 @@ struct UNetRun {
     Bx = Bfull;                    // every buffer is sized for the full batch
     const int H = x.H, Wd = x.W, C = w.C, HW = H * Wd, M = Bfull * HW, M1 = Bpre * HW;
     const int nh = w.heads, hdp = nh * w.dp;
+    const bool ffn_fused = w.w1c != nullptr && ffn_fused_supported(C, M) && HW % 128 == 0;
     *out = talloc(H, Wd, C, out_stats);
     const size_t mk = m->arena.mark();
     Tensor n = talloc(H, Wd, C);
@@ -781,6 +796,19 @@ struct UNetRun {
     }
     GILL_TRY(attend(q, m->kcache[w.layer_id], m->vcache[w.layer_id], o, HW, m->cfg.ctx_len, hw_pad, m->ctx_pad, w));
     GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M, w.out2.w, w.out2.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, &st3));
+    }
+    if (ffn_fused) {
+      // --- GEGLU feed-forward, its residual, proj_out and the outer residual as ONE kernel (ffn.hip)
+      if (!dry) {
+        FfnArgs fa;
+        fa.M = M; fa.T = tres; fa.ln_stats = st3.p; fa.ln_planes = st3.planes;
+        fa.W1c = w.w1c; fa.b1c = w.b1c; fa.W2p = w.w2p; fa.Wfo = w.wfo; fa.bo = w.bfo; fa.resid = xd.p; fa.out = out->p;
+        if (out->stats && out->sbin == 5) { fa.gn_stats = out->stats; fa.rows_per_batch = HW; out->nslab = HW / GN_SLAB_ROWS; }
+        else out->stats = nullptr;        // (no partials from this producer: the consumer runs its own statistics pass)
+        GILL_TRY(ffn_fused_launch(fa, s));
+      }
+      m->arena.release(mk);
+      return 0;
     }
     // --- GEGLU feed-forward
     bf16_t* ffh = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)M * 4 * C);
@@ -1206,6 +1234,56 @@ extern "C" int gill_op_xattn_block(const void* o1, const void* t, const void* Wo
   xa.debug_stop = debug_stop;
   const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int r = e ? atoi(e) : 1; return r > 0 ? r : 1; }();
   for (int r = 0; r < rep; ++r) GILL_TRY(xattn_block_launch(xa, s));
+  GILL_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Operator-level entry for the fused feed-forward block (ffn.hip) on NATURAL operands (diffusers parameter layouts): folds norm3 into the
+// GEGLU projection, builds [Wp.W2 | Wp] and the kernel's weight layouts exactly as the engine's loader does, forms the LayerNorm row sums
+// of t, launches the kernel.  out = proj_out(ff2(geglu(ff1(LN(t)))) + t) + resid.  For tests/test_ops_gpu.py and tools; synchronises.
+__global__ __launch_bounds__(256) void ffn_op_rowsums_kernel(const bf16_t* __restrict__ t, int M, int C, float* __restrict__ stats) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float a = 0.f, q = 0.f;
+  for (int k = lane; k < C; k += 64) { const float v = bf2f(t[(size_t)row * C + k]); a += v; q += v * v; }
+  a = wave_sum(a); q = wave_sum(q);
+  if (lane == 0) { stats[(size_t)row * 2] = a; stats[(size_t)row * 2 + 1] = q; }
+}
+extern "C" int gill_op_ffn_fused(const void* t, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
+                                 const float* b2, const void* Wp, const float* bp, const void* resid, void* out, float* gn_stats,
+                                 int M, int rows_per_batch, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int C = 320, inner = 4 * C;
+  GILL_REQUIRE(t && ln_g && ln_b && W1 && b1 && W2 && b2 && Wp && bp && resid && out, "null argument");
+  GILL_REQUIRE(ffn_fused_supported(C, M), "ffn_fused: M must be a multiple of 128");
+  DevBuf idx, wff1, bff1, sff1, wfo, bfo, w1c, b1c, w2p, st;
+  std::vector<int32_t> map = geglu_row_permutation(inner);
+  GILL_TRY(idx.alloc(sizeof(int32_t) * map.size()));
+  GILL_CHECK_HIP(hipMemcpyAsync(idx.p, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice, s));
+  GILL_TRY(wff1.alloc(sizeof(bf16_t) * (size_t)2 * inner * C)); GILL_TRY(bff1.alloc(sizeof(float) * 2 * inner));
+  GILL_TRY(sff1.alloc(sizeof(float) * 2 * inner));
+  GILL_TRY(scatter_rows_bf16_launch((const bf16_t*)W1, 2 * inner, C, (const int32_t*)idx.p, (bf16_t*)wff1.p, C, s));
+  GILL_TRY(permute_f32_launch(b1, (const int32_t*)idx.p, 2 * inner, (float*)bff1.p, s));
+  GILL_TRY(ln_fold_rows_launch((bf16_t*)wff1.p, 2 * inner, C, ln_g, ln_b, (float*)sff1.p, (float*)bff1.p, s));
+  GILL_TRY(wfo.alloc(sizeof(bf16_t) * (size_t)C * 5 * C)); GILL_TRY(bfo.alloc(sizeof(float) * C));
+  hipLaunchKernelGGL(ffo_fuse_kernel, dim3(cdiv(5 * C + 1, 256), C), dim3(256), 0, s, Wp, 0, W2, 0, (const void*)b2, 1, (const void*)bp, 1, C,
+                     (bf16_t*)wfo.p, (float*)bfo.p);
+  GILL_CHECK_HIP(hipGetLastError());
+  GILL_TRY(w1c.alloc(sizeof(bf16_t) * (size_t)8 * C * C)); GILL_TRY(b1c.alloc(sizeof(float) * 8 * C));
+  GILL_TRY(w2p.alloc(sizeof(bf16_t) * (size_t)4 * C * C));
+  GILL_TRY(ffn_relayout_launch((const bf16_t*)wff1.p, (const float*)bff1.p, (const bf16_t*)wfo.p, (bf16_t*)w1c.p, (float*)b1c.p,
+                               (bf16_t*)w2p.p, s));
+  GILL_TRY(st.alloc(sizeof(float) * (size_t)M * 2));
+  hipLaunchKernelGGL(ffn_op_rowsums_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, (const bf16_t*)t, M, C, (float*)st.p);
+  GILL_CHECK_HIP(hipGetLastError());
+  FfnArgs fa;
+  fa.M = M; fa.T = (const bf16_t*)t; fa.ln_stats = (const float*)st.p; fa.ln_planes = 1;
+  fa.W1c = (const bf16_t*)w1c.p; fa.b1c = (const float*)b1c.p; fa.W2p = (const bf16_t*)w2p.p;
+  fa.Wfo = (const bf16_t*)wfo.p; fa.bo = (const float*)bfo.p; fa.resid = (const bf16_t*)resid; fa.out = (bf16_t*)out;
+  fa.gn_stats = gn_stats; fa.rows_per_batch = rows_per_batch;
+  static const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
+  for (int r = 0; r < rep; ++r) GILL_TRY(ffn_fused_launch(fa, s));
   GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
 }

@@ -247,6 +247,15 @@ int gill_op_groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int
 int gill_op_xattn_block(const void* o1, const void* t, const void* Wo1, const float* bo1, const float* ln_g, const float* ln_b,
                         const void* Wq, const void* k, const void* v, const void* Wo2, const float* bo2, void* out,
                         float* row_stats, int B, int HW, int C, int heads, int ctx_len, int src_rows, int debug_stop, void* stream);
+
+/* The feed-forward sub-block of a level-0 (C = 320) transformer block + proj_out + outer residual as one kernel (csrc/ffn.hip):
+ * out = proj_out(ff2(geglu(ff1(LN(t)))) + t) + resid on natural (diffusers-layout) operands; gn_stats (optional): GroupNorm partial sums
+ * of the output, [(b * rows_per_batch / 64 + slab) * 64 + bin][2], bins of 5 channels.  Replaces, inside gill_unet_forward, the
+ * BasicTransformerBlock.ff call + Transformer2DModel.proj_out of diffusers (reference call site: gill/custom_sd.py:633-638). */
+int gill_op_ffn_fused(const void* t_bf16, const float* ln_g, const float* ln_b, const void* W1_bf16, const float* b1,
+                      const void* W2_bf16, const float* b2, const void* Wp_bf16, const float* bp, const void* resid_bf16,
+                      void* out_bf16, float* gn_stats, int M, int rows_per_batch, void* stream);
+
 int gill_op_conv3x3_fp8(const void* x_bf16, const float* w_oihw, const float* bias, const void* resid_bf16, void* y_bf16,
                         int B, int H, int W, int Cin, int Cout, int splitk, void* stream);
 

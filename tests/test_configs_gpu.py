@@ -241,3 +241,29 @@ def test_fused_cross_attention_block_matches_the_four_launch_graph(cuda, tmp_pat
     assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
     _, rel, cos = _stats(f"fused cross-attention block vs four launches: {key}", a, b)
     assert rel < bar and cos > 0.999, f"{key}: rel-L2 {rel:.3e}"
+
+
+def test_ffn_fused_switch_full_size_forward(cuda):
+  """GILL_UNET_FFN_FUSED (read once per process): one full-size SD-1.5 forward with the level-0 feed-forward sub-blocks as the fused
+  kernel (default) and as GEGLU + the two-source GEMM, in two subprocesses on the same seeded weights.  Both forms have their oracle
+  tests (the default one in every full-size test of this file); here they must agree with each other to the distance either has from
+  the oracle."""
+  import tempfile
+  code = ("import torch, sys; sys.path.insert(0, %r); from gill_amd import synth; from gill_amd.sd import GillSDPipeline\n"
+          "cfg = synth.UNetConfig.sd15()\n"
+          "sd = {k: v.bfloat16() for k, v in synth.unet_state_dict(cfg, seed=95).items()}\n"
+          "pipe = GillSDPipeline(sd, cfg, synth.uncond_context(cfg.ctx_len, cfg.cross_attention_dim, seed=95), 'cuda:0', max_batch=2)\n"
+          "x = synth.normal('ff_x', (2, 4, 64, 64), 96); ctx = synth.normal('ff_c', (2, cfg.ctx_len, cfg.cross_attention_dim), 97)\n"
+          "y = pipe.unet(x, torch.tensor([961.0, 41.0]), ctx).float().cpu()\n"
+          "torch.save(y, sys.argv[1])\n") % ROOT
+  outs = []
+  with tempfile.TemporaryDirectory() as d:
+    for sw in ("0", "1"):
+      f = os.path.join(d, f"y{sw}.pt")
+      r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, GILL_UNET_FFN_FUSED=sw), capture_output=True, text=True,
+                         timeout=900)
+      assert r.returncode == 0, r.stderr[-2000:]
+      outs.append(torch.load(f))
+  assert torch.isfinite(outs[1]).all() and not torch.equal(outs[0], outs[1])       # (the switch did switch)
+  _, rel, cos = _stats("full-size forward: fused feed-forward blocks vs GEGLU + ffo GEMMs", outs[1], outs[0])
+  assert rel < 1.5e-2 and cos > 0.9995

@@ -381,3 +381,31 @@ def test_xattn_block_shared_prefix_rows(cuda):
   rel = ((got.float().cpu() - ref).norm() / ref.norm()).item()
   print(f"[xattn block, shared prefix] rel-L2 {rel:.3e}")
   assert rel < 1e-2
+
+
+# ---------------------------------------------------------------- fused feed-forward block (csrc/ffn.hip)
+@pytest.mark.parametrize("M,rows_per_batch", [(128, 128), (512, 256), (4096, 1024)])
+def test_ffn_fused_vs_torch(cuda, M, rows_per_batch):
+  """BasicTransformerBlock.ff (norm3 -> GEGLU -> Linear) + residual, then proj_out + the outer residual — at C = 320 one kernel: against
+  the fp32 restatement on the same bf16-rounded operands, and its GroupNorm partial sums (64-row slabs, bins of 5 channels) against sums
+  of the tensor it wrote.  Ref: diffusers BasicTransformerBlock / Transformer2DModel as restated in oracle/unet_ref.py:_transformer."""
+  from gill_amd import ops
+  C, H = 320, 1280
+  t = _bf(_rnd((M, C), 60, 1.5) + 0.3)
+  resid = _bf(_rnd((M, C), 61))
+  ln_g, ln_b = 1.0 + 0.2 * _rnd((C,), 62), 0.1 * _rnd((C,), 63)
+  w1, b1 = _bf(_rnd((2 * H, C), 64, 0.06)), 0.1 * _rnd((2 * H,), 65)
+  w2, b2 = _bf(_rnd((C, H), 66, 0.03)), 0.1 * _rnd((C,), 67)
+  wp, bp = _bf(_rnd((C, C), 68, 0.05)), 0.1 * _rnd((C,), 69)
+  x = F.layer_norm(t.float(), (C,), ln_g, ln_b, 1e-5)
+  pr = x @ w1.float().T + b1
+  h = pr[:, :H] * F.gelu(pr[:, H:])
+  y = t.float() + h @ w2.float().T + b2
+  ref = y @ wp.float().T + bp + resid.float()
+  out, stats = ops.ffn_fused(t.to(cuda), ln_g.to(cuda), ln_b.to(cuda), w1.to(cuda), b1.to(cuda), w2.to(cuda), b2.to(cuda), wp.to(cuda),
+                             bp.to(cuda), resid.to(cuda), rows_per_batch=rows_per_batch)
+  assert _report(f"fused FFN M={M}", out, ref) < 1e-2
+  o = out.float().cpu().view(M // 64, 64, 64, 5)                  # (slab, row, bin, channel in bin)
+  want = torch.stack([o.sum(dim=(1, 3)), (o * o).sum(dim=(1, 3))], dim=-1)
+  got = stats.cpu()
+  assert torch.allclose(got, want, rtol=2e-4, atol=2e-3), float((got - want).abs().max())
