@@ -227,10 +227,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           const float4 bv = *reinterpret_cast<const float4*>(btab + c * 128 + tt * 32 + 16 * hh + 8 * g2 + 4 * hi);
           const float4 bg = *reinterpret_cast<const float4*>(btab + c * 128 + 64 + tt * 32 + 16 * hh + 8 * g2 + 4 * hi);
           const int r = 8 * hh + 4 * g2;
-          const float o0 = (acc[tt][r] + bv.x) * gelu_erf(acc[2 + tt][r] + bg.x);
-          const float o1 = (acc[tt][r + 1] + bv.y) * gelu_erf(acc[2 + tt][r + 1] + bg.y);
-          const float o2 = (acc[tt][r + 2] + bv.z) * gelu_erf(acc[2 + tt][r + 2] + bg.z);
-          const float o3 = (acc[tt][r + 3] + bv.w) * gelu_erf(acc[2 + tt][r + 3] + bg.w);
+          const float o0 = (acc[tt][r] + bv.x) * gelu_logistic(acc[2 + tt][r] + bg.x);
+          const float o1 = (acc[tt][r + 1] + bv.y) * gelu_logistic(acc[2 + tt][r + 1] + bg.y);
+          const float o2 = (acc[tt][r + 2] + bv.z) * gelu_logistic(acc[2 + tt][r + 2] + bg.z);
+          const float o3 = (acc[tt][r + 3] + bv.w) * gelu_logistic(acc[2 + tt][r + 3] + bg.w);
           pk.u[2 * g2] = pack_bf2(o0, o1);
           pk.u[2 * g2 + 1] = pack_bf2(o2, o3);
         }
