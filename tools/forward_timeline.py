@@ -10,7 +10,7 @@ import sys
 
 
 def short(n):
-  return re.sub(r"\(.*$", "", n).replace("void ", "")[:60]
+  return re.sub(r"\(.*$", "", n.replace("(anonymous namespace)::", "")).replace("void ", "")[:60]
 
 
 def main():

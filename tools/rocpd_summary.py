@@ -7,7 +7,7 @@ import sys
 
 
 def short(name: str) -> str:
-  name = re.sub(r"\(.*$", "", name)
+  name = re.sub(r"\(.*$", "", name.replace("(anonymous namespace)::", ""))
   name = name.replace("void ", "")
   return name[:110]
 
