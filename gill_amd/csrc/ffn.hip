@@ -36,6 +36,7 @@ constexpr int FBIAS_OFF = FNSLOT * FSLOT;                 // b1 table [20][128] 
 constexpr int FSMEM = FBIAS_OFF + FNCH * 128 * 4;
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 template <int N> __device__ __forceinline__ void ffn_wait_vm() {
   // gfx9 s_waitcnt: vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14; expcnt / lgkmcnt left open
@@ -224,8 +225,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         union { bf16x8 v; unsigned u[4]; } pk;
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {      // register run r = 8 hh + 4 g2 .. +3  <->  rows 16 hh + 8 g2 + 4 hi .. +3
-          const float4 bv = *reinterpret_cast<const float4*>(btab + c * 128 + tt * 32 + 16 * hh + 8 * g2 + 4 * hi);
-          const float4 bg = *reinterpret_cast<const float4*>(btab + c * 128 + 64 + tt * 32 + 16 * hh + 8 * g2 + 4 * hi);
+          // (a NATIVE vector type: a float4 is a struct, its LDS load carries no alias info, and the waitcnt pass then makes it wait for
+          // every LDS-DMA in flight — s_waitcnt vmcnt(0), the ring drained once per chunk)
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(btab + c * 128 + tt * 32 + 16 * hh + 8 * g2 + 4 * hi);
+          const f32x4 bg = *reinterpret_cast<const f32x4*>(btab + c * 128 + 64 + tt * 32 + 16 * hh + 8 * g2 + 4 * hi);
           const int r = 8 * hh + 4 * g2;
           const float o0 = (acc[tt][r] + bv.x) * gelu_logistic(acc[2 + tt][r] + bg.x);
           const float o1 = (acc[tt][r + 1] + bv.y) * gelu_logistic(acc[2 + tt][r + 1] + bg.y);

@@ -150,6 +150,28 @@ bool ffn_fused_supported(int C, int M);
 int ffn_relayout_launch(const bf16_t* wff1, const float* bff1, const bf16_t* wfo, bf16_t* W1c, float* b1c, bf16_t* W2p, hipStream_t s);
 int ffn_fused_launch(const FfnArgs& a, hipStream_t s);
 
+// Two GEMMs of a level-0 transformer block around a LayerNorm as one kernel (lnproj.hip):
+//   mode 0: T = W1 . X + b1 (proj_in, K1 = 320);  [q | k | v] = W2p . LN(T) + c2 scattered head-major (three segments of 384 columns)
+//   mode 1: T = W1 . X + b1 + T (attn1.to_out, K1 = 384, in place);  q = W2p . LN(T) + c2 (one segment)
+// W2p: lnproj_kperm_launch() of the engine's LayerNorm-folded wqkv1 / wq2; c2 their folded bias (ln_fold_rows_launch).
+struct LnProjArgs {
+  int mode = 0;
+  int M = 0;
+  const bf16_t* X = nullptr;       // [M][K1]
+  bf16_t* T = nullptr;             // [M][320] residual stream (written; mode 1: read as the residual first)
+  const bf16_t* W1 = nullptr;      // [320][K1]
+  const float* b1 = nullptr;       // [320]
+  const bf16_t* W2p = nullptr;     // [nseg * 384][320], K order permuted
+  const float* c2 = nullptr;       // [nseg * 384]
+  float ln_eps = 1e-5f;
+  bf16_t *Cq = nullptr, *Ck = nullptr, *Cvt = nullptr;       // GemmArgs' OUT_QKV layout
+  int heads = 0, dp = 0, dpv = 0, ntok = 0, ntok_pad = 0, seg_base = 0;
+  float qscale = 1.f;
+};
+bool lnproj_supported(int C, int M, int heads, int dp);
+int lnproj_kperm_launch(const bf16_t* src, int N, bf16_t* dst, hipStream_t s);
+int lnproj_launch(const LnProjArgs& a, hipStream_t s);
+
 // LayerNorm over the last dim (eps inside sqrt), fp32 or bf16 rows in, bf16 rows out.
 int layernorm_launch(const void* x, int x_f32, const float* gamma, const float* beta, bf16_t* y,
                      int rows, int C, float eps, hipStream_t s);

@@ -57,6 +57,7 @@ struct XfW {  // Transformer2DModel with one BasicTransformerBlock
   LinW out2;
   bf16_t* wff1 = nullptr; float* bff1 = nullptr;   // GEGLU-permuted [8C][C]
   bf16_t* w1c = nullptr; float* b1c = nullptr; bf16_t* w2p = nullptr;   // the same weights as the fused feed-forward kernel reads them (ffn.hip; C = 320 only)
+  bf16_t *wqkv1p = nullptr, *wq2p = nullptr;   // wqkv1 / wq2 (LayerNorm-folded) with the K order of the fused projection pairs (lnproj.hip; C = 320 only)
   // norm1/2/3 are folded into wqkv1 / wq2 / wff1 at load (GemmArgs::ln_stats): column sums of g*W and beta.W^T (+ bias)
   float *s_qkv1 = nullptr, *c_qkv1 = nullptr, *s_q2 = nullptr, *c_q2 = nullptr, *s_ff1 = nullptr;
   LinW ff2;                   // [C][4C]
@@ -217,6 +218,11 @@ __global__ __launch_bounds__(256) void ffo_fuse_kernel(const void* wp, int dt_p,
 
 // The feed-forward sub-blocks at C = 320 (level 0) run as one kernel (ffn.hip) instead of GEGLU + the two-source ffo GEMM: loop
 // 528.9 -> 522.8 ms.  GILL_UNET_FFN_FUSED = 0 restores the two GEMMs.
+// GILL_UNET_LNPROJ=0: proj_in / QKV and attn1.to_out / attn2.to_q of the level-0 blocks as the separate GEMMs
+static bool lnproj_on() {
+  static const bool on = [] { const char* e = getenv("GILL_UNET_LNPROJ"); return !(e && e[0] == '0'); }();
+  return on;
+}
 static bool ffn_fused_on() {
   static const bool on = [] { const char* e = getenv("GILL_UNET_FFN_FUSED"); return !(e && e[0] == '0'); }();
   return on;
@@ -379,6 +385,12 @@ struct Loader {
       GILL_TRY(pool.alloc(&x->b1c, (size_t)8 * C, false));
       GILL_TRY(pool.alloc(&x->w2p, (size_t)4 * C * C, false));
       GILL_TRY(ffn_relayout_launch(x->wff1, x->bff1, x->wfo, x->w1c, x->b1c, x->w2p, s));
+    }
+    if (lnproj_on() && lnproj_supported(C, 128, H, x->dp)) {
+      GILL_TRY(pool.alloc(&x->wqkv1p, (size_t)3 * hdp * C, false));
+      GILL_TRY(pool.alloc(&x->wq2p, (size_t)hdp * C, false));
+      GILL_TRY(lnproj_kperm_launch(x->wqkv1, 3 * hdp, x->wqkv1p, s));
+      GILL_TRY(lnproj_kperm_launch(x->wq2, hdp, x->wq2p, s));
     }
     return 0;
   }
@@ -718,6 +730,9 @@ struct UNetRun {
     const int H = x.H, Wd = x.W, C = w.C, HW = H * Wd, M = Bfull * HW, M1 = Bpre * HW;
     const int nh = w.heads, hdp = nh * w.dp;
     const bool ffn_fused = w.w1c != nullptr && ffn_fused_supported(C, M) && HW % 128 == 0;
+    // proj_in + norm1 + QKV, and attn1.to_out + residual + norm2 + attn2.to_q, as one kernel each (lnproj.hip).  Not on the shared-prefix
+    // block: its M1 = M / 2 rows are 128 tiles for 256 CUs — one tile per CU takes as long as at full size, the two GEMMs take half.
+    const bool lnproj = w.wqkv1p != nullptr && !shared && lnproj_supported(C, M, nh, w.dp) && HW % 32 == 0;
     *out = talloc(H, Wd, C, out_stats);
     const size_t mk = m->arena.mark();
     Tensor n = talloc(H, Wd, C);
@@ -730,14 +745,20 @@ struct UNetRun {
     // norm1/2/3 never materialise: the GEMM that writes the residual stream also accumulates each row's sum and sum of
     // squares, and the projection that follows applies mean / rstd in its epilogue on weights pre-multiplied by the LN gain
     RowStats st1 = ln_slot(M, C), st2 = ln_slot(M, C), st3 = ln_slot(M, C);
-    GILL_TRY(linear(n.p, C, nullptr, 0, C, M1, w.proj_in.w, w.proj_in.b, C, C, nullptr, ACT_NONE, t.p, C, nullptr, &st1));
+    if (!lnproj) GILL_TRY(linear(n.p, C, nullptr, 0, C, M1, w.proj_in.w, w.proj_in.b, C, C, nullptr, ACT_NONE, t.p, C, nullptr, &st1));
     const int hw_pad = round_up(HW, 32);   // kv tiles are 32 wide; pad rows hold finite stale data and are masked
     bf16_t* q = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * nh * hw_pad * w.dp);
     bf16_t* k = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * nh * hw_pad * w.dp);
     bf16_t* vt = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * nh * w.dpv * hw_pad);
     bf16_t* o = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)M * hdp);
     // --- self attention
-    {
+    LnProjArgs lp;
+    lp.M = M; lp.T = t.p; lp.heads = nh; lp.dp = w.dp; lp.dpv = w.dpv; lp.ntok = HW; lp.ntok_pad = hw_pad;
+    lp.Cq = q; lp.Ck = k; lp.Cvt = vt; lp.qscale = 1.4426950408889634f / sqrtf((float)w.d);
+    if (lnproj) {
+      lp.mode = 0; lp.X = n.p; lp.W1 = w.proj_in.w; lp.b1 = w.proj_in.b; lp.W2p = w.wqkv1p; lp.c2 = w.c_qkv1;
+      if (!dry) GILL_TRY(lnproj_launch(lp, s));
+    } else {
       GemmArgs g;
       g.M = M1; g.N = 3 * hdp; g.K = C; g.K1 = C; g.A = t.p; g.lda = C; g.W = w.wqkv1;
       g.ln_stats = st1.p; g.ln_planes = st1.planes; g.ln_colsum = w.s_qkv1; g.bias = w.c_qkv1;
@@ -778,6 +799,10 @@ struct UNetRun {
       }
       tres = t2.p;
     } else {
+    if (lnproj) {
+      lp.mode = 1; lp.X = o; lp.W1 = w.out1.w; lp.b1 = w.out1.b; lp.W2p = w.wq2p; lp.c2 = w.c_q2;
+      if (!dry) GILL_TRY(lnproj_launch(lp, s));
+    } else {
     GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M1, w.out1.w, w.out1.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, &st2));
     if (shared && !dry) {
       // second half of the pair := first half (residual stream, its LayerNorm row sums, the block input)
@@ -793,6 +818,7 @@ struct UNetRun {
       g.ntok = HW; g.ntok_pad_q = hw_pad; g.ntok_pad_kv = hw_pad; g.seg_base = 0;
       g.qscale = 1.4426950408889634f / sqrtf((float)w.d);
       GILL_TRY(gemm(g));
+    }
     }
     GILL_TRY(attend(q, m->kcache[w.layer_id], m->vcache[w.layer_id], o, HW, m->cfg.ctx_len, hw_pad, m->ctx_pad, w));
     GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M, w.out2.w, w.out2.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, &st3));
@@ -1284,6 +1310,51 @@ extern "C" int gill_op_ffn_fused(const void* t, const float* ln_g, const float* 
   fa.gn_stats = gn_stats; fa.rows_per_batch = rows_per_batch;
   static const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
   for (int r = 0; r < rep; ++r) GILL_TRY(ffn_fused_launch(fa, s));
+  GILL_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Operator-level entry for the fused projection pairs around norm1 / norm2 of a level-0 block (lnproj.hip) on NATURAL operands
+// (unpadded heads, plain LayerNorm parameters): pads / folds / permutes them exactly as the engine's loader does, launches the kernel.
+//   mode 0: t = W1 . x + b1;  [q | k | v] = W2 . LN(t)            x [M][320], W2 [3 * 320][320] = to_q | to_k | to_v rows
+//   mode 1: t = W1 . x + b1 + t;  q = W2 . LN(t)                  x [M][320] = the attention output (heads x 40), W2 [320][320]
+// q, k: [B][8][hw_pad][48] (q scaled by log2(e) / sqrt(40)); vt: [B][8][64][hw_pad] with row 48 = 1.  For tests and tools; synchronises.
+extern "C" int gill_op_lnproj(int mode, const void* x, void* t, const void* W1, const float* b1, const float* ln_g, const float* ln_b,
+                              const void* W2, void* q, void* k, void* vt, int B, int HW, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int C = 320, heads = 8, d = 40, dp = attn_padded_dim(d), dpv = round_up(dp, 32), hdp = heads * dp, M = B * HW;
+  const int nseg = mode == 0 ? 3 : 1;
+  GILL_REQUIRE(mode == 0 || mode == 1, "mode must be 0 or 1");
+  GILL_REQUIRE(x && t && W1 && b1 && ln_g && ln_b && W2 && q && (mode == 1 || (k && vt)), "null argument");
+  GILL_REQUIRE(lnproj_supported(C, M, heads, dp), "lnproj: B * HW must be a multiple of 128");
+  DevBuf xp, w1p, w2, w2p, cs, cb;
+  GILL_TRY(w2.alloc_zero(sizeof(bf16_t) * (size_t)nseg * hdp * C, s));
+  GILL_TRY(w2p.alloc(sizeof(bf16_t) * (size_t)nseg * hdp * C));
+  GILL_TRY(cs.alloc_zero(sizeof(float) * (size_t)nseg * hdp, s));
+  GILL_TRY(cb.alloc_zero(sizeof(float) * (size_t)nseg * hdp, s));
+  for (int sg = 0; sg < nseg; ++sg)
+    hipLaunchKernelGGL(pad_head_rows_kernel, dim3(1024), dim3(256), 0, s, (const void*)((const bf16_t*)W2 + (size_t)sg * C * C), 0, heads, d, dp, C,
+                       (bf16_t*)w2.p + (size_t)sg * hdp * C);
+  GILL_CHECK_HIP(hipGetLastError());
+  GILL_TRY(ln_fold_rows_launch((bf16_t*)w2.p, nseg * hdp, C, ln_g, ln_b, (float*)cs.p, (float*)cb.p, s));
+  GILL_TRY(lnproj_kperm_launch((const bf16_t*)w2.p, nseg * hdp, (bf16_t*)w2p.p, s));
+  LnProjArgs a;
+  a.mode = mode; a.M = M; a.T = (bf16_t*)t; a.b1 = b1; a.W2p = (const bf16_t*)w2p.p; a.c2 = (const float*)cb.p;
+  a.Cq = (bf16_t*)q; a.Ck = (bf16_t*)k; a.Cvt = (bf16_t*)vt; a.heads = heads; a.dp = dp; a.dpv = dpv; a.ntok = HW; a.ntok_pad = round_up(HW, 32);
+  a.qscale = 1.4426950408889634f / sqrtf((float)d);
+  if (mode == 0) {
+    a.X = (const bf16_t*)x; a.W1 = (const bf16_t*)W1;
+  } else {
+    GILL_TRY(xp.alloc_zero(sizeof(bf16_t) * (size_t)M * hdp, s));
+    GILL_TRY(w1p.alloc_zero(sizeof(bf16_t) * (size_t)C * hdp, s));
+    hipLaunchKernelGGL(pad_head_cols_kernel, dim3(1024), dim3(256), 0, s, x, 0, M, heads, d, dp, (bf16_t*)xp.p);
+    hipLaunchKernelGGL(pad_head_cols_kernel, dim3(1024), dim3(256), 0, s, W1, 0, C, heads, d, dp, (bf16_t*)w1p.p);
+    GILL_CHECK_HIP(hipGetLastError());
+    a.X = (const bf16_t*)xp.p; a.W1 = (const bf16_t*)w1p.p;
+  }
+  static const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
+  for (int r = 0; r < rep; ++r) GILL_TRY(lnproj_launch(a, s));
   GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
 }

@@ -208,3 +208,23 @@ def ffn_fused(t: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, w1: torch
   N.check(N.lib().gill_op_ffn_fused(N.ptr(t), N.ptr(ln_g), N.ptr(ln_b), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(b2), N.ptr(wp), N.ptr(bp),
                                     N.ptr(resid), N.ptr(out), N.ptr(stats), M, rows_per_batch, N.current_stream()))
   return (out, stats) if rows_per_batch else out
+
+
+def lnproj(mode: int, x: torch.Tensor, t, w1: torch.Tensor, b1: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, w2: torch.Tensor,
+           B: int, HW: int):
+  """The two projections around norm1 (mode 0) / norm2 (mode 1) of a C = 320, 8-head transformer block as one kernel (csrc/lnproj.hip).
+  mode 0: t = x @ w1.T + b1; q, k, v = LN(t) @ w2.T with w2 (960, 320) = to_q | to_k | to_v.  mode 1: t = t + x @ w1.T + b1 (x = the
+  attention output); q = LN(t) @ w2.T with w2 (320, 320).  Returns (t (M, 320) bf16, q, k, vt) in the attention kernels' layouts
+  (q, k (B, 8, hw_pad, 48), q pre-scaled by log2(e) / sqrt(40); vt (B, 8, 64, hw_pad) with row 48 = 1); k, vt None in mode 1."""
+  x, w1, w2 = (_bf(v) for v in (x, w1, w2))
+  M = B * HW
+  hw_pad = (HW + 31) // 32 * 32
+  t = torch.empty((M, 320), device=x.device, dtype=torch.bfloat16) if mode == 0 else _bf(t).clone()
+  q = torch.zeros((B, 8, hw_pad, 48), device=x.device, dtype=torch.bfloat16)
+  k = torch.zeros_like(q) if mode == 0 else None
+  vt = torch.zeros((B, 8, 64, hw_pad), device=x.device, dtype=torch.bfloat16) if mode == 0 else None
+  f = lambda v: v.float().contiguous()
+  b1, ln_g, ln_b = f(b1), f(ln_g), f(ln_b)
+  N.check(N.lib().gill_op_lnproj(mode, N.ptr(x), N.ptr(t), N.ptr(w1), N.ptr(b1), N.ptr(ln_g), N.ptr(ln_b), N.ptr(w2), N.ptr(q), N.ptr(k),
+                                 N.ptr(vt), B, HW, N.current_stream()))
+  return t, q, k, vt

@@ -256,6 +256,16 @@ int gill_op_ffn_fused(const void* t_bf16, const float* ln_g, const float* ln_b, 
                       const void* W2_bf16, const float* b2, const void* Wp_bf16, const float* bp, const void* resid_bf16,
                       void* out_bf16, float* gn_stats, int M, int rows_per_batch, void* stream);
 
+/* The two projections around norm1 / norm2 of a level-0 (C = 320, 8 heads of 40) transformer block as one kernel (csrc/lnproj.hip), on
+ * natural (diffusers-layout) operands.  mode 0: t = proj_in(x); [q | k | v] = [to_q; to_k; to_v](LN(t)) (W2 = the three weights stacked,
+ * (960, 320)).  mode 1: t += to_out(x) + b1 (in place, x = the attention output); q = to_q(LN(t)) (W2 (320, 320)).  Outputs in the
+ * attention kernels' layouts: q, k [B][8][hw_pad][48] bf16 (q pre-scaled by log2(e) / sqrt(40)), vt [B][8][64][hw_pad] (row 48 = 1);
+ * hw_pad = HW rounded up to 32; B * HW a multiple of 128.  Replaces, inside gill_unet_forward, Transformer2DModel.proj_in + norm1 +
+ * attn1.to_q/k/v, resp. attn1.to_out + residual + norm2 + attn2.to_q of diffusers (reference call site: gill/custom_sd.py:633-638).
+ * Synchronises. */
+int gill_op_lnproj(int mode, const void* x_bf16, void* t_bf16, const void* W1_bf16, const float* b1, const float* ln_g, const float* ln_b,
+                   const void* W2_bf16, void* q_bf16, void* k_bf16, void* vt_bf16, int B, int HW, void* stream);
+
 int gill_op_conv3x3_fp8(const void* x_bf16, const float* w_oihw, const float* bias, const void* resid_bf16, void* y_bf16,
                         int B, int H, int W, int Cin, int Cout, int splitk, void* stream);
 

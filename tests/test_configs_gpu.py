@@ -243,9 +243,11 @@ def test_fused_cross_attention_block_matches_the_four_launch_graph(cuda, tmp_pat
     assert rel < bar and cos > 0.999, f"{key}: rel-L2 {rel:.3e}"
 
 
-def test_ffn_fused_switch_full_size_forward(cuda):
-  """GILL_UNET_FFN_FUSED (read once per process): one full-size SD-1.5 forward with the level-0 feed-forward sub-blocks as the fused
-  kernel (default) and as GEGLU + the two-source GEMM, in two subprocesses on the same seeded weights.  Both forms have their oracle
+@pytest.mark.parametrize("switch", ["GILL_UNET_FFN_FUSED", "GILL_UNET_LNPROJ"])
+def test_fused_block_switches_full_size_forward(cuda, switch):
+  """GILL_UNET_FFN_FUSED / GILL_UNET_LNPROJ (read once per process): one full-size SD-1.5 forward with the level-0 feed-forward sub-blocks as the fused
+  kernel (default) and as GEGLU + the two-source GEMM — resp. with the projection pairs around norm1 / norm2 as one kernel each (lnproj.hip,
+  default) and as separate GEMMs — in two subprocesses on the same seeded weights.  Both forms have their oracle
   tests (the default one in every full-size test of this file); here they must agree with each other to the distance either has from
   the oracle."""
   import tempfile
@@ -260,10 +262,10 @@ def test_ffn_fused_switch_full_size_forward(cuda):
   with tempfile.TemporaryDirectory() as d:
     for sw in ("0", "1"):
       f = os.path.join(d, f"y{sw}.pt")
-      r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, GILL_UNET_FFN_FUSED=sw), capture_output=True, text=True,
+      r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **{switch: sw}), capture_output=True, text=True,
                          timeout=900)
       assert r.returncode == 0, r.stderr[-2000:]
       outs.append(torch.load(f))
   assert torch.isfinite(outs[1]).all() and not torch.equal(outs[0], outs[1])       # (the switch did switch)
-  _, rel, cos = _stats("full-size forward: fused feed-forward blocks vs GEGLU + ffo GEMMs", outs[1], outs[0])
+  _, rel, cos = _stats(f"full-size forward: {switch} on vs off", outs[1], outs[0])
   assert rel < 1.5e-2 and cos > 0.9995

@@ -409,3 +409,48 @@ def test_ffn_fused_vs_torch(cuda, M, rows_per_batch):
   want = torch.stack([o.sum(dim=(1, 3)), (o * o).sum(dim=(1, 3))], dim=-1)
   got = stats.cpu()
   assert torch.allclose(got, want, rtol=2e-4, atol=2e-3), float((got - want).abs().max())
+
+
+# ---------------------------------------------------------------- fused projection pairs around norm1 / norm2 (csrc/lnproj.hip)
+@pytest.mark.parametrize("B,HW", [(1, 128), (2, 192), (2, 1024)])
+def test_lnproj_proj_in_qkv_vs_torch(cuda, B, HW):
+  """Transformer2DModel.proj_in -> norm1 -> attn1.to_q / to_k / to_v at C = 320 (8 heads of 40) as one kernel: the residual stream and the
+  head-major q / k / v^T it scatters (padded head dim 48, q pre-scaled, spare V^T row = 1) against the fp32 restatement on the same
+  bf16-rounded operands.  Ref: diffusers Transformer2DModel / BasicTransformerBlock as restated in oracle/unet_ref.py:_transformer."""
+  from gill_amd import ops
+  C, nh, d, M = 320, 8, 40, B * HW
+  hw_pad = (HW + 31) // 32 * 32
+  x = _bf(_rnd((M, C), 70))
+  w1, b1 = _bf(_rnd((C, C), 71, 0.08)), 0.2 * _rnd((C,), 72)
+  ln_g, ln_b = 1.0 + 0.2 * _rnd((C,), 73), 0.1 * _rnd((C,), 74)
+  w2 = _bf(_rnd((3 * C, C), 75, 0.06))
+  t_ref = x.float() @ w1.float().T + b1
+  tb = _bf(t_ref).float()                       # (the kernel normalises the ROUNDED residual stream, as every other consumer reads it)
+  qkv = F.layer_norm(tb, (C,), ln_g, ln_b, 1e-5) @ w2.float().T
+  t, q, k, vt = ops.lnproj(0, x.to(cuda), None, w1.to(cuda), b1.to(cuda), ln_g.to(cuda), ln_b.to(cuda), w2.to(cuda), B, HW)
+  assert _report(f"lnproj mode 0 t B={B} HW={HW}", t, t_ref) < 6e-3
+  heads = lambda v: v.view(B, HW, nh, d).permute(0, 2, 1, 3)                      # (B, h, tok, d)
+  qs = 1.4426950408889634 / d ** 0.5
+  assert _report("lnproj q", q[:, :, :HW, :d], heads(qkv[:, :C]) * qs) < 1e-2
+  assert _report("lnproj k", k[:, :, :HW, :d], heads(qkv[:, C:2 * C])) < 1e-2
+  assert _report("lnproj v^T", vt[:, :, :d, :HW], heads(qkv[:, 2 * C:]).transpose(2, 3)) < 1e-2
+  assert float(q[:, :, :HW, d:].float().abs().max()) == 0 and float(k[:, :, :HW, d:].float().abs().max()) == 0
+  assert torch.all(vt[:, :, 48, :HW].float() == 1.0)
+
+
+@pytest.mark.parametrize("B,HW", [(1, 128), (2, 1024)])
+def test_lnproj_to_out_to_q_vs_torch(cuda, B, HW):
+  """attn1.to_out + residual -> norm2 -> attn2.to_q as one kernel, against the fp32 restatement on the same bf16-rounded operands."""
+  from gill_amd import ops
+  C, nh, d, M = 320, 8, 40, B * HW
+  o = _bf(_rnd((M, C), 80))
+  t0 = _bf(_rnd((M, C), 81, 1.5) + 0.2)
+  w1, b1 = _bf(_rnd((C, C), 82, 0.08)), 0.2 * _rnd((C,), 83)
+  ln_g, ln_b = 1.0 + 0.2 * _rnd((C,), 84), 0.1 * _rnd((C,), 85)
+  w2 = _bf(_rnd((C, C), 86, 0.06))
+  t_ref = o.float() @ w1.float().T + b1 + t0.float()
+  q_ref = F.layer_norm(_bf(t_ref).float(), (C,), ln_g, ln_b, 1e-5) @ w2.float().T
+  t, q, _, _ = ops.lnproj(1, o.to(cuda), t0.to(cuda), w1.to(cuda), b1.to(cuda), ln_g.to(cuda), ln_b.to(cuda), w2.to(cuda), B, HW)
+  assert _report(f"lnproj mode 1 t B={B} HW={HW}", t, t_ref) < 6e-3
+  qs = 1.4426950408889634 / d ** 0.5
+  assert _report("lnproj q2", q[:, :, :HW, :d], q_ref.view(B, HW, nh, d).permute(0, 2, 1, 3) * qs) < 1e-2
