@@ -35,6 +35,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // access WITHOUT alias info (float4 / uint4 are structs: none) wait for every LDS-DMA in flight — s_waitcnt vmcnt(0), the ring drained
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #ifndef LP_ABL
 #define LP_ABL 0
 #endif
@@ -53,9 +54,15 @@ constexpr int lp_tiles(int mode, int g) { return lp_pieces(mode, g); }          
 // pieces that may stay outstanding when stage g + 1 must have landed (in front of step 3 of stage g): all of stages g+2 .. g+5 and the
 // three pieces of stage g + 6 issued in steps 0 .. 2
 // ... and, vmcnt on gfx9 counting stores too (in issue order with the loads), the epilogue stores issued in that window: the 20 of the
-// residual stream in front of stage G1, the 24 of the Q / K scatter in front of a later segment's first stage (6-bit counter: capped)
+// residual stream in front of stage G1, those of a segment's scatter in front of the next segment's first stage (6-bit counter: capped)
+// segment computed in slot k of the second GEMM: mode 0 runs V, K, Q — the V^T tile is stored in 64-B runs (its rows are tokens), the Q / K
+// tiles in 1-KiB runs; the scatter of the LAST segment has nothing to hide behind
+constexpr int lp_seg(int mode, int k) { return mode == 0 ? 2 - k : 0; }
+constexpr int lp_scatter_stores(int seg) { return seg == 2 ? 32 : 24; }
 constexpr int lp_stores_before(int mode, int g) {
-  return g == lp_g1(mode) ? 20 : (g > lp_g1(mode) && g < lp_nst(mode) && (g - lp_g1(mode)) % 15 == 0 ? 24 : 0);
+  if (g == lp_g1(mode)) return 20;
+  if (g > lp_g1(mode) && g < lp_nst(mode) && (g - lp_g1(mode)) % 15 == 0) return lp_scatter_stores(lp_seg(mode, (g - lp_g1(mode)) / 15 - 1));
+  return 0;
 }
 constexpr int lp_waitn(int mode, int g) {
   int n = lp_pieces(mode, g + 2) + lp_pieces(mode, g + 3) + lp_pieces(mode, g + 4) + lp_pieces(mode, g + 5) + (lp_pieces(mode, g + 6) ? 3 : 0);
@@ -63,12 +70,17 @@ constexpr int lp_waitn(int mode, int g) {
   return n > 63 ? 63 : n;
 }
 
-
 // LDS writes of the per-wave staging patch as inline asm: for a compiler-visible LDS store the waitcnt pass assumes it may overwrite
 // what an LDS-DMA in flight writes and drains the whole queue (s_waitcnt vmcnt(0)) in front of it.  LDS executes a wave's accesses in
 // order, so the compiler-emitted reads behind these see the data; the "memory" clobber keeps them behind.
 __device__ __forceinline__ void lds_write_b64(unsigned addr, uint2 v) {
   asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_write_b32(unsigned addr, float v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_write_b128(unsigned addr, u32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 __device__ __forceinline__ void lds_write_b16_pair(unsigned addr, unsigned v) {       // low half -> addr, high half -> addr + 64
   asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:64" ::"v"(addr), "v"(v) : "memory");
@@ -89,7 +101,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto slab_of = [&](int g) -> Slab {
     if (g < G1) { const int u = g / KS1, j = g - u * KS1; return Slab{p.W1 + (size_t)u * 160 * K1 + 64 * j, K1}; }
     const int h = g - G1, seg = h / 15, r = h - seg * 15, chunk = r / 5, j = r - chunk * 5;
-    return Slab{p.W2p + (size_t)(seg * LSEG + chunk * 128) * LC + 64 * j, LC};
+    return Slab{p.W2p + (size_t)(lp_seg(MODE, seg) * LSEG + chunk * 128) * LC + 64 * j, LC};
   };
   auto issue_piece = [&](const Slab& st, int slot, int i) {
     const int pc = w + 4 * i;
@@ -109,28 +121,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < 5; ++i)
       if (i < lp_pieces(MODE, g)) issue_piece(st, g % LNSLOT, i);
   }
-  // (operand loads BEHIND the first stages' LDS-DMA: one memory latency in front of the stream instead of two)
-  // ---- first GEMM's B operand: rows of X (n, or the attention output o), k16 step s -> X[m][16 s + 8 hi .. +8]
+  __builtin_amdgcn_sched_barrier(0);      // (pins the issue order the counted waits below rely on)
+  // ---- operand loads BEHIND the first stages' LDS-DMA (one memory latency in front of the stream instead of two), oldest first in the
+  // order they are needed: tables, residual rows, X fragments.
+  // Branch-free (clamped index, the surplus threads rewrite the last entry): under a predicate the compiler sinks the load into the
+  // branch, where it is the newest memory operation and its wait a full vmcnt(0).
+  float tb1[2], tc2[(NSEG * LSEG + 255) / 256];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) tb1[j] = p.b1[min(tid + 256 * j, LC - 1)];
+#pragma unroll
+  for (int j = 0; j < (NSEG * LSEG + 255) / 256; ++j) tc2[j] = p.c2[min(tid + 256 * j, NSEG * LSEG - 1)];
+  __builtin_amdgcn_sched_barrier(0);      // (the scheduler reorders independent loads freely: fences between the three groups)
+  // MODE 1: the residual rows, 16 B per lane over 64-B runs (row lane / 4 (+ 16), part lane % 4 of each 32-column tile); they reach the
+  // accumulator layout (lane (m, hi): columns 32 i + 8 q4 + 4 hi .. +3) through the wave's LDS patch
+  u32x4 res[MODE == 1 ? 20 : 1];
+  if constexpr (MODE == 1) {
+    const bf16_t* tsrc = p.T + (size_t)(blockIdx.x * LTM + w * 32 + (lane >> 2)) * LC + (lane & 3) * 8;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      res[2 * i] = (LP_ABL & 32) ? u32x4{0, 0, 0, 0} : *reinterpret_cast<const u32x4*>(tsrc + 32 * i);
+      res[2 * i + 1] = (LP_ABL & 32) ? u32x4{0, 0, 0, 0} : *reinterpret_cast<const u32x4*>(tsrc + 32 * i + 16 * LC);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // first GEMM's B operand: rows of X (n, or the attention output o), k16 step s -> X[m][16 s + 8 hi .. +8]
   bf16x8 xf[K1 / 16];
 #pragma unroll
   for (int s = 0; s < K1 / 16; ++s) xf[s] = (LP_ABL & 64) ? bf16x8{1, 2, 3, 4, 5, 6, 7, 8} : *reinterpret_cast<const bf16x8*>(p.X + (size_t)((LP_ABL & 4) ? (m & 31) : m) * K1 + 16 * s + 8 * hi);
-  // MODE 1: the residual rows in the accumulator layout (lane (m, hi): columns 32 i + 8 q4 + 4 hi .. +3)
-  uint2 res[MODE == 1 ? 40 : 1];
-  if constexpr (MODE == 1) {
-#pragma unroll
-    for (int i = 0; i < 10; ++i)
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) res[4 * i + q4] = (LP_ABL & 32) ? make_uint2(0, 0) : *reinterpret_cast<const uint2*>(p.T + (size_t)((LP_ABL & 4) ? (m & 31) : m) * LC + 32 * i + 8 * q4 + 4 * hi);
-  }
   {
     float* bt = reinterpret_cast<float*>(smem + LBIAS_OFF);
-    for (int i = tid; i < LC; i += 256) bt[i] = p.b1[i];
-    for (int i = tid; i < NSEG * LSEG; i += 256) bt[LC + i] = p.c2[i];
+    const unsigned bt_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)bt;
+    // everything has landed.  (Starting the first stages with the X fragments still in flight would hide ~2 us, but with LDS-DMA
+    // interleaved the compiler's own waits for loaded registers come out as vmcnt(0) instead of counted — measured in the ISA — and a full
+    // wait inside stage 0 drains the ring.)
+    lp_wait_vm<0>();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) lds_write_b32(bt_lds + 4 * min(tid + 256 * j, LC - 1), tb1[j]);
+#pragma unroll
+    for (int j = 0; j < (NSEG * LSEG + 255) / 256; ++j) lds_write_b32(bt_lds + 4 * (LC + min(tid + 256 * j, NSEG * LSEG - 1)), tc2[j]);
   }
   const float* b1t = reinterpret_cast<const float*>(smem + LBIAS_OFF);
   const float* c2t = b1t + LC;
-
-  lp_wait_vm<0>();         // (also covers xf / res: see ffn.hip)
 
   bf16x8 wf[2][5];
   // one stage with a compile-time index G; mma(s, fragments) issues the MFMAs of k16 step s
@@ -188,18 +219,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   {
     f32x16 acc1[10];
 #pragma unroll
-    for (int i = 0; i < 10; ++i)
+    for (int i = 0; i < 10; ++i) {
+      if constexpr (MODE == 1) {
+        lds_write_b128(wb_lds + (lane >> 2) * 80 + (lane & 3) * 16, res[2 * i]);
+        lds_write_b128(wb_lds + (lane >> 2) * 80 + (lane & 3) * 16 + 16 * 80, res[2 * i + 1]);
+      }
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(b1t + 32 * i + 8 * q4 + 4 * hi);
         float v0 = bv.x, v1 = bv.y, v2 = bv.z, v3 = bv.w;
         if constexpr (MODE == 1) {
-          const uint2 r = res[4 * i + q4];
+          const u32x2 r = *reinterpret_cast<const u32x2*>(wb + l31 * 80 + q4 * 16 + hi * 8);
           v0 += __uint_as_float(r.x << 16); v1 += __uint_as_float(r.x & 0xffff0000u);
           v2 += __uint_as_float(r.y << 16); v3 += __uint_as_float(r.y & 0xffff0000u);
         }
         acc1[i][4 * q4] = v0; acc1[i][4 * q4 + 1] = v1; acc1[i][4 * q4 + 2] = v2; acc1[i][4 * q4 + 3] = v3;
       }
+    }
 #pragma unroll
     for (int q = 0; q < 5; ++q) wf[0][q] = wfrag(smem, q, 0);
     auto stages1 = [&](auto... gs) {
@@ -273,7 +309,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   [&]<int... SG>(std::integer_sequence<int, SG...>) {
     ([&] {
-      constexpr int SEG = SG;                // 0 -> Q (scaled), 1 -> K, 2 -> V^T   (dp == 48: head and element of a column are static)
+      constexpr int SIDX = SG;               // position in the run order
+      constexpr int SEG = lp_seg(MODE, SIDX);  // 0 -> Q (scaled), 1 -> K, 2 -> V^T   (dp == 48: head and element of a column are static)
       f32x16 acc2[12];
 #pragma unroll
       for (int i = 0; i < 12; ++i)
@@ -283,10 +320,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           acc2[i][4 * q4] = c.x; acc2[i][4 * q4 + 1] = c.y; acc2[i][4 * q4 + 2] = c.z; acc2[i][4 * q4 + 3] = c.w;
         }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) wf[0][q] = wfrag(smem + ((G1 + SEG * 15) % LNSLOT) * LSLOT, q, 0);
+      for (int q = 0; q < 4; ++q) wf[0][q] = wfrag(smem + ((G1 + SIDX * 15) % LNSLOT) * LSLOT, q, 0);
       auto stages2 = [&](auto... gs) {
         (run_stage(gs, [&](int s, const bf16x8* wfp) {
-           constexpr int H = decltype(gs)::value - G1 - SEG * 15;
+           constexpr int H = decltype(gs)::value - G1 - SIDX * 15;
            constexpr int CH = H / 5, J = H % 5;
 #pragma unroll
            for (int q = 0; q < 4; ++q)
@@ -294,7 +331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
          }), ...);
       };
       [&]<int... I>(std::integer_sequence<int, I...>) {
-        stages2(std::integral_constant<int, G1 + SEG * 15 + I>{}...);
+        stages2(std::integral_constant<int, G1 + SIDX * 15 + I>{}...);
       }(std::make_integer_sequence<int, 15>{});
       // scatter, one head (48 columns = 6 groups of 8: group 6 h + g6 = tile (6h + g6) / 4, registers 4 ((6h + g6) % 4) .. +3) at a time
       if (!((LP_ABL & 1) || ((LP_ABL & 8) && SEG == 2) || ((LP_ABL & 16) && SEG < 2)) || p.M < 0) {
