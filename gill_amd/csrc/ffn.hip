@@ -37,6 +37,8 @@ constexpr int FSMEM = FBIAS_OFF + FNCH * 128 * 4;
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 template <int N> __device__ __forceinline__ void ffn_wait_vm() {
   // gfx9 s_waitcnt: vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14; expcnt / lgkmcnt left open
@@ -51,32 +53,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
   const int m = blockIdx.x * FTM + w * 32 + l31;            // this lane's row (M % 128 == 0: always valid)
-
-  // ---- t fragments (B operand): k16 step s -> t[m][16 s + 8 hi .. +8]
-  bf16x8 tf[20];
-#pragma unroll
-  for (int s = 0; s < 20; ++s) tf[s] = *reinterpret_cast<const bf16x8*>(p.T + (size_t)m * FC + 16 * s + 8 * hi);
-  // LayerNorm factors of the row (as ln_row_factors() in gemm.hip: planes added in plane order)
-  float ln_mean, ln_rstd;
-  {
-    const int R = p.ln_rows ? p.ln_rows : p.M;
-    const int mr = m >= R ? m - R : m;
-    const float* base = p.ln_stats + (size_t)mr * 2;
-    const size_t pstride = (size_t)R * 2;
-    float2 st = make_float2(0.f, 0.f);
-    for (int pl = 0; pl < p.ln_planes; ++pl) {
-      const float2 v = *reinterpret_cast<const float2*>(base + (size_t)pl * pstride);
-      st.x += v.x; st.y += v.y;
-    }
-    ln_mean = st.x * (1.f / FC);
-    const float var = fmaxf(st.y * (1.f / FC) - ln_mean * ln_mean, 0.f);
-    ln_rstd = rsqrtf(var + p.ln_eps);
-  }
-  // b1' table -> LDS
-  {
-    float* bt = reinterpret_cast<float*>(smem + FBIAS_OFF);
-    for (int i = tid; i < FNCH * 128; i += 256) bt[i] = p.b1c[i];
-  }
 
   // ---- LDS-DMA staging: piece pc of a stage covers slab rows 8pc .. 8pc+7 (1 KiB); lane: row 8pc + (lane >> 3), physical 16-B chunk
   // lane & 7 holds logical chunk (lane & 7) ^ (row & 7).  Wave w issues pieces w, w+4, w+8, ... (4 per wave for 128 rows, 5 for 160).
@@ -100,18 +76,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     return *reinterpret_cast<const bf16x8*>(slot + row * 128 + (((2 * s + hi) ^ (row & 7)) * 16));
   };
 
-  f32x16 out[10];
-#pragma unroll
-  for (int i = 0; i < 10; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) out[i][r] = 0.f;
-
+  // the first six stages' LDS-DMA goes out FIRST, the operand loads behind it: one memory latency in front of the stream instead of two
 #pragma unroll
   for (int f = 0; f < 6; ++f) {
     const Slab st = slab_f(f);
 #pragma unroll
     for (int i = 0; i < 5; ++i) issue_piece(st, f, i);
   }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- t fragments (B operand): k16 step s -> t[m][16 s + 8 hi .. +8]
+  bf16x8 tf[20];
+#pragma unroll
+  for (int s = 0; s < 20; ++s) tf[s] = *reinterpret_cast<const bf16x8*>(p.T + (size_t)m * FC + 16 * s + 8 * hi);
+  // LayerNorm factors of the row (as ln_row_factors() in gemm.hip: planes added in plane order)
+  float ln_mean, ln_rstd;
+  {
+    const int R = p.ln_rows ? p.ln_rows : p.M;
+    const int mr = m >= R ? m - R : m;
+    const float* base = p.ln_stats + (size_t)mr * 2;
+    const size_t pstride = (size_t)R * 2;
+    float2 st = make_float2(0.f, 0.f);
+    for (int pl = 0; pl < p.ln_planes; ++pl) {
+      const float2 v = *reinterpret_cast<const float2*>(base + (size_t)pl * pstride);
+      st.x += v.x; st.y += v.y;
+    }
+    ln_mean = st.x * (1.f / FC);
+    const float var = fmaxf(st.y * (1.f / FC) - ln_mean * ln_mean, 0.f);
+    ln_rstd = rsqrtf(var + p.ln_eps);
+  }
+  // b1' table -> LDS
+  {
+    float* bt = reinterpret_cast<float*>(smem + FBIAS_OFF);
+    static_assert(FNCH * 128 % 256 == 0, "table fill: whole rounds of the workgroup");
+    float tb[FNCH * 128 / 256];
+#pragma unroll
+    for (int j = 0; j < FNCH * 128 / 256; ++j) tb[j] = p.b1c[tid + 256 * j];
+#pragma unroll
+    for (int j = 0; j < FNCH * 128 / 256; ++j) bt[tid + 256 * j] = tb[j];
+  }
+
+  f32x16 out[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[i][r] = 0.f;
+
   // one explicit full wait: it also covers the t fragments and the row sums (without it the compiler cannot prove inside the loop that
   // those registers have landed and fences the first MFMA of EVERY stage with vmcnt(0))
   ffn_wait_vm<0>();
@@ -257,34 +266,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int c = 0; c + 1 < FNCH; ++c) run_chunk(c, std::false_type{});
   run_chunk(FNCH - 1, std::true_type{});
 
-  // ---- epilogue: + bias + outer residual, bf16.  Lane (m, hi) holds columns n = tile * 32 + 8 q4 + 4 hi .. +3 of its row.  With gn_stats
-  // the rounded values also go to an LDS tile (the ring is dead; rows 648 B apart: the 32 row lanes of an 8-byte ds_write then hit distinct
-  // banks) from which the GroupNorm partial sums of the output are formed: per (64-row slab, column) over the rows, then per bin of
-  // 5 columns — every sum in a fixed order, written once: the layout fuse_stats() consumers read (GemmArgs::gn_stats).
-  constexpr int OSTR = 648;
-  bf16_t* orow = p.out + (size_t)m * FC;
-  const bf16_t* rrow = p.resid + (size_t)m * FC;
-  if (p.gn_stats) __syncthreads();          // every wave is done with the ring
-  unsigned char* otile = smem + (size_t)(w * 32 + l31) * OSTR;
+  // ---- epilogue: + bias + outer residual, bf16.  Lane (m, hi) holds columns n = tile * 32 + 8 q4 + 4 hi .. +3 of its row: moved in that
+  // layout, the residual / the output are 8-B pieces of 32 different rows per instruction, and with one wave per SIMD (every workgroup of
+  // the launch in the same phase) the memory pipeline's time for them is fully exposed.  The ring is dead: both go through an LDS tile
+  // (rows OSTR B apart), as 16 B per lane over the wave's 32 x 640 B = 20 KiB contiguous rows.  The tile then also feeds the GroupNorm
+  // partial sums of the output: per (64-row slab, column) over the rows, then per bin of 5 columns — every sum in a fixed order, written
+  // once: the layout fuse_stats() consumers read (GemmArgs::gn_stats).
+  constexpr int OSTR = 656;                      // 16-B aligned rows; 164 words: the 32 row lanes of an 8-byte access spread over the banks
+  __syncthreads();                               // every wave is done with the ring
+  unsigned char* wtile = smem + (size_t)(w * 32) * OSTR;          // this wave's 32 rows
+  unsigned char* otile = wtile + (size_t)l31 * OSTR;
+  {
+    const bf16_t* rsrc = p.resid + (size_t)(blockIdx.x * FTM + w * 32) * FC;
+    u32x4 rr[20];
+#pragma unroll
+    for (int j = 0; j < 20; ++j) rr[j] = *reinterpret_cast<const u32x4*>(rsrc + (size_t)(lane + 64 * j) * 8);
+#pragma unroll
+    for (int j = 0; j < 20; ++j) {
+      const int c = lane + 64 * j;               // 16-B chunk c of the 32 x 40: row c / 40, part c % 40
+      *reinterpret_cast<u32x4*>(wtile + (c / 40) * OSTR + (c % 40) * 16) = rr[j];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
-    uint2 rv[4]; float4 bo[4];
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const int n = i * 32 + 8 * q4 + 4 * hi;
-      rv[q4] = *reinterpret_cast<const uint2*>(rrow + n);
-      bo[q4] = *reinterpret_cast<const float4*>(p.bo + n);
+      const f32x4 bo = *reinterpret_cast<const f32x4*>(p.bo + n);
+      const u32x2 rv = *reinterpret_cast<const u32x2*>(otile + n * 2);
+      const float v0 = out[i][4 * q4] + bo.x + __uint_as_float(rv.x << 16);
+      const float v1 = out[i][4 * q4 + 1] + bo.y + __uint_as_float(rv.x & 0xffff0000u);
+      const float v2 = out[i][4 * q4 + 2] + bo.z + __uint_as_float(rv.y << 16);
+      const float v3 = out[i][4 * q4 + 3] + bo.w + __uint_as_float(rv.y & 0xffff0000u);
+      *reinterpret_cast<u32x2*>(otile + n * 2) = u32x2{pack_bf2(v0, v1), pack_bf2(v2, v3)};
     }
+  }
+  {
+    bf16_t* odst = p.out + (size_t)(blockIdx.x * FTM + w * 32) * FC;
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      const int n = i * 32 + 8 * q4 + 4 * hi;
-      const float v0 = out[i][4 * q4] + bo[q4].x + __uint_as_float(rv[q4].x << 16);
-      const float v1 = out[i][4 * q4 + 1] + bo[q4].y + __uint_as_float(rv[q4].x & 0xffff0000u);
-      const float v2 = out[i][4 * q4 + 2] + bo[q4].z + __uint_as_float(rv[q4].y << 16);
-      const float v3 = out[i][4 * q4 + 3] + bo[q4].w + __uint_as_float(rv[q4].y & 0xffff0000u);
-      const uint2 o = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
-      *reinterpret_cast<uint2*>(orow + n) = o;
-      if (p.gn_stats) *reinterpret_cast<uint2*>(otile + n * 2) = o;
+    for (int j = 0; j < 20; ++j) {
+      const int c = lane + 64 * j;
+      *reinterpret_cast<u32x4*>(odst + (size_t)c * 8) = *reinterpret_cast<const u32x4*>(wtile + (c / 40) * OSTR + (c % 40) * 16);
     }
   }
   if (p.gn_stats) {
