@@ -105,7 +105,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   auto issue_piece = [&](const Slab& st, int slot, int i) {
     const int pc = w + 4 * i;
-    const bf16_t* src = st.src + (size_t)(8 * pc + srow) * st.ld + schunk * 8;
+    // uniform base (scalar arithmetic, SGPR pair) + one 32-bit per-lane offset: the saddr form of the load — no 64-bit per-piece address
+    // registers to keep (the compiler hoists them: 60+ VGPRs) or to compute in the MFMA gaps
+    // (readfirstlane pins the base in SGPRs: left alone, the compiler re-associates it into hoisted 64-bit per-lane addresses)
+    const uint64_t b64 = (uint64_t)(uintptr_t)(st.src + (size_t)(8 * pc) * st.ld);
+    const bf16_t* base = (const bf16_t*)(uintptr_t)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b64 >> 32)) << 32) |
+                                                     (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b64));
+    const bf16_t* src = (const bf16_t*)((const char*)base + (unsigned)((srow * st.ld + schunk * 8) * 2));     // (a 32-bit BYTE offset)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(smem + slot * LSLOT + pc * 1024), 16, 0, 0);
   };
