@@ -144,10 +144,16 @@ struct FfnArgs {
   const bf16_t* Wfo = nullptr; const float* bo = nullptr;              // [320][1600] (its last 320 columns = Wp), [320]
   const bf16_t* resid = nullptr; bf16_t* out = nullptr;                // [M][320]
   float* gn_stats = nullptr; int rows_per_batch = 0;                   // optional: GroupNorm partials of the output, bins of 5 channels,
-                                                                       // [(b * rows_per_batch / 64 + slab) * 64 + bin][2] (GemmArgs::gn_stats layout)
+                                                                       // [(b * rows_per_batch / 64 + slab) * 64 + bin][2] (GemmArgs::gn_stats layout)  // X != nullptr: the block's attn2.to_out + residual run in front, inside the kernel: t = Wo . X + bo2 + T (T = the stream BEFORE
+  // attn2.to_out; t is never stored, its LayerNorm statistics are formed in registers: ln_stats unused).  W1c then in the permuted k
+  // order and Wpp = Wp with it (ffn_relayout_launch with Wpp != nullptr).
+  const bf16_t* X = nullptr;                                           // [M][384] cross-attention output (8 heads x padded 48)
+  const bf16_t* Wo = nullptr; const float* bo2 = nullptr;              // [320][384], [320]
+  const bf16_t* Wpp = nullptr;                                         // [320][320]
 };
 bool ffn_fused_supported(int C, int M);
-int ffn_relayout_launch(const bf16_t* wff1, const float* bff1, const bf16_t* wfo, bf16_t* W1c, float* b1c, bf16_t* W2p, hipStream_t s);
+int ffn_relayout_launch(const bf16_t* wff1, const float* bff1, const bf16_t* wfo, bf16_t* W1c, float* b1c, bf16_t* W2p, bf16_t* Wpp,
+                        hipStream_t s);
 int ffn_fused_launch(const FfnArgs& a, hipStream_t s);
 
 // Two GEMMs of a level-0 transformer block around a LayerNorm as one kernel (lnproj.hip):

@@ -57,6 +57,7 @@ struct XfW {  // Transformer2DModel with one BasicTransformerBlock
   LinW out2;
   bf16_t* wff1 = nullptr; float* bff1 = nullptr;   // GEGLU-permuted [8C][C]
   bf16_t* w1c = nullptr; float* b1c = nullptr; bf16_t* w2p = nullptr;   // the same weights as the fused feed-forward kernel reads them (ffn.hip; C = 320 only)
+  bf16_t* wpp = nullptr;        // proj_out's weight in the permuted k order: set when the fused feed-forward kernel also runs attn2.to_out (ffn.hip PRE)
   bf16_t *wqkv1p = nullptr, *wq2p = nullptr;   // wqkv1 / wq2 (LayerNorm-folded) with the K order of the fused projection pairs (lnproj.hip; C = 320 only)
   // norm1/2/3 are folded into wqkv1 / wq2 / wff1 at load (GemmArgs::ln_stats): column sums of g*W and beta.W^T (+ bias)
   float *s_qkv1 = nullptr, *c_qkv1 = nullptr, *s_q2 = nullptr, *c_q2 = nullptr, *s_ff1 = nullptr;
@@ -223,6 +224,15 @@ static bool lnproj_on() {
   static const bool on = [] { const char* e = getenv("GILL_UNET_LNPROJ"); return !(e && e[0] == '0'); }();
   return on;
 }
+static bool xattn_env_on() {
+  static const bool on = [] { const char* e = getenv("GILL_UNET_XATTN"); return e && e[0] == '1'; }();
+  return on;
+}
+// GILL_UNET_FFN_PRE=0: attn2.to_out + residual of the level-0 blocks as its own GEMM in front of the fused feed-forward kernel
+static bool ffn_pre_on() {
+  static const bool on = [] { const char* e = getenv("GILL_UNET_FFN_PRE"); return !(e && e[0] == '0'); }();
+  return on;
+}
 static bool ffn_fused_on() {
   static const bool on = [] { const char* e = getenv("GILL_UNET_FFN_FUSED"); return !(e && e[0] == '0'); }();
   return on;
@@ -384,7 +394,9 @@ struct Loader {
       GILL_TRY(pool.alloc(&x->w1c, (size_t)8 * C * C, false));
       GILL_TRY(pool.alloc(&x->b1c, (size_t)8 * C, false));
       GILL_TRY(pool.alloc(&x->w2p, (size_t)4 * C * C, false));
-      GILL_TRY(ffn_relayout_launch(x->wff1, x->bff1, x->wfo, x->w1c, x->b1c, x->w2p, s));
+      // (PRE form: not next to the opt-in fused cross-attention block, which writes the stream AFTER attn2.to_out)
+      if (ffn_pre_on() && !xattn_env_on() && hdp == 384) GILL_TRY(pool.alloc(&x->wpp, (size_t)C * C, false));
+      GILL_TRY(ffn_relayout_launch(x->wff1, x->bff1, x->wfo, x->w1c, x->b1c, x->w2p, x->wpp, s));
     }
     if (lnproj_on() && lnproj_supported(C, 128, H, x->dp)) {
       GILL_TRY(pool.alloc(&x->wqkv1p, (size_t)3 * hdp * C, false));
@@ -774,8 +786,9 @@ struct UNetRun {
     // geometry has one (levels 0 / 1).  OFF by default: measured slower than the four launches it replaces (loop 545.5 -> 549.5 ms;
     // level 0: 91 us vs 95 us, level 1: 96 us vs 79 us — every phase streams the weights from L2 at ~25-35 GB/s per CU with the
     // 50-70 KB of LDS-DMA it can keep in flight next to its row tile: profiles/r03_xattn_fused.md).  GILL_UNET_XATTN = 1 turns it on.
-    static const bool xattn_on = [] { const char* e = getenv("GILL_UNET_XATTN"); return e && e[0] == '1'; }();
+    const bool xattn_on = xattn_env_on();
     const bf16_t* tres = t.p;         // the residual stream after the two attention sub-blocks
+    bool ffn_pre = false;             // ... or, PRE: before attn2.to_out, which the feed-forward kernel then runs itself
     if (xattn_on && xattn_block_supported(C, nh, w.dp, HW, m->ctx_pad)) {
       Tensor t2 = talloc(H, Wd, C);
       if (!dry) {
@@ -821,7 +834,9 @@ struct UNetRun {
     }
     }
     GILL_TRY(attend(q, m->kcache[w.layer_id], m->vcache[w.layer_id], o, HW, m->cfg.ctx_len, hw_pad, m->ctx_pad, w));
-    GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M, w.out2.w, w.out2.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, &st3));
+    // (with the fused feed-forward kernel's PRE form, attn2.to_out + residual run inside it: ffn.hip)
+    ffn_pre = ffn_fused && w.wpp != nullptr;
+    if (!ffn_pre) GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M, w.out2.w, w.out2.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, &st3));
     }
     if (ffn_fused) {
       // --- GEGLU feed-forward, its residual, proj_out and the outer residual as ONE kernel (ffn.hip)
@@ -829,6 +844,7 @@ struct UNetRun {
         FfnArgs fa;
         fa.M = M; fa.T = tres; fa.ln_stats = st3.p; fa.ln_planes = st3.planes;
         fa.W1c = w.w1c; fa.b1c = w.b1c; fa.W2p = w.w2p; fa.Wfo = w.wfo; fa.bo = w.bfo; fa.resid = xd.p; fa.out = out->p;
+        if (ffn_pre) { fa.X = o; fa.Wo = w.out2.w; fa.bo2 = w.out2.b; fa.Wpp = w.wpp; }
         if (out->stats && out->sbin == 5) { fa.gn_stats = out->stats; fa.rows_per_batch = HW; out->nslab = HW / GN_SLAB_ROWS; }
         else out->stats = nullptr;        // (no partials from this producer: the consumer runs its own statistics pass)
         GILL_TRY(ffn_fused_launch(fa, s));
@@ -1276,14 +1292,25 @@ __global__ __launch_bounds__(256) void ffn_op_rowsums_kernel(const bf16_t* __res
   a = wave_sum(a); q = wave_sum(q);
   if (lane == 0) { stats[(size_t)row * 2] = a; stats[(size_t)row * 2 + 1] = q; }
 }
+// o2 / Wo / bo2 (optional, all or none): the PRE form — t := t + to_out(o2) first, inside the kernel (o2 [M][320] = the cross-attention
+// output, heads x 40; Wo [320][320], bo2 [320]: BasicTransformerBlock.attn2.to_out[0]).
 extern "C" int gill_op_ffn_fused(const void* t, const float* ln_g, const float* ln_b, const void* W1, const float* b1, const void* W2,
                                  const float* b2, const void* Wp, const float* bp, const void* resid, void* out, float* gn_stats,
-                                 int M, int rows_per_batch, void* stream) {
+                                 int M, int rows_per_batch, const void* o2, const void* Wo, const float* bo2, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  const int C = 320, inner = 4 * C;
+  const int C = 320, inner = 4 * C, heads = 8, d = 40, dp = attn_padded_dim(d), hdp = heads * dp;
   GILL_REQUIRE(t && ln_g && ln_b && W1 && b1 && W2 && b2 && Wp && bp && resid && out, "null argument");
+  GILL_REQUIRE((o2 != nullptr) == (Wo != nullptr) && (o2 != nullptr) == (bo2 != nullptr), "o2 / Wo / bo2: all or none");
   GILL_REQUIRE(ffn_fused_supported(C, M), "ffn_fused: M must be a multiple of 128");
-  DevBuf idx, wff1, bff1, sff1, wfo, bfo, w1c, b1c, w2p, st;
+  DevBuf idx, wff1, bff1, sff1, wfo, bfo, w1c, b1c, w2p, st, wpp, o2p, wop;
+  if (o2) {
+    GILL_TRY(wpp.alloc(sizeof(bf16_t) * (size_t)C * C));
+    GILL_TRY(o2p.alloc_zero(sizeof(bf16_t) * (size_t)M * hdp, s));
+    GILL_TRY(wop.alloc_zero(sizeof(bf16_t) * (size_t)C * hdp, s));
+    hipLaunchKernelGGL(pad_head_cols_kernel, dim3(1024), dim3(256), 0, s, o2, 0, M, heads, d, dp, (bf16_t*)o2p.p);
+    hipLaunchKernelGGL(pad_head_cols_kernel, dim3(1024), dim3(256), 0, s, Wo, 0, C, heads, d, dp, (bf16_t*)wop.p);
+    GILL_CHECK_HIP(hipGetLastError());
+  }
   std::vector<int32_t> map = geglu_row_permutation(inner);
   GILL_TRY(idx.alloc(sizeof(int32_t) * map.size()));
   GILL_CHECK_HIP(hipMemcpyAsync(idx.p, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice, s));
@@ -1299,7 +1326,7 @@ extern "C" int gill_op_ffn_fused(const void* t, const float* ln_g, const float* 
   GILL_TRY(w1c.alloc(sizeof(bf16_t) * (size_t)8 * C * C)); GILL_TRY(b1c.alloc(sizeof(float) * 8 * C));
   GILL_TRY(w2p.alloc(sizeof(bf16_t) * (size_t)4 * C * C));
   GILL_TRY(ffn_relayout_launch((const bf16_t*)wff1.p, (const float*)bff1.p, (const bf16_t*)wfo.p, (bf16_t*)w1c.p, (float*)b1c.p,
-                               (bf16_t*)w2p.p, s));
+                               (bf16_t*)w2p.p, o2 ? (bf16_t*)wpp.p : nullptr, s));
   GILL_TRY(st.alloc(sizeof(float) * (size_t)M * 2));
   hipLaunchKernelGGL(ffn_op_rowsums_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, (const bf16_t*)t, M, C, (float*)st.p);
   GILL_CHECK_HIP(hipGetLastError());
@@ -1308,6 +1335,7 @@ extern "C" int gill_op_ffn_fused(const void* t, const float* ln_g, const float* 
   fa.W1c = (const bf16_t*)w1c.p; fa.b1c = (const float*)b1c.p; fa.W2p = (const bf16_t*)w2p.p;
   fa.Wfo = (const bf16_t*)wfo.p; fa.bo = (const float*)bfo.p; fa.resid = (const bf16_t*)resid; fa.out = (bf16_t*)out;
   fa.gn_stats = gn_stats; fa.rows_per_batch = rows_per_batch;
+  if (o2) { fa.X = (const bf16_t*)o2p.p; fa.Wo = (const bf16_t*)wop.p; fa.bo2 = bo2; fa.Wpp = (const bf16_t*)wpp.p; }
   static const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
   for (int r = 0; r < rep; ++r) GILL_TRY(ffn_fused_launch(fa, s));
   GILL_CHECK_HIP(hipStreamSynchronize(s));

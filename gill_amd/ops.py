@@ -194,19 +194,24 @@ def xattn_block_shared(o1, t, wo1, bo1, ln_g, ln_b, wq, k, v, wo2, bo2, heads: i
 
 
 def ffn_fused(t: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor,
-              b2: torch.Tensor, wp: torch.Tensor, bp: torch.Tensor, resid: torch.Tensor, rows_per_batch: int = 0):
+              b2: torch.Tensor, wp: torch.Tensor, bp: torch.Tensor, resid: torch.Tensor, rows_per_batch: int = 0,
+              o2: Optional[torch.Tensor] = None, wo: Optional[torch.Tensor] = None, bo2: Optional[torch.Tensor] = None):
   """The feed-forward sub-block of a C = 320 transformer block + proj_out + outer residual as one kernel (csrc/ffn.hip):
   out = (t + ff2(value * gelu(gate))) @ wp.T + bp + resid with [value | gate] = LN(t) @ w1.T + b1 (diffusers layouts: w1 (2560, 320),
   w2 (320, 1280), wp (320, 320)).  t, resid (M, 320) bf16, M % 128 == 0.  Returns out (M, 320) bf16 [, GroupNorm partial sums
-  (M / 64, 64, 2) fp32 when rows_per_batch > 0]."""
+  (M / 64, 64, 2) fp32 when rows_per_batch > 0].  o2 / wo / bo2 (all or none): t := t + o2 @ wo.T + bo2 first, inside the kernel
+  (BasicTransformerBlock.attn2.to_out + its residual; o2 (M, 320), wo (320, 320)) — the form the UNet engine runs."""
   t, w1, w2, wp, resid = (_bf(x) for x in (t, w1, w2, wp, resid))
   M = t.shape[0]
   out = torch.empty((M, 320), device=t.device, dtype=torch.bfloat16)
   stats = torch.zeros((M // 64, 64, 2), device=t.device, dtype=torch.float32) if rows_per_batch else None
   f = lambda x: x.float().contiguous()
   ln_g, ln_b, b1, b2, bp = f(ln_g), f(ln_b), f(b1), f(b2), f(bp)
+  if o2 is not None:       # the PRE form: t := t + o2 @ wo.T + bo2 first, inside the kernel
+    o2, wo, bo2 = _bf(o2), _bf(wo), f(bo2)
   N.check(N.lib().gill_op_ffn_fused(N.ptr(t), N.ptr(ln_g), N.ptr(ln_b), N.ptr(w1), N.ptr(b1), N.ptr(w2), N.ptr(b2), N.ptr(wp), N.ptr(bp),
-                                    N.ptr(resid), N.ptr(out), N.ptr(stats), M, rows_per_batch, N.current_stream()))
+                                    N.ptr(resid), N.ptr(out), N.ptr(stats), M, rows_per_batch, N.ptr(o2), N.ptr(wo), N.ptr(bo2),
+                                    N.current_stream()))
   return (out, stats) if rows_per_batch else out
 
 

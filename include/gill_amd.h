@@ -251,10 +251,13 @@ int gill_op_xattn_block(const void* o1, const void* t, const void* Wo1, const fl
 /* The feed-forward sub-block of a level-0 (C = 320) transformer block + proj_out + outer residual as one kernel (csrc/ffn.hip):
  * out = proj_out(ff2(geglu(ff1(LN(t)))) + t) + resid on natural (diffusers-layout) operands; gn_stats (optional): GroupNorm partial sums
  * of the output, [(b * rows_per_batch / 64 + slab) * 64 + bin][2], bins of 5 channels.  Replaces, inside gill_unet_forward, the
- * BasicTransformerBlock.ff call + Transformer2DModel.proj_out of diffusers (reference call site: gill/custom_sd.py:633-638). */
+ * BasicTransformerBlock.ff call + Transformer2DModel.proj_out of diffusers (reference call site: gill/custom_sd.py:633-638).
+ * o2 / Wo / bo2 (optional, all or none): t := t + attn2.to_out(o2) first, inside the kernel (o2 (M, 320) = the cross-attention output,
+ * Wo (320, 320), bo2 (320)) — the form the UNet engine runs. */
 int gill_op_ffn_fused(const void* t_bf16, const float* ln_g, const float* ln_b, const void* W1_bf16, const float* b1,
                       const void* W2_bf16, const float* b2, const void* Wp_bf16, const float* bp, const void* resid_bf16,
-                      void* out_bf16, float* gn_stats, int M, int rows_per_batch, void* stream);
+                      void* out_bf16, float* gn_stats, int M, int rows_per_batch, const void* o2_bf16, const void* Wo_bf16,
+                      const float* bo2, void* stream);
 
 /* The two projections around norm1 / norm2 of a level-0 (C = 320, 8 heads of 40) transformer block as one kernel (csrc/lnproj.hip), on
  * natural (diffusers-layout) operands.  mode 0: t = proj_in(x); [q | k | v] = [to_q; to_k; to_v](LN(t)) (W2 = the three weights stacked,

@@ -243,7 +243,7 @@ def test_fused_cross_attention_block_matches_the_four_launch_graph(cuda, tmp_pat
     assert rel < bar and cos > 0.999, f"{key}: rel-L2 {rel:.3e}"
 
 
-@pytest.mark.parametrize("switch", ["GILL_UNET_FFN_FUSED", "GILL_UNET_LNPROJ"])
+@pytest.mark.parametrize("switch", ["GILL_UNET_FFN_FUSED", "GILL_UNET_LNPROJ", "GILL_UNET_FFN_PRE"])
 def test_fused_block_switches_full_size_forward(cuda, switch):
   """GILL_UNET_FFN_FUSED / GILL_UNET_LNPROJ (read once per process): one full-size SD-1.5 forward with the level-0 feed-forward sub-blocks as the fused
   kernel (default) and as GEGLU + the two-source GEMM — resp. with the projection pairs around norm1 / norm2 as one kernel each (lnproj.hip,

@@ -411,6 +411,33 @@ def test_ffn_fused_vs_torch(cuda, M, rows_per_batch):
   assert torch.allclose(got, want, rtol=2e-4, atol=2e-3), float((got - want).abs().max())
 
 
+
+@pytest.mark.parametrize("M", [128, 1024])
+def test_ffn_fused_with_attn2_to_out_in_front_vs_torch(cuda, M):
+  """The form the UNet engine runs: attn2.to_out + its residual inside the same kernel (t = t_prev + to_out(o2), never stored), then the
+  feed-forward block as above — against the fp32 restatement on the same bf16-rounded operands (t rounded to bf16 where the separate
+  GEMM would have stored it)."""
+  from gill_amd import ops
+  C, H = 320, 1280
+  t_prev = _bf(_rnd((M, C), 160, 1.5) + 0.3)
+  o2 = _bf(_rnd((M, C), 161))
+  wo, bo2 = _bf(_rnd((C, C), 162, 0.06)), 0.2 * _rnd((C,), 163)
+  resid = _bf(_rnd((M, C), 164))
+  ln_g, ln_b = 1.0 + 0.2 * _rnd((C,), 165), 0.1 * _rnd((C,), 166)
+  w1, b1 = _bf(_rnd((2 * H, C), 167, 0.06)), 0.1 * _rnd((2 * H,), 168)
+  w2, b2 = _bf(_rnd((C, H), 169, 0.03)), 0.1 * _rnd((C,), 170)
+  wp, bp = _bf(_rnd((C, C), 171, 0.05)), 0.1 * _rnd((C,), 172)
+  t = _bf(t_prev.float() + o2.float() @ wo.float().T + bo2).float()
+  pr = F.layer_norm(t, (C,), ln_g, ln_b, 1e-5) @ w1.float().T + b1
+  y = t + (pr[:, :H] * F.gelu(pr[:, H:])) @ w2.float().T + b2
+  ref = y @ wp.float().T + bp + resid.float()
+  out, stats = ops.ffn_fused(t_prev.to(cuda), ln_g.to(cuda), ln_b.to(cuda), w1.to(cuda), b1.to(cuda), w2.to(cuda), b2.to(cuda), wp.to(cuda),
+                             bp.to(cuda), resid.to(cuda), rows_per_batch=128, o2=o2.to(cuda), wo=wo.to(cuda), bo2=bo2.to(cuda))
+  assert _report(f"fused FFN with attn2.to_out M={M}", out, ref) < 1e-2
+  o = out.float().cpu().view(M // 64, 64, 64, 5)
+  want = torch.stack([o.sum(dim=(1, 3)), (o * o).sum(dim=(1, 3))], dim=-1)
+  assert torch.allclose(stats.cpu(), want, rtol=2e-4, atol=2e-3)
+
 # ---------------------------------------------------------------- fused projection pairs around norm1 / norm2 (csrc/lnproj.hip)
 @pytest.mark.parametrize("B,HW", [(1, 128), (2, 192), (2, 1024)])
 def test_lnproj_proj_in_qkv_vs_torch(cuda, B, HW):
