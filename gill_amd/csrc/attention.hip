@@ -55,8 +55,11 @@ struct AttCfg {
   static constexpr int SMEM_BYTES = 2 * BUF_ELEMS * 2;
 };
 
-template <int DP, int ATT_THREADS>
+// QF (DP = 48 with d = 40 only): the running max rides in the padding — q[40] := -m_run (bf16), k[40] := 1 — so the MFMA result is
+// already s - m_run on a ZERO accumulator (an inline constant: no 32 register initialisations per 64-key tile).
+template <int DP, int ATT_THREADS, bool QF>
 __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_kernel(const AttnArgs p) {
+  static_assert(!QF || DP == 48, "QF: the spare column is dim 40 of a 48-wide head");
   using Cfg = AttCfg<DP, ATT_THREADS>;
   constexpr int ATT_QB = ATT_THREADS / 2;
   constexpr int KS = Cfg::KS, NDT = Cfg::NDT, KSTR = Cfg::KSTR, VSTR = Cfg::VSTR;
@@ -154,6 +157,9 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
       const int c = tid + i * ATT_THREADS;
       const int row = c / (DP / 8);
       const int col = c - row * (DP / 8);
+      if constexpr (QF) {      // dim 40 = element 0 of chunk 5 of the row := 1.0
+        if (col == 5) kreg[i].x = (kreg[i].x & 0xffff0000u) | 0x3F80u;
+      }
       *reinterpret_cast<u32x4*>(Ks + row * KSTR + col * 8) = kreg[i];
     }
 #pragma unroll
@@ -189,17 +195,20 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
       // ---- S^T for the two 32-key halves.  Q arrives pre-multiplied by scale*log2(e), and the accumulator starts at
       // -m_run, so the MFMA result IS the exponent s - m_run: no per-element scale / subtract VALU work.
       const bool first = (it == 0);
-      const float acc0 = first ? 0.f : -m_run;
+      const float acc0 = (QF || first) ? 0.f : -m_run;
       f32x16 s[2];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
+        if constexpr (!QF) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[hh][r] = acc0;
+          for (int r = 0; r < 16; ++r) s[hh][r] = acc0;
+        }
         const bf16_t* krow = Ks + (hh * 32 + lq) * KSTR + hi * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + ks * 16);
-          s[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[hh], 0, 0, 0);
+          if (QF && ks == 0) s[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+          else s[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[hh], 0, 0, 0);
         }
       }
       // ---- masking only where the tile is not entirely visible (wave-uniform test)
@@ -227,6 +236,17 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
       const bool grow = first || (mx > 8.0f);
       if (__any(grow)) {
         float delta;
+        if constexpr (QF) {
+          // the max that is IN the scores is the bf16 value held in q[40]: keep m_run equal to it (any common offset is a valid "max")
+          const float m_old = m_run;
+          const float m_new = first ? ((mx > -INFINITY) ? mx : 0.f) : m_run + fmaxf(mx, 0.f);
+          m_run = bf2f(f2bf(m_new));
+          delta = m_run - m_old;
+          union { bf16x8 v; uint32_t u[4]; } x;
+          x.v = qf[2];
+          if (hi) x.u[0] = (x.u[0] & 0xffff0000u) | (uint32_t)f2bf(-m_run);      // lane (q, hi = 1) holds dims 40 .. 47 of its query
+          qf[2] = x.v;
+        } else
         if (first) { m_run = (mx > -INFINITY) ? mx : 0.f; delta = m_run; }   // (a valid row always sees key 0)
         else { delta = fmaxf(mx, 0.f); m_run += delta; }                    // fully masked row: mx = -inf -> 0
         if (!first) {
@@ -304,19 +324,23 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
   }
 }
 
-template <int DP, int NTHR>
+template <int DP, int NTHR, bool QF = false>
 static int attention_launch_inst(const AttnArgs& a, hipStream_t s) {
+  if constexpr (DP == 48 && !QF) {
+    static const bool qf_on = [] { const char* e = getenv("GILL_ATT_QFOLD"); return !(e && e[0] == '0'); }();     // A/B switch
+    if (a.d == 40 && qf_on) return attention_launch_inst<DP, NTHR, true>(a, s);
+  }
   static bool attr_set = false;
   constexpr int smem = AttCfg<DP, NTHR>::SMEM_BYTES;
   if (!attr_set) {
-    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel<DP, NTHR>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel<DP, NTHR, QF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   static const int xcd_on = [] { const char* e = getenv("GILL_ATT_XCD"); return e ? atoi(e) : 1; }();
   AttnArgs b = a;
   b.xcd_map = xcd_on;
   dim3 grid((xcd_on ? 8 * cdiv(a.H * a.B, 8) : a.H * a.B) * cdiv(a.nq, NTHR / 2), 1, 1);   // (XCD, pair slot, query tile): see the kernel's map
-  hipLaunchKernelGGL((attention_kernel<DP, NTHR>), grid, dim3(NTHR), smem, s, b);
+  hipLaunchKernelGGL((attention_kernel<DP, NTHR, QF>), grid, dim3(NTHR), smem, s, b);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -163,7 +163,7 @@ extern "C" int gill_op_attention(const void* q, const void* k, const void* v, vo
   AttnArgs a;
   a.Q = (const bf16_t*)Q.p; a.K = (const bf16_t*)K.p; a.Vt = (const bf16_t*)Vt.p; a.O = (bf16_t*)O.p;
   a.B = B; a.H = H; a.nq = nq; a.nkv = nkv; a.nq_pad = nq_pad; a.nkv_pad = nkv_pad; a.dp = dp; a.dpv = dpv;
-  a.ldo = H * dp; a.scale = scale; a.causal = causal;
+  a.ldo = H * dp; a.scale = scale; a.causal = causal; a.d = d;
   for (int r = 0; r < op_repeat(); ++r) GILL_TRY(attention_launch(a, s));
   GILL_TRY(unpad_heads_launch((const bf16_t*)O.p, (int64_t)B * nq, H, d, dp, (bf16_t*)o, s));
   GILL_CHECK_HIP(hipStreamSynchronize(s));

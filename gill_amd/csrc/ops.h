@@ -105,6 +105,7 @@ struct AttnArgs {
   int B = 0, H = 0, nq = 0, nkv = 0, nq_pad = 0, nkv_pad = 0, dp = 0, dpv = 0;
   int ldo = 0;          // row stride of O in elements (>= H*dp)
   float scale = 1.f;    // informative only: Q must arrive pre-multiplied by scale * log2(e) (GemmArgs::qscale)
+  int d = 0;            // the real head dim when known (0: not stated).  dp = 48 with d = 40: the kernel uses padding dim 40 (see QF)
   int causal = 0;
   int kv_bstride_zero = 0;  // 1: K/Vt have a single batch entry shared by every b (learned queries etc.)
   int xcd_map = 1;          // 1: all query tiles of a (sample, head) on one XCD (set by the launcher; GILL_ATT_XCD=0 turns it off)

@@ -729,7 +729,7 @@ struct UNetRun {
     AttnArgs a;
     a.Q = q; a.K = k; a.Vt = vt; a.O = o;
     a.B = Bx; a.H = w.heads; a.nq = nq; a.nkv = nkv; a.nq_pad = nq_pad; a.nkv_pad = nkv_pad;
-    a.dp = w.dp; a.dpv = w.dpv; a.ldo = w.heads * w.dp;
+    a.dp = w.dp; a.dpv = w.dpv; a.ldo = w.heads * w.dp; a.d = w.d;
     a.scale = 1.0f / sqrtf((float)w.d);
     return attention_launch(a, s);
   }
