@@ -173,7 +173,7 @@ __device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& 
 template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT, int MI>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void gemm_kernel(const GemmDev d) {
   constexpr int BM = (NWV / 2) * MI * 16;
-  static_assert(MI == 4 || (MI == 2 && NWV == 4 && CONV == 0 && STAGES == 2 && KT == 64) ||
+  static_assert(MI == 4 || (MI == 2 && NWV == 4 && CONV == 0 && (STAGES == 2 || STAGES == 3) && KT == 64) ||
                     (MI == 2 && NWV == 8 && BN == 160 && CONV != 0 && STAGES == 3 && KT == 64),
                 "MI = 2: the 4-wave 64-row plain tile, or the 128 x 160 ping-pong conv tile (8 waves of 32 x 80)");
   constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
@@ -1208,7 +1208,14 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
     if (d.nwv == 2) return gemm_launch_inst<2, BN, CONV, EPI, 2>(d, grid, s);
   }
   if constexpr (CONV == 0 && (EPI == 0 || EPI == 3 || EPI == 4) && BN == 128) {
-    if (d.nwv == 4 && d.mi == 2) return gemm_launch_inst<4, BN, CONV, EPI, 2, BK, 2>(d, grid, s);   // 64-row tile on four waves
+    if (d.nwv == 4 && d.mi == 2) {
+      // 64-row tile on four waves, 3-deep ring (72 KB: two workgroups per CU).  These grids are 1-2 workgroups per CU, so the ring depth IS
+      // the number of K stages in flight on a CU, and a K step of these short-K GEMMs is one L2 round trip: 2-deep 487.3 ms, 3-deep
+      // 483.4 ms, 4-deep (one workgroup per CU) 496.1 ms on the loop.  GILL_GEMM_DEEP=2 restores the 2-deep ring.
+      static const int deep = env_int("GILL_GEMM_DEEP");
+      if (deep == 2) return gemm_launch_inst<4, BN, CONV, EPI, 2, BK, 2>(d, grid, s);
+      return gemm_launch_inst<4, BN, CONV, EPI, 3, BK, 2>(d, grid, s);
+    }
   }
   if constexpr (BN == 160 && CONV != 0) {
     if (d.nwv == 8 && d.mi == 2) return gemm_launch_inst<8, BN, CONV, EPI, 3, BK, 2>(d, grid, s);   // ping-pong 128 x 160 tile
@@ -1237,6 +1244,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   d.nwv = 4;
   // (tile_width() counts 128 x 160 tiles when it hands these GEMMs BN = 128, this rule counts 128 x 128 tiles: an 8192 x 640 GEMM
   // — 256 vs 320 — therefore lands on the 4-wave 128 x 128 tile, not the 64-row one; measured better that way: 567.8 vs 575.5 ms)
+  // (re-measured with the 3-deep ring below: < 300 493.8 ms, < 400 495.6, < 520 496.3, < 700 496.5)
   if (!a.conv && sk == 1 && (int64_t)cdiv(a.M, 128) * d.tiles_n < 300 && a.M > 64) d.nwv = 2;   // measured: < 300 +0.3 %, < 520 -3 % end to end
   d.mi = 4;
   // the 64-row tile on FOUR waves (2 x 2, wave tile 32 x 64) where its width is 128: same LDS, twice the waves per CU —
