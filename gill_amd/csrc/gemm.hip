@@ -1063,14 +1063,23 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
 #pragma unroll
     for (int e = 0; e < 4; ++e) colp[ty][tx * 4 + e] = make_float2(gs[e], gq[e]);
     __syncthreads();
+    // two levels, each in index order: column totals over the 16 row lanes (one thread per column), then the bin's columns — a chain
+    // of 16 + gn_cg additions instead of 16 x gn_cg on the 2 x bins threads that finish the block (640 at 40 channels per group)
+    __shared__ float2 colt[W];
+    if ((int)threadIdx.x < W) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float2 v = colp[r][threadIdx.x]; a += v.x; q += v.y; }
+      colt[threadIdx.x] = make_float2(a, q);
+    }
+    __syncthreads();
     const int bins_blk = W / p.gn_cg;            // gemm_fused_gn_ok(): W % gn_cg == 0
     if ((int)threadIdx.x < 2 * bins_blk && mbase < p.M) {
       const int which = threadIdx.x & 1, lb = threadIdx.x >> 1;
       const int bin = blockIdx.x * bins_blk + lb;
       if (bin < p.gn_groups) {
         float a = 0.f;
-        for (int r = 0; r < 16; ++r)
-          for (int c = 0; c < p.gn_cg; ++c) { const float2 v = colp[r][lb * p.gn_cg + c]; a += which ? v.y : v.x; }
+        for (int c = 0; c < p.gn_cg; ++c) { const float2 v = colt[lb * p.gn_cg + c]; a += which ? v.y : v.x; }
         const int b = mbase / p.rows_per_batch;
         const int slab = (mbase - b * p.rows_per_batch) / ROWS;
         const int nslab = p.rows_per_batch / ROWS;
