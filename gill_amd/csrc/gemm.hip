@@ -1216,6 +1216,12 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
   if constexpr (CONV == 0 && EPI != 2) {
     if (d.nwv == 2) return gemm_launch_inst<2, BN, CONV, EPI, 2>(d, grid, s);
   }
+  if constexpr (CONV == 0 && (EPI == 0 || EPI == 4) && BN == 160) {
+    if (d.nwv == 4 && d.mi == 2) {
+      // (2-deep ring: 56 KB, two workgroups per CU; 3-deep = 84 KB = one per CU measured slower: 495.7 vs 489.4 ms)
+      return gemm_launch_inst<4, BN, CONV, EPI, 2, BK, 2>(d, grid, s);
+    }
+  }
   if constexpr (CONV == 0 && (EPI == 0 || EPI == 3 || EPI == 4) && BN == 128) {
     if (d.nwv == 4 && d.mi == 2) {
       // 64-row tile on four waves, 3-deep ring (72 KB: two workgroups per CU).  These grids are 1-2 workgroups per CU, so the ring depth IS
@@ -1259,6 +1265,10 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   // the 64-row tile on FOUR waves (2 x 2, wave tile 32 x 64) where its width is 128: same LDS, twice the waves per CU —
   // loop 580.4 -> 576.3 ms, 2048 x 1280 x 1280 19.8 -> 17.3 us
   if (d.nwv == 2 && BN == 128 && a.act != ACT_GEGLU && !a.gn_stats) { d.nwv = 4; d.mi = 2; }
+  // ... and where it is 160 (the feed-forward output GEMMs of levels 1-3 with their fused GroupNorm partials: bins of 20 / 40 channels
+  // need the 160-wide tile): loop 492.4 -> 489.4 ms.  GILL_GEMM_MI2_160=0 keeps the two-wave tile.
+  static const bool mi2_160 = [] { const char* e = getenv("GILL_GEMM_MI2_160"); return !(e && e[0] == '0'); }();
+  if (d.nwv == 2 && BN == 160 && mi2_160 && a.act == ACT_NONE && a.out_mode == OUT_BF16) { d.nwv = 4; d.mi = 2; }
   if (forced_bm == 128) { d.nwv = 4; d.mi = 4; }
   if (forced_bm == 64 && !a.conv && sk == 1) { d.nwv = 2; d.mi = 4; }
   // 3x3 convolutions: 256 x 160 tile with the ping-pong main loop, one workgroup per CU (GILL_GEMM_PP = 0 keeps the two
