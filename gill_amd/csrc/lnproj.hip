@@ -36,9 +36,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-#ifndef LP_ABL
-#define LP_ABL 0
-#endif
 
 template <int N> __device__ __forceinline__ void lp_wait_vm() {
   __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
@@ -145,15 +142,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bf16_t* tsrc = p.T + (size_t)(blockIdx.x * LTM + w * 32 + (lane >> 2)) * LC + (lane & 3) * 8;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-      res[2 * i] = (LP_ABL & 32) ? u32x4{0, 0, 0, 0} : *reinterpret_cast<const u32x4*>(tsrc + 32 * i);
-      res[2 * i + 1] = (LP_ABL & 32) ? u32x4{0, 0, 0, 0} : *reinterpret_cast<const u32x4*>(tsrc + 32 * i + 16 * LC);
+      res[2 * i] = *reinterpret_cast<const u32x4*>(tsrc + 32 * i);
+      res[2 * i + 1] = *reinterpret_cast<const u32x4*>(tsrc + 32 * i + 16 * LC);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
   // first GEMM's B operand: rows of X (n, or the attention output o), k16 step s -> X[m][16 s + 8 hi .. +8]
   bf16x8 xf[K1 / 16];
 #pragma unroll
-  for (int s = 0; s < K1 / 16; ++s) xf[s] = (LP_ABL & 64) ? bf16x8{1, 2, 3, 4, 5, 6, 7, 8} : *reinterpret_cast<const bf16x8*>(p.X + (size_t)((LP_ABL & 4) ? (m & 31) : m) * K1 + 16 * s + 8 * hi);
+  for (int s = 0; s < K1 / 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(p.X + (size_t)m * K1 + 16 * s + 8 * hi);
   {
     float* bt = reinterpret_cast<float*>(smem + LBIAS_OFF);
     const unsigned bt_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)bt;
@@ -276,7 +273,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         sq += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
       }
       const u32x4 d0 = *reinterpret_cast<const u32x4*>(wb + t_rd0), d1 = *reinterpret_cast<const u32x4*>(wb + t_rd1);
-      if (!(LP_ABL & 2) || p.M < 0) {
+      {
         *reinterpret_cast<u32x4*>(tdst + 32 * i) = d0;
         *reinterpret_cast<u32x4*>(tdst + 32 * i + 16 * LC) = d1;
       }
@@ -340,7 +337,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         stages2(std::integral_constant<int, G1 + SIDX * 15 + I>{}...);
       }(std::make_integer_sequence<int, 15>{});
       // scatter, one head (48 columns = 6 groups of 8: group 6 h + g6 = tile (6h + g6) / 4, registers 4 ((6h + g6) % 4) .. +3) at a time
-      if (!((LP_ABL & 1) || ((LP_ABL & 8) && SEG == 2) || ((LP_ABL & 16) && SEG < 2)) || p.M < 0) {
+      {
         if constexpr (SEG < 2) {
           bf16_t* dst = (SEG == 0 ? p.Cq : p.Ck) + ((size_t)(bidx * 8) * p.ntok_pad + tok0) * LDP + lane * 8;
           const size_t head_stride = (size_t)p.ntok_pad * LDP;
