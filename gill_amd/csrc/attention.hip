@@ -29,6 +29,7 @@
 // (zero weight rows); padding rows of Vt (up to dpv = roundup(DP,32)) only feed output rows that are never stored.
 #include "ops.h"
 #include <stdlib.h>
+#include <type_traits>
 
 // threads per workgroup NTHR = 512 | 256 | 128 (template): one wave per 32 queries, NTHR / 2 queries per workgroup
 #define ATT_KVT 64     // keys per tile
@@ -55,11 +56,10 @@ struct AttCfg {
   static constexpr int SMEM_BYTES = 2 * BUF_ELEMS * 2;
 };
 
-// QF (DP = 48 with d = 40 only): the running max rides in the padding — q[40] := -m_run (bf16), k[40] := 1 — so the MFMA result is
-// already s - m_run on a ZERO accumulator (an inline constant: no 32 register initialisations per 64-key tile).
-template <int DP, int ATT_THREADS, bool QF>
+// (A one-dim form of attention_dma_kernel's QF3 lived here in round 3 — q[40] := -m_run as ONE bf16 value: its offset loses the low bits at
+// |score| >= 2^15, ADVICE r03.  The d = 40 shapes that matter run on the LDS-DMA kernel below; this kernel keeps the exact fp32 offset.)
+template <int DP, int ATT_THREADS>
 __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_kernel(const AttnArgs p) {
-  static_assert(!QF || DP == 48, "QF: the spare column is dim 40 of a 48-wide head");
   using Cfg = AttCfg<DP, ATT_THREADS>;
   constexpr int ATT_QB = ATT_THREADS / 2;
   constexpr int KS = Cfg::KS, NDT = Cfg::NDT, KSTR = Cfg::KSTR, VSTR = Cfg::VSTR;
@@ -157,9 +157,6 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
       const int c = tid + i * ATT_THREADS;
       const int row = c / (DP / 8);
       const int col = c - row * (DP / 8);
-      if constexpr (QF) {      // dim 40 = element 0 of chunk 5 of the row := 1.0
-        if (col == 5) kreg[i].x = (kreg[i].x & 0xffff0000u) | 0x3F80u;
-      }
       *reinterpret_cast<u32x4*>(Ks + row * KSTR + col * 8) = kreg[i];
     }
 #pragma unroll
@@ -195,20 +192,17 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
       // ---- S^T for the two 32-key halves.  Q arrives pre-multiplied by scale*log2(e), and the accumulator starts at
       // -m_run, so the MFMA result IS the exponent s - m_run: no per-element scale / subtract VALU work.
       const bool first = (it == 0);
-      const float acc0 = (QF || first) ? 0.f : -m_run;
+      const float acc0 = first ? 0.f : -m_run;
       f32x16 s[2];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        if constexpr (!QF) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[hh][r] = acc0;
-        }
+        for (int r = 0; r < 16; ++r) s[hh][r] = acc0;
         const bf16_t* krow = Ks + (hh * 32 + lq) * KSTR + hi * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + ks * 16);
-          if (QF && ks == 0) s[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
-          else s[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[hh], 0, 0, 0);
+          s[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[hh], 0, 0, 0);
         }
       }
       // ---- masking only where the tile is not entirely visible (wave-uniform test)
@@ -236,17 +230,6 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
       const bool grow = first || (mx > 8.0f);
       if (__any(grow)) {
         float delta;
-        if constexpr (QF) {
-          // the max that is IN the scores is the bf16 value held in q[40]: keep m_run equal to it (any common offset is a valid "max")
-          const float m_old = m_run;
-          const float m_new = first ? ((mx > -INFINITY) ? mx : 0.f) : m_run + fmaxf(mx, 0.f);
-          m_run = bf2f(f2bf(m_new));
-          delta = m_run - m_old;
-          union { bf16x8 v; uint32_t u[4]; } x;
-          x.v = qf[2];
-          if (hi) x.u[0] = (x.u[0] & 0xffff0000u) | (uint32_t)f2bf(-m_run);      // lane (q, hi = 1) holds dims 40 .. 47 of its query
-          qf[2] = x.v;
-        } else
         if (first) { m_run = (mx > -INFINITY) ? mx : 0.f; delta = m_run; }   // (a valid row always sees key 0)
         else { delta = fmaxf(mx, 0.f); m_run += delta; }                    // fully masked row: mx = -inf -> 0
         if (!first) {
@@ -324,23 +307,278 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
   }
 }
 
-template <int DP, int NTHR, bool QF = false>
-static int attention_launch_inst(const AttnArgs& a, hipStream_t s) {
-  if constexpr (DP == 48 && !QF) {
-    static const bool qf_on = [] { const char* e = getenv("GILL_ATT_QFOLD"); return !(e && e[0] == '0'); }();     // A/B switch
-    if (a.d == 40 && qf_on) return attention_launch_inst<DP, NTHR, true>(a, s);
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for d = 40 (DP = 48), non-causal, nq % (NTHR / 2) == 0, nkv_pad % 64 == 0: the level-0 attention of the UNet.
+//
+// The register-staged kernel above spends ~175 wave instructions per 64-key tile, of which only 14 are MFMAs: at d = 40 the
+// SIMD's VALU issue port — not the matrix pipe (39.9 % busy) — is what a tile waits for (32 exp + 16 packs + ~27 for the running max incl.
+// a cross-half ds_bpermute + ~30 for staging addresses, the staging stores and the loop).  This variant removes everything that is not
+// softmax arithmetic from the VALU stream:
+//   * K and V^T tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction): no staging registers, no
+//     ds_write, no per-tile address arithmetic (uniform base per tile + one fixed 32-bit lane offset per piece).  Both tiles are
+//     [64 rows][128 B] images (K rows padded from 96 to 128 B: the lanes of the two pad chunks re-fetch chunks 0 / 1 of the same row —
+//     the same cache line — into slots nobody reads), XOR-swizzled on the SOURCE address and the ds_read address
+//     (chunk ^= (row >> 1) & 7: conflict-free for the 16-lane groups of ds_read_b128 at a 128-B row stride).
+//   * The K rows are DEALT to LDS rows with bits 2 and 3 of the row index swapped (the DMA source address is per lane, so any row
+//     order is free).  The S^T accumulator registers 8 a .. 8 a + 7 of a lane are then 8 CONSECUTIVE keys (16 a + 8 hi + j), i.e. the
+//     lane's P fragment pairs with ONE natural 16-byte chunk of the V^T row: no permuted V^T image (the register-staged kernel
+//     builds one with split 8-byte stores).
+//   * QF3: the running max rides in THREE padding dims, q[40..42] := the exact three-way bf16 split of -m_run (8 + 8 + 8 mantissa
+//     bits = fp32), against k[40..42] = 1 — so S accumulates on an inline-constant zero AND the offset is exact at any magnitude (the
+//     one-dim QF above carries a bf16-rounded offset).  The ones never come from memory: dims 40..47 of K are the
+//     same for every key, so the half wave that holds them (hi = 1, k step 2) reads its fragment from ONE constant 16-byte LDS slot
+//     (its lane address points there for every row; broadcast read).
+//   * The lazy running max is decided on the lane's OWN 32 scores (wave-uniform `any`); the two half waves that share a query only
+//     exchange their maxima in the rare slow path.
+//   * The tile loop is unrolled by two so that the ring stage is a compile-time constant: every LDS address is a loop-invariant lane
+//     offset + an immediate.
+// Everything else (transposed S^T / O^T, P in registers, ones-row of V^T carrying the row sum, XCD map, rotated tile walk) is as above.
+template <int DP, int ATT_THREADS>
+__global__ __launch_bounds__(ATT_THREADS, 4) void attention_dma_kernel(const AttnArgs p) {
+  static_assert(DP == 48, "QF3 needs three padding dims behind d = 40");
+  constexpr int NW = ATT_THREADS / 64;            // waves per workgroup
+  constexpr int ATT_QB = ATT_THREADS / 2;         // queries per workgroup
+  constexpr int KS = DP / 16, NDT = (DP + 31) / 32, NCH = DP / 8;
+  constexpr int PPW = 8 / NW;                     // K pieces (and V^T pieces) per wave and tile: 8 pieces of 8 rows each
+  constexpr int K_BYTES = 64 * 128, STAGE = 2 * K_BYTES, CONST_OFF = 2 * STAGE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_smem_raw[];
+  unsigned char* smem = att_smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqt = p.nq / ATT_QB;
+  int pair, qtile;
+  if (p.xcd_map) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    pair = xcd + 8 * (slot / nqt);
+    qtile = slot - (slot / nqt) * nqt;
+  } else {
+    pair = blockIdx.x / nqt;
+    qtile = blockIdx.x - pair * nqt;
   }
+  if (pair >= p.B * p.H) return;
+  const int b = pair / p.H, h = pair - b * p.H;
+  const int q0 = qtile * ATT_QB + w * 32;
+  const int lq = lane & 31;
+  const int hi = lane >> 5;
+  const int kvb = p.kv_bstride_zero ? 0 : b;
+
+  const bf16_t* Qb = p.Q + (size_t)(b * p.H + h) * p.nq_pad * DP;
+  const bf16_t* Kb = p.K + (size_t)(kvb * p.H + h) * p.nkv_pad * DP;
+  const bf16_t* Vb = p.Vt + (size_t)(kvb * p.H + h) * p.dpv * p.nkv_pad;
+  const int qrow = q0 + lq;          // (nq % ATT_QB == 0: always a valid row)
+
+  // k[40..42] = 1, k[43..47] = 0 for every key: one constant fragment (visible after the first barrier below)
+  if (tid == 0) *reinterpret_cast<uint4*>(smem + CONST_OFF) = make_uint4(0x3F803F80u, 0x00003F80u, 0u, 0u);
+
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)qrow * DP + s * 16 + hi * 8);
+
+  // ---- LDS-DMA geometry: piece pc (0..7) of a tile image covers its rows 8 pc .. 8 pc + 7; wave w issues pieces w * PPW + j
+  const int r8 = lane >> 3, pch = lane & 7;
+  unsigned koff[PPW], voff[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int i = (w * PPW + j) * 8 + r8;                       // LDS row of this lane's 16 bytes
+    const int c = pch ^ ((i >> 1) & 7);                         // logical chunk held at physical position pch of row i
+    const int key = (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);   // K: LDS row i holds key swap23(i) of the tile
+    const int ck = c >= NCH ? c - NCH : c;                      // (pad chunks: re-fetch chunk 0 / 1 — never read)
+    koff[j] = (unsigned)((key * DP + ck * 8) * 2);
+    voff[j] = (unsigned)((i * p.nkv_pad + c * 8) * 2);
+  }
+  auto issue_tile = [&](int tile, int stage) {
+    const char* kbase = (const char*)(Kb + (size_t)tile * ATT_KVT * DP);     // (uniform)
+    const char* vbase = (const char*)(Vb + (size_t)tile * ATT_KVT);
+    unsigned char* dst = smem + stage * STAGE + (w * PPW) * 1024;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + koff[j]),
+                                       (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + voff[j]),
+                                       (__attribute__((address_space(3))) void*)(dst + K_BYTES + j * 1024), 16, 0, 0);
+    }
+  };
+  // fragment reads: row (32 hh | 32 t) + lq, logical chunk 2 c4 + hi -> physical (2 c4 + hi) ^ ((lq >> 1) & 7): one lane offset per c4
+  int fo[4];
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) fo[c4] = lq * 128 + (((2 * c4 + hi) ^ ((lq >> 1) & 7)) * 16);
+  // k step 2 of QK^T: dims 32..39 (hi = 0) from the tile, dims 40..47 (hi = 1) from the constant slot — an address per (stage, half),
+  // because the immediates of the other reads do not apply to the constant
+  int k2a[2][2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) k2a[st][hh] = hi ? CONST_OFF : st * STAGE + hh * 4096 + fo[2];
+
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int t = 0; t < NDT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float m_run = 0.f;       // (q[40..42] = 0 so far)
+
+  const int ntiles = (p.nkv + ATT_KVT - 1) / ATT_KVT;
+  const int rot = p.xcd_map ? (qtile * 5) % ntiles : 0;
+  issue_tile(rot, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // one tile; STG (the ring stage) is a compile-time constant: the loop below is unrolled by two
+  auto tile_body = [&](int it, auto stg) {
+    constexpr int STG = decltype(stg)::value;
+    int tile = it + rot;
+    if (tile >= ntiles) tile -= ntiles;
+    const int kv0 = tile * ATT_KVT;
+    // the other stage was last read in iteration it - 1, and every wave has passed the barrier that closed it
+    if (it + 1 < ntiles) issue_tile(tile + 1 < ntiles ? tile + 1 : 0, STG ^ 1);
+    const unsigned char* Ks = smem + STG * STAGE;
+    const unsigned char* Vs = Ks + K_BYTES;
+
+    f32x16 s[2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const bf16x8 kf = (ks == 2) ? *reinterpret_cast<const bf16x8*>(smem + k2a[STG][hh])
+                                    : *reinterpret_cast<const bf16x8*>(Ks + hh * 4096 + fo[ks]);
+        if (ks == 0) s[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+        else s[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[hh], 0, 0, 0);
+      }
+    }
+    // register r of s[hh] is key kv0 + 32 hh + 16 (r >> 3) + 8 hi + (r & 7) (rows dealt with bits 2 / 3 swapped, see the header)
+    if (kv0 + ATT_KVT > p.nkv) {      // ragged last tile (wave-uniform)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + hh * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+          s[hh][r] = (kv >= p.nkv) ? -INFINITY : s[hh][r];
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[hh][r]);
+    // Lazy running max (see the kernel above): decided on the lane's own 32 scores; only the slow path joins the two half waves
+    const bool first = (it == 0);
+    if (first || __any(mx > 8.0f)) {
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float delta;
+      if (first) delta = (mx > -INFINITY) ? mx : 0.f;      // (m_run = 0 so far, and O = 0: the common update below is exact)
+      else delta = fmaxf(mx, 0.f);                          // fully masked row: mx = -inf -> 0
+      m_run += delta;
+      {   // q[40..42] := -m_run as an exact sum of three bf16 values (lane (q, hi = 1) holds dims 40 .. 47 of its query)
+        const float x = -m_run;
+        const bf16_t a0 = f2bf(x);
+        const float r1 = x - bf2f(a0);
+        const bf16_t a1 = f2bf(r1);
+        const float r2 = r1 - bf2f(a1);
+        const bf16_t a2 = f2bf(r2);
+        union { bf16x8 v; uint32_t u[4]; } xq;
+        xq.v = qf[2];
+        if (hi) { xq.u[0] = (uint32_t)a0 | ((uint32_t)a1 << 16); xq.u[1] = (uint32_t)a2; }
+        qf[2] = xq.v;
+      }
+      if (!first) {          // (first tile: O = 0, and exp2(-delta) may be inf)
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int t = 0; t < NDT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[hh][r] -= delta;
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[hh][r] = __builtin_amdgcn_exp2f(s[hh][r]);
+    bf16x8 pa[4];
+#pragma unroll
+    for (int h4 = 0; h4 < 4; ++h4) {
+      union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pk.u[j] = pack_bf2(s[h4 >> 1][(h4 & 1) * 8 + 2 * j], s[h4 >> 1][(h4 & 1) * 8 + 2 * j + 1]);
+      pa[h4] = pk.v;
+    }
+#pragma unroll
+    for (int t = 0; t < NDT; ++t) {
+#pragma unroll
+      for (int h4 = 0; h4 < 4; ++h4) {
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + t * 4096 + fo[h4]);
+        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pa[h4], oacc[t], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own pieces of the next tile have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");                       // (the next tile's LDS reads stay behind the barrier)
+  };
+  for (int it = 0; it < ntiles; it += 2) {
+    tile_body(it, std::integral_constant<int, 0>{});
+    if (it + 1 < ntiles) tile_body(it + 1, std::integral_constant<int, 1>{});
+  }
+
+  // V^T row DP is all ones (written by the QKV epilogue), so O^T row DP accumulated sum_kv P: register 8 of tile DP / 32, hi = 0 half
+  static_assert(DP % 32 == 16, "ones-row position");
+  const float l_run = __shfl(oacc[DP / 32][8], lq, 64);
+  const float inv = 1.f / l_run;
+  bf16_t* orow = p.O + (size_t)(b * p.nq + qrow) * p.ldo + h * DP;
+#pragma unroll
+  for (int t = 0; t < NDT; ++t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = t * 32 + 8 * g + 4 * hi;
+      if (d < DP) {
+        uint2 o;
+        o.x = pack_bf2(oacc[t][g * 4 + 0] * inv, oacc[t][g * 4 + 1] * inv);
+        o.y = pack_bf2(oacc[t][g * 4 + 2] * inv, oacc[t][g * 4 + 3] * inv);
+        *reinterpret_cast<uint2*>(orow + d) = o;
+      }
+    }
+  }
+}
+
+template <int DP, int NTHR>
+static int attention_dma_launch(const AttnArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  constexpr int smem = 2 * 2 * 64 * 128 + 64;     // two stages of (K | V^T) images + the constant K fragment
+  if (!attr_set) {
+    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_dma_kernel<DP, NTHR>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  static const int xcd_on = [] { const char* e = getenv("GILL_ATT_XCD"); return e ? atoi(e) : 1; }();
+  AttnArgs b = a;
+  b.xcd_map = xcd_on;
+  dim3 grid((xcd_on ? 8 * cdiv(a.H * a.B, 8) : a.H * a.B) * (a.nq / (NTHR / 2)), 1, 1);
+  hipLaunchKernelGGL((attention_dma_kernel<DP, NTHR>), grid, dim3(NTHR), smem, s, b);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+// GILL_ATT_DMA=0: the register-staged kernel everywhere (A/B switch)
+static bool attention_dma_ok(const AttnArgs& a, int nthr) {
+  static const bool on = [] { const char* e = getenv("GILL_ATT_DMA"); return !(e && e[0] == '0'); }();
+  return on && a.dp == 48 && a.d == 40 && !a.causal && a.nq % (nthr / 2) == 0 && a.nkv_pad % 64 == 0 && a.dpv >= 64 && a.nkv >= 1;
+}
+
+template <int DP, int NTHR>
+static int attention_launch_inst(const AttnArgs& a, hipStream_t s) {
   static bool attr_set = false;
   constexpr int smem = AttCfg<DP, NTHR>::SMEM_BYTES;
   if (!attr_set) {
-    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel<DP, NTHR, QF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel<DP, NTHR>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   static const int xcd_on = [] { const char* e = getenv("GILL_ATT_XCD"); return e ? atoi(e) : 1; }();
   AttnArgs b = a;
   b.xcd_map = xcd_on;
   dim3 grid((xcd_on ? 8 * cdiv(a.H * a.B, 8) : a.H * a.B) * cdiv(a.nq, NTHR / 2), 1, 1);   // (XCD, pair slot, query tile): see the kernel's map
-  hipLaunchKernelGGL((attention_kernel<DP, NTHR, QF>), grid, dim3(NTHR), smem, s, b);
+  hipLaunchKernelGGL((attention_kernel<DP, NTHR>), grid, dim3(NTHR), smem, s, b);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -353,7 +591,11 @@ template <int DP>
 static int attention_launch_dp(const AttnArgs& a, hipStream_t s) {
   const int64_t bh = (int64_t)a.H * a.B;
   static const int forced = [] { const char* e = getenv("GILL_ATT_THREADS"); return e ? atoi(e) : 0; }();   // tests / tools
-  if (forced == 512 || (forced != 256 && cdiv(a.nq, 256) * bh >= 256)) return attention_launch_inst<DP, 512>(a, s);
+  const bool big = forced == 512 || (forced != 256 && cdiv(a.nq, 256) * bh >= 256);
+  if constexpr (DP == 48) {
+    if (attention_dma_ok(a, big ? 512 : 256)) return big ? attention_dma_launch<DP, 512>(a, s) : attention_dma_launch<DP, 256>(a, s);
+  }
+  if (big) return attention_launch_inst<DP, 512>(a, s);
   return attention_launch_inst<DP, 256>(a, s);   // (128-thread workgroups would stage 10+ chunks per thread: spills)
 }
 

@@ -1266,9 +1266,8 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   // loop 580.4 -> 576.3 ms, 2048 x 1280 x 1280 19.8 -> 17.3 us
   if (d.nwv == 2 && BN == 128 && a.act != ACT_GEGLU && !a.gn_stats) { d.nwv = 4; d.mi = 2; }
   // ... and where it is 160 (the feed-forward output GEMMs of levels 1-3 with their fused GroupNorm partials: bins of 20 / 40 channels
-  // need the 160-wide tile): loop 492.4 -> 489.4 ms.  GILL_GEMM_MI2_160=0 keeps the two-wave tile.
-  static const bool mi2_160 = [] { const char* e = getenv("GILL_GEMM_MI2_160"); return !(e && e[0] == '0'); }();
-  if (d.nwv == 2 && BN == 160 && mi2_160 && a.act == ACT_NONE && a.out_mode == OUT_BF16) { d.nwv = 4; d.mi = 2; }
+  // need the 160-wide tile): loop 492.4 -> 489.4 ms against the two-wave tile.
+  if (d.nwv == 2 && BN == 160 && a.act == ACT_NONE && a.out_mode == OUT_BF16) { d.nwv = 4; d.mi = 2; }
   if (forced_bm == 128) { d.nwv = 4; d.mi = 4; }
   if (forced_bm == 64 && !a.conv && sk == 1) { d.nwv = 2; d.mi = 4; }
   // 3x3 convolutions: 256 x 160 tile with the ping-pong main loop, one workgroup per CU (GILL_GEMM_PP = 0 keeps the two

@@ -112,26 +112,6 @@ struct AttnArgs {
 };
 int attention_launch(const AttnArgs& a, hipStream_t s);
 
-// The cross-attention sub-block of a UNet transformer block as one kernel (xattn.hip):
-//   out = t' + softmax(LN2(t') Wq^T . K^T) V . Wo2^T + bo2,   t' = t + o1 . Wo1^T + bo1
-// o1 [src_rows][heads*dp] (self-attention output, token-major, padded heads), t [src_rows][C], out [M][C] (must not alias t when
-// src_rows < M); rows m >= src_rows read o1 / t at m - src_rows (the shared prefix of a classifier-free-guidance pair).
-// Kc [B][heads][ctx_pad][dp], Vt [B][heads][roundup(dp,32)][ctx_pad]: the prompt's cached keys / values (GemmArgs OUT_QKV layout).
-// Wq is the LayerNorm-folded projection (ln_fold_rows_launch: q_colsum, q_bias); qscale = log2(e) / sqrt(d).
-// row_stats (optional): [4][M][2] row sums of the bf16-rounded output (planes of a following folded LayerNorm, ln_planes = 4).
-struct XattnArgs {
-  int M = 0, HW = 0, C = 0, heads = 0, dp = 0, src_rows = 0;
-  const bf16_t* o1 = nullptr; const bf16_t* t = nullptr; bf16_t* out = nullptr;
-  const bf16_t* Wo1 = nullptr; const float* bo1 = nullptr;
-  const bf16_t* Wq = nullptr; const float* q_colsum = nullptr; const float* q_bias = nullptr;
-  const bf16_t* Kc = nullptr; const bf16_t* Vt = nullptr; int ctx_len = 0, ctx_pad = 0;
-  const bf16_t* Wo2 = nullptr; const float* bo2 = nullptr;
-  float* row_stats = nullptr;
-  float qscale = 1.f, ln_eps = 1e-5f;
-  int debug_stop = 0;   // tools only: 1 / 2 / 3 = return after the first GEMM / the q projection / the attention phase
-};
-bool xattn_block_supported(int C, int heads, int dp, int HW, int ctx_pad);
-int xattn_block_launch(const XattnArgs& a, hipStream_t s);
 
 // The feed-forward sub-block + proj_out + outer residual of a level-0 transformer block (C = 320) as one kernel (ffn.hip):
 //   out = [Wp.W2 | Wp] . [ value * gelu(gate) | t ] + bo + resid,  [value | gate] = W1' . LN(t) + b1'  (LN from the row-sum planes).
@@ -256,6 +236,7 @@ struct SdLoopArgs {
 // plain device-side fill / copy kernels for use INSIDE a captured forward: hipMemsetAsync / hipMemcpyAsync become memset /
 // memcpy graph nodes, whose replay was not reliable (profiles/r02_soak_bisect.md).  16-byte aligned pointers and sizes.
 int zero_bytes_launch(void* dst, size_t bytes, hipStream_t s);
+int touch_bytes_launch(const void* src, size_t bytes, int blocks, hipStream_t s);   // weight prefetch (elementwise.hip)
 int copy_bytes_launch(void* dst, const void* src, size_t bytes, hipStream_t s);
 int dup_pair_launch(void* a, const void* b, void* b2, size_t bytes, hipStream_t s);   // a[bytes..] := a[0..bytes); b2[0..bytes) = b2[bytes..] := b[0..bytes)
 // first kernel of a step: latents -> UNet input (both CFG halves), time-embedding row of the current step -> temb_cur

@@ -224,10 +224,6 @@ static bool lnproj_on() {
   static const bool on = [] { const char* e = getenv("GILL_UNET_LNPROJ"); return !(e && e[0] == '0'); }();
   return on;
 }
-static bool xattn_env_on() {
-  static const bool on = [] { const char* e = getenv("GILL_UNET_XATTN"); return e && e[0] == '1'; }();
-  return on;
-}
 // GILL_UNET_FFN_PRE=0: attn2.to_out + residual of the level-0 blocks as its own GEMM in front of the fused feed-forward kernel
 static bool ffn_pre_on() {
   static const bool on = [] { const char* e = getenv("GILL_UNET_FFN_PRE"); return !(e && e[0] == '0'); }();
@@ -394,8 +390,7 @@ struct Loader {
       GILL_TRY(pool.alloc(&x->w1c, (size_t)8 * C * C, false));
       GILL_TRY(pool.alloc(&x->b1c, (size_t)8 * C, false));
       GILL_TRY(pool.alloc(&x->w2p, (size_t)4 * C * C, false));
-      // (PRE form: not next to the opt-in fused cross-attention block, which writes the stream AFTER attn2.to_out)
-      if (ffn_pre_on() && !xattn_env_on() && hdp == 384) GILL_TRY(pool.alloc(&x->wpp, (size_t)C * C, false));
+      if (ffn_pre_on() && hdp == 384) GILL_TRY(pool.alloc(&x->wpp, (size_t)C * C, false));
       GILL_TRY(ffn_relayout_launch(x->wff1, x->bff1, x->wfo, x->w1c, x->b1c, x->w2p, x->wpp, s));
     }
     if (lnproj_on() && lnproj_supported(C, 128, H, x->dp)) {
@@ -599,6 +594,11 @@ struct UNetRun {
     pick_sk(g);
     if (rs) { g.row_stats = rs->p; rs->planes = gemm_row_planes(g); }
     if (ys && ys->stats) ys->nslab = ys->H * ys->W / gemm_gn_slab_rows(g);
+    {   // tools: GILL_UNET_TOUCH_W=1 pulls every GEMM's weights into the Infinity Cache right before it (on the same stream) — the
+        // kernel trace then shows what each GEMM costs with warm weights, i.e. what an ideal weight prefetcher could buy
+      static const bool touch = getenv("GILL_UNET_TOUCH_W") != nullptr;
+      if (touch) GILL_TRY(touch_bytes_launch(g.W, sizeof(bf16_t) * (size_t)g.N * g.K * ((g.conv && g.ups == 2) ? 4 : 1), 1024, s));
+    }
     GILL_TRY(gemm_launch(g, s));
     return dbg_sync(g.conv ? "conv" : (g.act == ACT_GEGLU ? "geglu" : (g.out_mode == OUT_QKV ? "qkv" : "gemm")), g.M, g.N, g.K);
   }
@@ -782,36 +782,9 @@ struct UNetRun {
     Bx = Bpre;
     GILL_TRY(attend(q, k, vt, o, HW, HW, hw_pad, hw_pad, w));
     Bx = Bfull;
-    // --- attn1.to_out + residual, norm2, attn2 (77 cached prompt keys), attn2.to_out + residual as ONE kernel (xattn.hip) where the
-    // geometry has one (levels 0 / 1).  OFF by default: measured slower than the four launches it replaces (loop 545.5 -> 549.5 ms;
-    // level 0: 91 us vs 95 us, level 1: 96 us vs 79 us — every phase streams the weights from L2 at ~25-35 GB/s per CU with the
-    // 50-70 KB of LDS-DMA it can keep in flight next to its row tile: profiles/r03_xattn_fused.md).  GILL_UNET_XATTN = 1 turns it on.
-    const bool xattn_on = xattn_env_on();
     const bf16_t* tres = t.p;         // the residual stream after the two attention sub-blocks
     bool ffn_pre = false;             // ... or, PRE: before attn2.to_out, which the feed-forward kernel then runs itself
-    if (xattn_on && xattn_block_supported(C, nh, w.dp, HW, m->ctx_pad)) {
-      Tensor t2 = talloc(H, Wd, C);
-      if (!dry) {
-        XattnArgs xa;
-        xa.M = M; xa.HW = HW; xa.C = C; xa.heads = nh; xa.dp = w.dp; xa.src_rows = M1;
-        xa.o1 = o; xa.t = t.p; xa.out = t2.p;
-        xa.Wo1 = w.out1.w; xa.bo1 = w.out1.b;
-        xa.Wq = w.wq2; xa.q_colsum = w.s_q2; xa.q_bias = w.c_q2;
-        xa.Kc = m->kcache[w.layer_id]; xa.Vt = m->vcache[w.layer_id]; xa.ctx_len = m->cfg.ctx_len; xa.ctx_pad = m->ctx_pad;
-        xa.Wo2 = w.out2.w; xa.bo2 = w.out2.b;
-        xa.row_stats = st3.p; st3.planes = 4;
-        xa.qscale = 1.4426950408889634f / sqrtf((float)w.d);
-        static const bool dbg = getenv("GILL_DEBUG_SYNC") != nullptr;     // tools: fence the launch to attribute a device fault
-        if (dbg) { GILL_CHECK_HIP(hipStreamSynchronize(s)); fprintf(stderr, "[xattn] before: C %d M %d M1 %d HW %d layer %d\n", C, M, M1, HW, w.layer_id); }
-        GILL_TRY(xattn_block_launch(xa, s));
-        if (dbg) { GILL_CHECK_HIP(hipStreamSynchronize(s)); fprintf(stderr, "[xattn] after\n"); }
-        if (shared) {     // the block input at full batch (outer residual of the last GEMM)
-          GILL_TRY(copy_bytes_launch(xd.p, x.p, sizeof(bf16_t) * (size_t)M1 * C, s));
-          GILL_TRY(copy_bytes_launch(xd.p + (size_t)M1 * C, x.p, sizeof(bf16_t) * (size_t)M1 * C, s));
-        }
-      }
-      tres = t2.p;
-    } else {
+    {
     if (lnproj) {
       lp.mode = 1; lp.X = o; lp.W1 = w.out1.w; lp.b1 = w.out1.b; lp.W2p = w.wq2p; lp.c2 = w.c_q2;
       if (!dry) GILL_TRY(lnproj_launch(lp, s));
@@ -861,14 +834,9 @@ struct UNetRun {
       g.act = ACT_GEGLU; g.C = ffh; g.ldc = 4 * C;
       GILL_TRY(gemm(g));
     }
-    // --- feed-forward output, its residual, proj_out and the outer residual: one GEMM over K = [h | t] (see ffo_fuse_kernel)
-    static const bool unfused = getenv("GILL_UNET_FFO_UNFUSED") != nullptr;     // A/B switch: the two GEMMs of the reference graph
-    if (unfused) {
-      GILL_TRY(linear(ffh, 4 * C, nullptr, 0, 4 * C, M, w.ff2.w, w.ff2.b, C, 4 * C, tres, ACT_NONE, t.p, C));
-      GILL_TRY(linear(t.p, C, nullptr, 0, C, M, w.proj_out.w, w.proj_out.b, C, C, xd.p, ACT_NONE, out->p, C, out));
-    } else {
-      GILL_TRY(linear(ffh, 4 * C, tres, C, 4 * C, M, w.wfo, w.bfo, C, 5 * C, xd.p, ACT_NONE, out->p, C, out));
-    }
+    // --- feed-forward output, its residual, proj_out and the outer residual: one GEMM over K = [h | t] (see ffo_fuse_kernel; the
+    // reference graph's two GEMMs measured 604.3 -> 588.9 ms against it, profiles/HISTORY.md)
+    GILL_TRY(linear(ffh, 4 * C, tres, C, 4 * C, M, w.wfo, w.bfo, C, 5 * C, xd.p, ACT_NONE, out->p, C, out));
     m->arena.release(mk);
     return 0;
   }
@@ -951,7 +919,7 @@ static int unet_plan_and_alloc(gill_unet* m) {
   const int Bx = c.max_batch;
   const int L = c.sample_size;
   const size_t n_lat = (size_t)c.in_channels * L * L;
-  m->ctx_pad = round_up(c.ctx_len, 32);     // (before the dry run: which blocks take the fused cross-attention kernel depends on it)
+  m->ctx_pad = round_up(c.ctx_len, 64);     // whole 64-key tiles: the LDS-DMA attention kernel streams them unclamped (attention.hip)
   // dry run to size the activation arena
   m->arena.dry = true; m->arena.off = 0; m->arena.high = 0;
   m->kcache.assign(m->n_xf, nullptr); m->vcache.assign(m->n_xf, nullptr);
@@ -1230,53 +1198,6 @@ static int sd_denoise_on(gill_unet* m, const void* cond_bf16, const void* uncond
     }
   }
   GILL_CHECK_HIP(hipMemcpyAsync(latents_out, m->lat, sizeof(float) * n_lat * B, hipMemcpyDeviceToDevice, s));
-  return 0;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Operator-level entry for the fused cross-attention sub-block (xattn.hip) on NATURAL operands (unpadded heads, plain LayerNorm
-// parameters, projected prompt keys / values): pads / folds them exactly as the engine's loader does, then launches the kernel.
-// For tests/test_ops_gpu.py and tools; synchronises.
-extern "C" int gill_op_xattn_block(const void* o1, const void* t, const void* Wo1, const float* bo1, const float* ln_g, const float* ln_b,
-                                   const void* Wq, const void* k, const void* v, const void* Wo2, const float* bo2, void* out,
-                                   float* row_stats, int B, int HW, int C, int heads, int ctx_len, int src_rows, int debug_stop,
-                                   void* stream) {
-  hipStream_t s = (hipStream_t)stream;
-  GILL_REQUIRE(o1 && t && Wo1 && bo1 && ln_g && ln_b && Wq && k && v && Wo2 && bo2 && out, "null argument");
-  GILL_REQUIRE(heads > 0 && C % heads == 0, "heads must divide C");
-  const int d = C / heads, dp = attn_padded_dim(d), dpv = round_up(dp, 32), hdp = heads * dp, M = B * HW;
-  const int ctx_pad = round_up(ctx_len, 32);
-  GILL_REQUIRE(xattn_block_supported(C, heads, dp, HW, ctx_pad), "xattn_block: unsupported geometry");
-  DevBuf o1p, wo1p, wo2p, wqp, cs, cb, kc, vt;
-  GILL_TRY(o1p.alloc_zero(sizeof(bf16_t) * (size_t)src_rows * hdp, s));
-  GILL_TRY(wo1p.alloc_zero(sizeof(bf16_t) * (size_t)C * hdp, s));
-  GILL_TRY(wo2p.alloc_zero(sizeof(bf16_t) * (size_t)C * hdp, s));
-  GILL_TRY(wqp.alloc_zero(sizeof(bf16_t) * (size_t)hdp * C, s));
-  GILL_TRY(cs.alloc_zero(sizeof(float) * (size_t)hdp, s));
-  GILL_TRY(cb.alloc_zero(sizeof(float) * (size_t)hdp, s));
-  GILL_TRY(kc.alloc_zero(sizeof(bf16_t) * (size_t)B * heads * ctx_pad * dp, s));
-  GILL_TRY(vt.alloc_zero(sizeof(bf16_t) * (size_t)B * heads * dpv * ctx_pad, s));
-  hipLaunchKernelGGL(pad_head_cols_kernel, dim3(1024), dim3(256), 0, s, o1, 0, src_rows, heads, d, dp, (bf16_t*)o1p.p);
-  hipLaunchKernelGGL(pad_head_cols_kernel, dim3(1024), dim3(256), 0, s, Wo1, 0, C, heads, d, dp, (bf16_t*)wo1p.p);
-  hipLaunchKernelGGL(pad_head_cols_kernel, dim3(1024), dim3(256), 0, s, Wo2, 0, C, heads, d, dp, (bf16_t*)wo2p.p);
-  hipLaunchKernelGGL(pad_head_rows_kernel, dim3(1024), dim3(256), 0, s, Wq, 0, heads, d, dp, C, (bf16_t*)wqp.p);
-  GILL_CHECK_HIP(hipGetLastError());
-  GILL_TRY(ln_fold_rows_launch((bf16_t*)wqp.p, hdp, C, ln_g, ln_b, (float*)cs.p, (float*)cb.p, s));
-  GILL_TRY(pack_heads_launch((const bf16_t*)k, B, ctx_len, heads, d, ctx_pad, dp, dpv, 0, (bf16_t*)kc.p, s));
-  GILL_TRY(pack_heads_launch((const bf16_t*)v, B, ctx_len, heads, d, ctx_pad, dp, dpv, 1, (bf16_t*)vt.p, s));
-  XattnArgs xa;
-  xa.M = M; xa.HW = HW; xa.C = C; xa.heads = heads; xa.dp = dp; xa.src_rows = src_rows;
-  xa.o1 = (const bf16_t*)o1p.p; xa.t = (const bf16_t*)t; xa.out = (bf16_t*)out;
-  xa.Wo1 = (const bf16_t*)wo1p.p; xa.bo1 = bo1;
-  xa.Wq = (const bf16_t*)wqp.p; xa.q_colsum = (const float*)cs.p; xa.q_bias = (const float*)cb.p;
-  xa.Kc = (const bf16_t*)kc.p; xa.Vt = (const bf16_t*)vt.p; xa.ctx_len = ctx_len; xa.ctx_pad = ctx_pad;
-  xa.Wo2 = (const bf16_t*)wo2p.p; xa.bo2 = bo2;
-  xa.row_stats = row_stats;
-  xa.qscale = 1.4426950408889634f / sqrtf((float)d);
-  xa.debug_stop = debug_stop;
-  const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int r = e ? atoi(e) : 1; return r > 0 ? r : 1; }();
-  for (int r = 0; r < rep; ++r) GILL_TRY(xattn_block_launch(xa, s));
-  GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
 }
 

@@ -160,39 +160,6 @@ def conv3x3_fp8(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tens
   return y
 
 
-def xattn_block(o1: torch.Tensor, t: torch.Tensor, wo1: torch.Tensor, bo1: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor,
-                wq: torch.Tensor, k: torch.Tensor, v: torch.Tensor, wo2: torch.Tensor, bo2: torch.Tensor, heads: int, B: int,
-                want_row_stats: bool = False, debug_stop: int = 0):
-  """The cross-attention sub-block of a UNet transformer block as one kernel (csrc/xattn.hip):
-  t' = t + o1 @ wo1.T + bo1;  out = t' + attn(LN(t') @ wq.T, k, v) @ wo2.T + bo2.
-  o1, t (src_rows, C) bf16 (rows >= src_rows of the B*HW output rows re-use row - src_rows); wo1 / wq / wo2 (C, C) bf16;
-  k, v (B, ctx_len, C) bf16 (projected prompt keys / values); biases and LayerNorm parameters fp32.
-  Returns out (B*HW, C) bf16 [, row_stats (4, B*HW, 2) fp32]."""
-  o1, t, wo1, wq, wo2, k, v = (_bf(x) for x in (o1, t, wo1, wq, wo2, k, v))
-  src_rows, Cc = t.shape
-  ctx_len = k.shape[1]
-  M = B * (src_rows // B) if src_rows % B == 0 and src_rows >= B else src_rows
-  return _xattn(o1, t, wo1, bo1, ln_g, ln_b, wq, k, v, wo2, bo2, heads, B, M, Cc, ctx_len, src_rows, want_row_stats, debug_stop)
-
-
-def _xattn(o1, t, wo1, bo1, ln_g, ln_b, wq, k, v, wo2, bo2, heads, B, M, Cc, ctx_len, src_rows, want_row_stats, debug_stop):
-  out = torch.zeros((M, Cc), device=t.device, dtype=torch.bfloat16)
-  rs = torch.zeros((4, M, 2), device=t.device, dtype=torch.float32) if want_row_stats else None
-  f = lambda x: x.float().contiguous()  # noqa: E731
-  bo1, ln_g, ln_b, bo2 = f(bo1), f(ln_g), f(ln_b), f(bo2)
-  N.check(N.lib().gill_op_xattn_block(N.ptr(o1), N.ptr(t), N.ptr(wo1), N.ptr(bo1), N.ptr(ln_g), N.ptr(ln_b), N.ptr(wq), N.ptr(k),
-                                      N.ptr(v), N.ptr(wo2), N.ptr(bo2), N.ptr(out), N.ptr(rs), B, M // B, Cc, heads, ctx_len, src_rows,
-                                      debug_stop, N.current_stream()))
-  return (out, rs) if want_row_stats else out
-
-
-def xattn_block_shared(o1, t, wo1, bo1, ln_g, ln_b, wq, k, v, wo2, bo2, heads: int, B: int, want_row_stats: bool = False):
-  """Same with the shared classifier-free-guidance prefix: o1 / t hold the FIRST half of the batch only (B/2 samples), k / v all B."""
-  o1, t, wo1, wq, wo2, k, v = (_bf(x) for x in (o1, t, wo1, wq, wo2, k, v))
-  src_rows, Cc = t.shape
-  return _xattn(o1, t, wo1, bo1, ln_g, ln_b, wq, k, v, wo2, bo2, heads, B, 2 * src_rows, Cc, k.shape[1], src_rows, want_row_stats, 0)
-
-
 def ffn_fused(t: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor,
               b2: torch.Tensor, wp: torch.Tensor, bp: torch.Tensor, resid: torch.Tensor, rows_per_batch: int = 0,
               o2: Optional[torch.Tensor] = None, wo: Optional[torch.Tensor] = None, bo2: Optional[torch.Tensor] = None):

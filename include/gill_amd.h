@@ -237,17 +237,6 @@ int gill_op_groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int
  * counterpart (the reference runs SD in fp16, gill/models.py:550-551).  x (B,H,W,Cin) bf16 NHWC, w (Cout,Cin,3,3) fp32,
  * optional bias (Cout) fp32 and residual (B,H,W,Cout) bf16 -> y (B,H,W,Cout) bf16.  Operands are quantised inside
  * (activations x 8 per tensor, weights per output channel).  splitk 0 = heuristic. */
-/* The cross-attention sub-block of a UNet transformer block as one kernel (csrc/xattn.hip; reference semantics: diffusers
- * BasicTransformerBlock attn1.to_out[0] + residual, norm2, attn2 over the prompt's keys, attn2.to_out[0] + residual — the chain
- * behind self.unet(...) at gill/custom_sd.py:633-638):  out = t' + softmax(LN(t') Wq^T K^T / sqrt(d)) V Wo2^T + bo2,
- * t' = t + o1 Wo1^T + bo1.  All matrices bf16 row-major with natural (unpadded) head layout: o1 [src_rows][C], t [src_rows][C],
- * Wo1 / Wq / Wo2 [C][C], k / v [B][ctx_len][C] (already projected), biases / LayerNorm parameters fp32; out [B*HW][C] bf16;
- * row_stats (optional) [4][B*HW][2] fp32.  Rows >= src_rows read o1 / t at row - src_rows.  Supported: C 320 / 640 with 8 heads
- * (SD-1.x levels 0 / 1) or 5 / 10 heads (SD-2.x), HW a multiple of 64.  Synchronises. */
-int gill_op_xattn_block(const void* o1, const void* t, const void* Wo1, const float* bo1, const float* ln_g, const float* ln_b,
-                        const void* Wq, const void* k, const void* v, const void* Wo2, const float* bo2, void* out,
-                        float* row_stats, int B, int HW, int C, int heads, int ctx_len, int src_rows, int debug_stop, void* stream);
-
 /* The feed-forward sub-block of a level-0 (C = 320) transformer block + proj_out + outer residual as one kernel (csrc/ffn.hip):
  * out = proj_out(ff2(geglu(ff1(LN(t)))) + t) + resid on natural (diffusers-layout) operands; gn_stats (optional): GroupNorm partial sums
  * of the output, [(b * rows_per_batch / 64 + slab) * 64 + bin][2], bins of 5 channels.  Replaces, inside gill_unet_forward, the

@@ -255,8 +255,11 @@ def _attn_ref(q, k, v, H, scale, causal):
 
 
 @pytest.mark.parametrize("B,H,nq,nkv,d,causal", [
-  (2, 8, 256, 256, 40, False),    # UNet level-0 shape class (d=40 -> padded 48)
+  (2, 8, 256, 256, 40, False),    # UNet level-0 shape class (d=40 -> padded 48): the LDS-DMA kernel, 128-query workgroups
   (1, 8, 1024, 1024, 40, False),
+  (2, 8, 4096, 4096, 40, False),  # the UNet's level-0 self-attention itself: LDS-DMA kernel, 256-query workgroups, 64 key tiles
+  (2, 8, 256, 100, 40, False),    # LDS-DMA kernel with a ragged last key tile (100 keys in a 128-key allocation)
+  (3, 8, 384, 192, 40, False),    # ... an odd number of key tiles (the loop is unrolled by two) and of (sample, head) pairs per XCD
   (2, 8, 64, 77, 40, False),      # cross-attention: ragged kv length
   (2, 8, 256, 77, 80, False),
   (1, 8, 64, 64, 160, False),
@@ -285,6 +288,40 @@ def test_attention_softmax_spike(cuda):
   ref = _attn_ref(q, k, v, H, d ** -0.5, False)
   out = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), H)
   assert _report("attn spike", out, ref) < 2e-2
+
+
+@pytest.mark.parametrize("mag", [1.0, 64.0, 4096.0])
+def test_attention_d40_large_scores(cuda, mag, monkeypatch):
+  """d = 40 (the QF3 / LDS-DMA kernel): scores far outside bf16's integer range, and a running max that jumps in a late tile.
+  The offset rides in three bf16 padding dims as an exact split of the fp32 running max, so magnitude must not matter
+  (the one-dim bf16 offset of the register-staged kernel loses the low bits at |score| >= 2^15)."""
+  from gill_amd import ops
+  B, H, n, d = 1, 8, 256, 40
+  q, k, v = _rnd((B, n, H * d), 36), _rnd((B, n, H * d), 37), _rnd((B, n, H * d), 38)
+  k[:, 200] = q[:, 7] * 3.0      # spike in the last 64-key tile
+  q = q * mag
+  q, k, v = _bf(q), _bf(k), _bf(v)
+  ref = _attn_ref(q, k, v, H, d ** -0.5, False)
+  out = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), H)
+  assert torch.isfinite(out.float()).all()
+  assert _report(f"attn d40 mag {mag}", out, ref) < 2e-2
+
+
+def test_attention_dma_matches_register_staged(cuda):
+  """The LDS-DMA kernel against the register-staged kernel on the same operands (GILL_ATT_DMA=0 in a child process)."""
+  import subprocess, sys, os, tempfile
+  from gill_amd import ops
+  B, H, n, d = 2, 8, 512, 40
+  q, k, v = (_bf(_rnd((B, n, H * d), s)) for s in (51, 52, 53))
+  out = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), H).float().cpu()
+  with tempfile.TemporaryDirectory() as td:
+    torch.save((q, k, v), os.path.join(td, "in.pt"))
+    code = ("import torch, sys; sys.path.insert(0, %r); from gill_amd import ops; q, k, v = torch.load(%r); "
+            "o = ops.attention(q.cuda(), k.cuda(), v.cuda(), %d).float().cpu(); torch.save(o, %r)"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(td, "in.pt"), H, os.path.join(td, "out.pt")))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, GILL_ATT_DMA="0"))
+    old = torch.load(os.path.join(td, "out.pt"))
+  assert _report("attn dma vs register-staged", out, old) < 1e-2
 
 
 # ---------------------------------------------------------------- norms
@@ -320,67 +357,6 @@ def test_groupnorm(cuda, B, H, W, C1, C2, silu):
 
 
 from gill_amd import synth   # noqa: E402
-
-
-def _xattn_reference(o1, t, wo1, bo1, g, b, wq, k, v, wo2, bo2, heads, B):
-  """fp32 torch restatement of the sub-block (oracle/unet_ref.py:_transformer, attn1 output projection .. attn2 residual), with the
-  residual stream rounded to bf16 where the kernel rounds it."""
-  M, C = o1.shape[0], t.shape[1]
-  d = C // heads
-  t1 = (t + o1 @ wo1.T + bo1).bfloat16().float()
-  ln = torch.nn.functional.layer_norm(t1, (C,), g, b, 1e-5)
-  q = (ln @ wq.T).view(B, M // B, heads, d).transpose(1, 2)
-  kk = k.view(B, -1, heads, d).transpose(1, 2)
-  vv = v.view(B, -1, heads, d).transpose(1, 2)
-  a = torch.softmax(q @ kk.transpose(-1, -2) / d ** 0.5, dim=-1) @ vv
-  o2 = a.transpose(1, 2).reshape(M, C)
-  return t1 + o2 @ wo2.T + bo2
-
-
-@pytest.mark.parametrize("C,heads,HW,B", [(320, 8, 128, 3), (640, 8, 64, 2), (320, 5, 64, 2), (640, 10, 96, 2)])
-def test_xattn_block_vs_torch(cuda, C, heads, HW, B):
-  """csrc/xattn.hip at the four supported geometries (SD-1.x levels 0 / 1: 8 heads of 40 / 80; SD-2.x: 5 / 10 heads of 64) against the
-  fp32 restatement; the row sums it leaves for the next folded LayerNorm against sums of its own bf16 output."""
-  from gill_amd import ops
-  M = B * HW
-  r = lambda name, shape, std=1.0: synth.normal(name, shape, 7, std).bfloat16().float()   # noqa: E731
-  o1, t = r("xa_o1", (M, C)), r("xa_t", (M, C))
-  wo1, wq, wo2 = r("xa_wo1", (C, C), C ** -0.5), r("xa_wq", (C, C), C ** -0.5), r("xa_wo2", (C, C), C ** -0.5)
-  bo1, bo2 = synth.normal("xa_bo1", (C,), 7, 0.1), synth.normal("xa_bo2", (C,), 7, 0.1)
-  g, b = 1.0 + synth.normal("xa_g", (C,), 7, 0.1), synth.normal("xa_b", (C,), 7, 0.1)
-  k, v = r("xa_k", (B, 77, C)), r("xa_v", (B, 77, C))
-  ref = _xattn_reference(o1, t, wo1, bo1, g, b, wq, k, v, wo2, bo2, heads, B)
-  dev = lambda x: x.to(cuda).bfloat16()   # noqa: E731
-  got, rs = ops.xattn_block(dev(o1), dev(t), dev(wo1), bo1.to(cuda), g.to(cuda), b.to(cuda), dev(wq), dev(k), dev(v), dev(wo2),
-                            bo2.to(cuda), heads, B, want_row_stats=True)
-  torch.cuda.synchronize()
-  gf = got.float().cpu()
-  rel = ((gf - ref).norm() / ref.norm()).item()
-  print(f"[xattn block C={C} heads={heads} HW={HW} B={B}] rel-L2 {rel:.3e}, max abs {(gf - ref).abs().max().item():.3e}")
-  assert rel < 1e-2
-  sums = rs.sum(0).cpu()
-  assert torch.allclose(sums[:, 0], gf.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(sums[:, 1], (gf * gf).sum(1), rtol=1e-4, atol=1e-2)
-
-
-def test_xattn_block_shared_prefix_rows(cuda):
-  """src_rows < M: rows of the second half of a classifier-free-guidance pair read the first half's o1 / t and their OWN sample's keys."""
-  from gill_amd import ops
-  C, heads, HW, B = 320, 8, 64, 4
-  M1 = (B // 2) * HW
-  r = lambda name, shape, std=1.0: synth.normal(name, shape, 9, std).bfloat16().float()   # noqa: E731
-  o1, t = r("xs_o1", (M1, C)), r("xs_t", (M1, C))
-  wo1, wq, wo2 = r("xs_wo1", (C, C), C ** -0.5), r("xs_wq", (C, C), C ** -0.5), r("xs_wo2", (C, C), C ** -0.5)
-  bo1, bo2 = synth.normal("xs_bo1", (C,), 9, 0.1), synth.normal("xs_bo2", (C,), 9, 0.1)
-  g, b = 1.0 + synth.normal("xs_g", (C,), 9, 0.1), synth.normal("xs_b", (C,), 9, 0.1)
-  k, v = r("xs_k", (B, 77, C)), r("xs_v", (B, 77, C))
-  ref = _xattn_reference(torch.cat([o1, o1]), torch.cat([t, t]), wo1, bo1, g, b, wq, k, v, wo2, bo2, heads, B)
-  dev = lambda x: x.to(cuda).bfloat16()   # noqa: E731
-  got = ops.xattn_block_shared(dev(o1), dev(t), dev(wo1), bo1.to(cuda), g.to(cuda), b.to(cuda), dev(wq), dev(k), dev(v), dev(wo2),
-                               bo2.to(cuda), heads, B)
-  torch.cuda.synchronize()
-  rel = ((got.float().cpu() - ref).norm() / ref.norm()).item()
-  print(f"[xattn block, shared prefix] rel-L2 {rel:.3e}")
-  assert rel < 1e-2
 
 
 # ---------------------------------------------------------------- fused feed-forward block (csrc/ffn.hip)
