@@ -111,7 +111,7 @@ def build_model(dev, opt_cfg, unet_cfg, max_prompts, vae_cfg=None, keep_unet_cpu
 
 
 SETUP_KERNELS = ("at::native", "__amd_rocclr", "convert_", "relayout", "pad_head", "scatter_rows", "permute", "ln_fold",
-                 "vec_add", "cast_")   # weight set-up / torch's own kernels: not the hot path
+                 "vec_add", "cast_", "ffo_fuse", "kperm")   # weight set-up (create time) / torch's own kernels: not the hot path
 
 
 def pmc_traffic_live(a):
@@ -252,6 +252,8 @@ def main():
   ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, the product path) | gloo (test rigs "
                   "where several ranks share one GPU; with --share-gpu every rank uses cuda:0)")
   ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
+  ap.add_argument("--scale-origin-value", type=float, default=0.0, help="images/s of the N = 1 line's scale_origin (8 prompts on one GPU): the "
+                  "N > 1 line then carries efficiency_vs_scale_origin = value / (N x this)")
   a = ap.parse_args()
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -313,6 +315,23 @@ def main():
     return out
   g.sd_pipe.__class__.__call__ = timed_call
 
+  # stages 1 and 2 the same way (their launches go to torch's current stream): OPT forward -> [IMG] hidden states, GILLMapper
+  opt_ev, map_ev = [], []
+
+  def wrap_events(obj, name, store):
+    fn = getattr(obj, name)
+
+    def timed(*args, **kw):
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      o = fn(*args, **kw)
+      e1.record()
+      store.append((e0, e1))
+      return o
+    setattr(obj, name, timed)
+  wrap_events(g.model, "img_hidden_states", opt_ev)
+  wrap_events(g.model.gen_text_hidden_fcs[0], "forward", map_ev)
+
   vae_ev = []
   orig_dec = g.sd_pipe.__class__.decode_latents
 
@@ -332,6 +351,8 @@ def main():
     step()
   ev["t"].clear()
   vae_ev.clear()
+  opt_ev.clear()
+  map_ev.clear()
   kept = []
   if world > 1:
     dist.barrier()
@@ -343,7 +364,13 @@ def main():
     dist.barrier()
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
+  per_rank = None
   if world > 1:
+    # every rank's own wall time and model-build time (a straggler or a slow loader shows up in the line), then the MAX as the job's time
+    mine = torch.tensor([dt, t_build], device=dev, dtype=torch.float64)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    per_rank = {"ms_per_step": [float(t[0].item()) / a.steps * 1e3 for t in allr], "model_build_s": [round(float(t[1].item()), 1) for t in allr]}
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
@@ -386,7 +413,7 @@ def main():
 
     def step8():
       return g.generate_images(ids8, num_inference_steps=a.infer_steps, guidance_scale=7.5, latents=lat8, decode=True)
-    ev_main, vae_main = list(ev["t"]), list(vae_ev)
+    ev_main, vae_main, opt_main, map_main = list(ev["t"]), list(vae_ev), list(opt_ev), list(map_ev)
     first = step8()
     ev["t"].clear()
     torch.cuda.synchronize()
@@ -406,6 +433,8 @@ def main():
       sys.exit(3)
     ev["t"][:] = ev_main
     vae_ev[:] = vae_main
+    opt_ev[:] = opt_main
+    map_ev[:] = map_main
     del outs8, first
 
   if rank == 0:
@@ -455,10 +484,30 @@ def main():
                    "kernel": f"{unet_name.split(' (')[0]} denoise loop (gill_sd_denoise: MFMA GEMM/implicit-conv + flash attention kernels)",
                    "algorithmic_tflop_per_launch": flop_per_call, "avg_launch_ms": unet_ms},
     }
+    # every stage's own time and roofline (HIP events on the launch stream, averaged over the timed steps; SURVEY.md section 8d: the OPT
+    # pass is bound by streaming its decoder weights from HBM once per batch, the mapper by launch latency, the UNet loop by MFMA)
+    avg = lambda evs: sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, len(evs))   # noqa: E731
+    opt_ms, map_ms = avg(opt_ev), avg(map_ev)
+    D, F, NL = opt_cfg.hidden_size, opt_cfg.ffn_dim, opt_cfg.num_layers
+    opt_gb = 2.0 * NL * (4 * D * D + 2 * D * F) / 1e9        # bf16 decoder matrices, each read once per batch
+    n_sd_calls = max(1, (P_local + 7) // 8)
+    rec["stages"] = {
+      "opt": {"ms": opt_ms, "GB": opt_gb, "TBps": opt_gb / max(opt_ms, 1e-9), "frac_of_8TBps": opt_gb / max(opt_ms, 1e-9) / 8.0, "bound": "hbm",
+              "what": f"gill_opt_img_hidden: {NL}-layer OPT forward of {P_local} x {a.prompt_len + 8} tokens, decoder weights streamed once"},
+      "mapper": {"us": map_ms * 1e3, "bound": "latency", "what": "gill_mapper_forward (4 + 4 transformer layers on 8 -> 77 tokens per prompt)"},
+      "unet_loop": {"ms": unet_ms * n_sd_calls, "frac_of_2.5PFLOPs": achieved / PEAK_BF16_TFLOPS, "bound": "mfma",
+                    "what": f"gill_sd_denoise x {n_sd_calls}: {a.infer_steps + 1} UNet forwards of batch {2 * per_call}"},
+      "vae": {"ms": vae_ms, "what": f"gill_vae_decode of {P_local} latents to uint8 {side}x{side}"},
+      "host_and_gaps_ms": dt / a.steps * 1e3 - (opt_ms + map_ms + unet_ms * n_sd_calls + vae_ms),
+    }
     if want_origin:
       rec["scale_origin"] = scale_origin
     if world == 1 and not a.small and a.config == "c2":
       rec["roofline_kernels"] = kernel_rooflines(dev)
+    if per_rank is not None:
+      rec["per_rank"] = per_rank
+    if a.scale_origin_value > 0:
+      rec["efficiency_vs_scale_origin"] = value / (world * a.scale_origin_value)
     rec["cpu_baseline"], rec["forward_check"] = None, None
     if want_cpu:
       # (every config: the oracle forward is both the reported CPU baseline and the correctness gate of this very build of the

@@ -170,8 +170,9 @@ def ffn_fused(t: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, w1: torch
   (BasicTransformerBlock.attn2.to_out + its residual; o2 (M, 320), wo (320, 320)) — the form the UNet engine runs."""
   t, w1, w2, wp, resid = (_bf(x) for x in (t, w1, w2, wp, resid))
   M = t.shape[0]
-  out = torch.empty((M, 320), device=t.device, dtype=torch.bfloat16)
-  stats = torch.zeros((M // 64, 64, 2), device=t.device, dtype=torch.float32) if rows_per_batch else None
+  # outputs start as NaN: the engine hands these kernels stale arena memory, so a tile the kernel forgot to write must show in a test
+  out = torch.full((M, 320), float("nan"), device=t.device, dtype=torch.bfloat16)
+  stats = torch.full((M // 64, 64, 2), float("nan"), device=t.device, dtype=torch.float32) if rows_per_batch else None
   f = lambda x: x.float().contiguous()
   ln_g, ln_b, b1, b2, bp = f(ln_g), f(ln_b), f(b1), f(b2), f(bp)
   if o2 is not None:       # the PRE form: t := t + o2 @ wo.T + bo2 first, inside the kernel
@@ -191,10 +192,12 @@ def lnproj(mode: int, x: torch.Tensor, t, w1: torch.Tensor, b1: torch.Tensor, ln
   x, w1, w2 = (_bf(v) for v in (x, w1, w2))
   M = B * HW
   hw_pad = (HW + 31) // 32 * 32
-  t = torch.empty((M, 320), device=x.device, dtype=torch.bfloat16) if mode == 0 else _bf(t).clone()
-  q = torch.zeros((B, 8, hw_pad, 48), device=x.device, dtype=torch.bfloat16)
-  k = torch.zeros_like(q) if mode == 0 else None
-  vt = torch.zeros((B, 8, 64, hw_pad), device=x.device, dtype=torch.bfloat16) if mode == 0 else None
+  # outputs start as NaN (the engine passes stale arena memory): pad columns 40..47, the ones-row of V^T and every row must be WRITTEN
+  nan = float("nan")
+  t = torch.full((M, 320), nan, device=x.device, dtype=torch.bfloat16) if mode == 0 else _bf(t).clone()
+  q = torch.full((B, 8, hw_pad, 48), nan, device=x.device, dtype=torch.bfloat16)
+  k = torch.full_like(q, nan) if mode == 0 else None
+  vt = torch.full((B, 8, 64, hw_pad), nan, device=x.device, dtype=torch.bfloat16) if mode == 0 else None
   f = lambda v: v.float().contiguous()
   b1, ln_g, ln_b = f(b1), f(ln_g), f(ln_b)
   N.check(N.lib().gill_op_lnproj(mode, N.ptr(x), N.ptr(t), N.ptr(w1), N.ptr(b1), N.ptr(ln_g), N.ptr(ln_b), N.ptr(w2), N.ptr(q), N.ptr(k),

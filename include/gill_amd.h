@@ -220,12 +220,12 @@ int gill_op_geglu(const void* A, const void* W, const float* bias, void* C, int 
 int gill_op_conv3x3(const void* x1, int C1, const void* x2, int C2, const float* w_oihw, const float* bias,
                     const float* rowvec, const void* resid, void* y, int B, int IH, int IW, int Cout, int stride, int ups,
                     int splitk, void* stream);
-/* softmax(scale * q k^T [+causal]) v over token-major q (B,nq,H*d), k/v (B,nkv,H*d) -> o (B,nq,H*d) */
 /* conv3x3 (stride 1, pad 1) of x1 ++ x2 plus a fused 1x1 convolution of xs1 ++ xs2 (ResnetBlock2D.conv2 + conv_shortcut as one
  * implicit GEMM): y (B,IH,IW,Cout) bf16 NHWC; w_oihw (Cout, C1+C2, 3, 3) fp32, w_sc (Cout, CS1+CS2) fp32.  Synchronises. */
 int gill_op_conv3x3_shortcut(const void* x1, int C1, const void* x2, int C2, const float* w_oihw, const float* bias,
                              const void* xs1, int CS1, const void* xs2, int CS2, const float* w_sc, void* y, int B, int IH, int IW,
                              int Cout, int splitk, void* stream);
+/* softmax(scale * q k^T [+causal]) v over token-major q (B,nq,H*d), k/v (B,nkv,H*d) -> o (B,nq,H*d) */
 int gill_op_attention(const void* q, const void* k, const void* v, void* o, int B, int H, int nq, int nkv, int d,
                       float scale, int causal, void* stream);
 int gill_op_layernorm(const void* x, int x_f32, const float* gamma, const float* beta, void* y_bf16, int rows, int C,
@@ -233,10 +233,6 @@ int gill_op_layernorm(const void* x, int x_f32, const float* gamma, const float*
 int gill_op_groupnorm(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, const float* gamma,
                       const float* beta, float eps, int silu, void* y, void* stream);
 
-/* fp8 (OCP e4m3) 3x3 convolution on CDNA4's v_mfma_scale_f32_16x16x128_f8f6f4 — BASELINE.json configs[4]; no reference
- * counterpart (the reference runs SD in fp16, gill/models.py:550-551).  x (B,H,W,Cin) bf16 NHWC, w (Cout,Cin,3,3) fp32,
- * optional bias (Cout) fp32 and residual (B,H,W,Cout) bf16 -> y (B,H,W,Cout) bf16.  Operands are quantised inside
- * (activations x 8 per tensor, weights per output channel).  splitk 0 = heuristic. */
 /* The feed-forward sub-block of a level-0 (C = 320) transformer block + proj_out + outer residual as one kernel (csrc/ffn.hip):
  * out = proj_out(ff2(geglu(ff1(LN(t)))) + t) + resid on natural (diffusers-layout) operands; gn_stats (optional): GroupNorm partial sums
  * of the output, [(b * rows_per_batch / 64 + slab) * 64 + bin][2], bins of 5 channels.  Replaces, inside gill_unet_forward, the
@@ -258,6 +254,10 @@ int gill_op_ffn_fused(const void* t_bf16, const float* ln_g, const float* ln_b, 
 int gill_op_lnproj(int mode, const void* x_bf16, void* t_bf16, const void* W1_bf16, const float* b1, const float* ln_g, const float* ln_b,
                    const void* W2_bf16, void* q_bf16, void* k_bf16, void* vt_bf16, int B, int HW, void* stream);
 
+/* fp8 (OCP e4m3) 3x3 convolution on CDNA4's v_mfma_scale_f32_16x16x128_f8f6f4 — BASELINE.json configs[4]; no reference
+ * counterpart (the reference runs SD in fp16, gill/models.py:550-551).  x (B,H,W,Cin) bf16 NHWC, w (Cout,Cin,3,3) fp32,
+ * optional bias (Cout) fp32 and residual (B,H,W,Cout) bf16 -> y (B,H,W,Cout) bf16.  Operands are quantised inside
+ * (activations x 8 per tensor, weights per output channel).  splitk 0 = heuristic. */
 int gill_op_conv3x3_fp8(const void* x_bf16, const float* w_oihw, const float* bias, const void* resid_bf16, void* y_bf16,
                         int B, int H, int W, int Cin, int Cout, int splitk, void* stream);
 

@@ -34,17 +34,25 @@ def xf(tag, hw, c):
   dp = 48 if d <= 48 else (64 if d <= 64 else (80 if d <= 80 else (128 if d <= 128 else 160)))
   hq = heads * dp
   dpv = (dp + 31) // 32 * 32
-  r = c + c            # GN-apply reads x ; proj_in reads n
-  w = c + c            # n ; t
-  r += c; w += 2 * hq + heads * dpv     # QKV: reads t, writes q, k, vt
-  r += 2 * hq + heads * dpv; w += hq    # self-attention
-  r += hq + c; w += c                   # out1 (+ residual t)
-  r += c; w += hq                       # to_q of the cross-attention
-  r += hq; w += hq                      # cross-attention (K/V of 77 tokens: negligible)
-  r += hq + c; w += c                   # out2
-  r += c; w += 4 * c                    # GEGLU
-  r += 4 * c + c; w += c                # FF out (+ residual)
-  r += c + c; w += c                    # proj_out (+ outer residual)
+  r = c; w = c                          # GN-apply: x -> n
+  if c == 320:
+    # level 0: the row-resident kernels (lnproj.hip, ffn.hip) keep t's LayerNorm-ed copy, the GEGLU product, the feed-forward output
+    # and the attn2.to_out result in registers
+    r += c; w += c + 2 * hq + heads * dpv                 # lnproj 0: n -> t, q, k, vt
+    r += 2 * hq + heads * dpv; w += hq                    # self-attention
+    r += hq + c; w += c + hq                              # lnproj 1: o, t -> t, q
+    r += hq; w += hq                                      # cross-attention (K/V of 77 tokens: negligible)
+    r += hq + c + c; w += c                               # ffn (PRE form): o, t, outer residual x -> out
+  else:
+    r += c; w += c                                        # proj_in: n -> t
+    r += c; w += 2 * hq + heads * dpv                     # QKV: reads t, writes q, k, vt
+    r += 2 * hq + heads * dpv; w += hq                    # self-attention
+    r += hq + c; w += c                                   # out1 (+ residual t)
+    r += c; w += hq                                       # to_q of the cross-attention
+    r += hq; w += hq                                      # cross-attention
+    r += hq + c; w += c                                   # out2
+    r += c; w += 4 * c                                    # GEGLU
+    r += 4 * c + c + c; w += c                            # [Wp W2 | Wp] GEMM over [h | t] + outer residual x -> out
   add(tag + " transformer", px * r, px * w)
 
 
