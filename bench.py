@@ -23,8 +23,10 @@ import subprocess
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before HIP initialises: see gill_amd/__init__.py
+
+import torch                      # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

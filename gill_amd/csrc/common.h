@@ -14,36 +14,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define GILL_WAVE 64
 
-// Bulk output stores.  GILL_WT_STORES=1: write-through (sc1) — the bytes leave the XCD's L2 as they are written instead of sitting dirty
-// until the end-of-kernel release writes the whole output back at once (tools/ubench/boundary.hip: a kernel that ends in a 20 MB store
-// burst, and the pair with its consumer, are 0.8-0.9 us shorter; where the consumer runs — same CU, same XCD, another XCD — makes no
-// difference: L2 contents do not survive a kernel boundary).  The asm store is invisible to the compiler's vmcnt bookkeeping (nothing
-// waits for a store; the hardware counter still holds it) and ends in s_nop 1 so that the next instruction cannot overwrite its data
-// registers before they are read (cdna_hip_programming.md section 5.7).
-typedef __attribute__((ext_vector_type(4))) unsigned int gill_u32x4;
-typedef __attribute__((ext_vector_type(2))) unsigned int gill_u32x2;
-#ifndef GILL_WT_STORES
-#define GILL_WT_STORES 0
-#endif
-__device__ __forceinline__ void st_out16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-#if GILL_WT_STORES
-  const gill_u32x4 v = {a, b, c, d};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#else
-  *reinterpret_cast<uint4*>(p) = make_uint4(a, b, c, d);
-#endif
-}
-__device__ __forceinline__ void st_out8(void* p, uint32_t a, uint32_t b) {
-#if GILL_WT_STORES
-  const gill_u32x2 v = {a, b};
-  asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
-#else
-  *reinterpret_cast<uint2*>(p) = make_uint2(a, b);
-#endif
-}
-__device__ __forceinline__ void st_out16f(void* p, float a, float b, float c, float d) {
-  st_out16(p, __float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d));
-}
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 

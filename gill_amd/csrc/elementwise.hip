@@ -409,34 +409,22 @@ int dup_pair_launch(void* a, const void* b, void* b2, size_t bytes, hipStream_t 
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }
-// Weight prefetch: one 4-byte read per 128-byte line pulls byte ranges from HBM into the Infinity Cache ahead of the GEMMs that stream
-// them (unet.hip: the UNet's 1.7 GB of weights cycle through a 256 MB cache every forward, so every GEMM meets its weights HBM-cold;
-// with the weights touched right before each GEMM the forward's GEMM kernels are 3.4 % shorter, profiles/r04_weight_touch.md).
-// `blocks` bounds the rate: a few dozen blocks are a background stream next to the forward's own kernels.  Non-temporal loads: the
-// lines are wanted in the memory-side cache, not in the L2 of whichever XCD the touching workgroup happens to run on.
+// tools (unet.hip, GILL_UNET_TOUCH_W): one 4-byte read per 128-byte line pulls a byte range from HBM into the Infinity Cache
 __device__ unsigned int g_touch_sink;
-__global__ __launch_bounds__(256) void touch_ranges_kernel(const TouchArgs a) {
+__global__ __launch_bounds__(256) void touch_bytes_kernel(const uint32_t* __restrict__ src, int64_t nlines) {
   uint32_t acc = 0;
-  for (int r = 0; r < a.n; ++r) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.p[r]);
-    const int64_t nlines = a.lines[r];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nlines; i += (int64_t)gridDim.x * blockDim.x)
-      acc ^= __builtin_nontemporal_load(src + i * 32);
-  }
-  if (acc == 0x9E3779B9u && a.n < 0) g_touch_sink = acc;     // (never true: keeps the loads)
-}
-int touch_ranges_launch(const TouchArgs& a, int blocks, hipStream_t s) {
-  if (a.n <= 0) return 0;
-  hipLaunchKernelGGL(touch_ranges_kernel, dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3(256), 0, s, a);
-  GILL_CHECK_HIP(hipGetLastError());
-  return 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nlines; i += (int64_t)gridDim.x * blockDim.x)
+    acc ^= __builtin_nontemporal_load(src + i * 32);
+  if (acc == 0x9E3779B9u && nlines < 0) g_touch_sink = acc;     // (never true: keeps the loads)
 }
 int touch_bytes_launch(const void* src, size_t bytes, int blocks, hipStream_t s) {
-  TouchArgs a;
-  a.n = 1; a.p[0] = src; a.lines[0] = (int64_t)(bytes / 128);
-  if (a.lines[0] == 0) return 0;
-  const int64_t g = (a.lines[0] + 255) / 256;
-  return touch_ranges_launch(a, (int)(g < blocks ? g : blocks), s);
+  const int64_t nlines = (int64_t)(bytes / 128);
+  if (nlines == 0) return 0;
+  int64_t g = (nlines + 255) / 256;
+  if (g > blocks) g = blocks;
+  hipLaunchKernelGGL(touch_bytes_kernel, dim3((unsigned)g), dim3(256), 0, s, (const uint32_t*)src, nlines);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 int zero_bytes_launch(void* dst, size_t bytes, hipStream_t s) {
   GILL_REQUIRE(((uintptr_t)dst & 15) == 0 && (bytes & 15) == 0, "zero_bytes: 16-byte alignment required");

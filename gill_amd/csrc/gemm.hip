@@ -100,7 +100,8 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0
   }
   if (fin) { fin[0] = v[0]; fin[1] = v[1]; fin[2] = v[2]; fin[3] = v[3]; }
   if (p.out_mode == OUT_BF16) {
-    st_out8((bf16_t*)p.C + (size_t)m * p.ldc + n, pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+    *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
   } else if (p.out_mode == OUT_F32) {
     *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
   } else {  // OUT_QKV
@@ -641,8 +642,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
         const int n = nbase + (pair ? g * 32 + fkc * 8 : (2 * g) * 16 + fkc * 4);
         if (n >= p.N) continue;
         float* dst = ws + (size_t)m * p.N + n;
-        st_out16f(dst, acc[i][2 * g][0], acc[i][2 * g][1], acc[i][2 * g][2], acc[i][2 * g][3]);
-        if (pair && n + 4 < p.N) st_out16f(dst + 4, acc[i][j1][0], acc[i][j1][1], acc[i][j1][2], acc[i][j1][3]);
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[i][2 * g][0], acc[i][2 * g][1], acc[i][2 * g][2], acc[i][2 * g][3]);
+        if (pair && n + 4 < p.N)
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[i][j1][0], acc[i][j1][1], acc[i][j1][2], acc[i][j1][3]);
       }
     }
   } else if constexpr (EPI == 1) {
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
           o[4 * h + 3] = (av[3] * rr[i] - rm[i] * sv[h].w + bv[h].w) * gelu_erf(ag[3] * rr[i] - rm[i] * sg[h].w + bg[h].w);
         }
         uint4 ov; ov.x = pack_bf2(o[0], o[1]); ov.y = pack_bf2(o[2], o[3]); ov.z = pack_bf2(o[4], o[5]); ov.w = pack_bf2(o[6], o[7]);
-        if (m < p.M) st_out16((bf16_t*)p.C + (size_t)m * p.ldc + no, ov.x, ov.y, ov.z, ov.w);
+        if (m < p.M) *reinterpret_cast<uint4*>((bf16_t*)p.C + (size_t)m * p.ldc + no) = ov;
       }
     }
   } else if constexpr (EPI == 3) {
@@ -744,7 +746,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
           bf16_t* dst = (seg == 0) ? p.Cq + (size_t)rq[i] + (size_t)h * p.ntok_pad_q * p.dp + dd
                                    : p.Ck + (size_t)rk[i] + (size_t)h * p.ntok_pad_kv * p.dp + dd;
           if (hi) {
-            st_out16(dst, pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+            uint4 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
+            *reinterpret_cast<uint4*>(dst) = o;
           } else {
             uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
             *reinterpret_cast<uint2*>(dst) = o;
@@ -902,8 +905,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
           if (st && hi) *reinterpret_cast<float4*>((float*)p.C + crow[i] + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
           uint4 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
-          if (st && hi) st_out16((bf16_t*)p.C + crow[i] + n, o.x, o.y, o.z, o.w);
-          else if (st) st_out8((bf16_t*)p.C + crow[i] + n, o.x, o.y);
+          if (st && hi) *reinterpret_cast<uint4*>((bf16_t*)p.C + crow[i] + n) = o;
+          else if (st) *reinterpret_cast<uint2*>((bf16_t*)p.C + crow[i] + n) = make_uint2(o.x, o.y);
           if (CONV == 0 && p.row_stats) {   // statistics of what the consumer will read: the rounded values (columns beyond N: none)
             const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
             const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);

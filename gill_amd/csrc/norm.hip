@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
         } else {
           gn_u32x4 wv;
           wv[0] = pack_bf2(o[0], o[1]); wv[1] = pack_bf2(o[2], o[3]); wv[2] = pack_bf2(o[4], o[5]); wv[3] = pack_bf2(o[6], o[7]);
-          st_out16(y + row * C + c, wv[0], wv[1], wv[2], wv[3]);
+          *reinterpret_cast<gn_u32x4*>(y + row * C + c) = wv;
         }
       }
     }

@@ -236,10 +236,6 @@ struct SdLoopArgs {
 // plain device-side fill / copy kernels for use INSIDE a captured forward: hipMemsetAsync / hipMemcpyAsync become memset /
 // memcpy graph nodes, whose replay was not reliable (profiles/r02_soak_bisect.md).  16-byte aligned pointers and sizes.
 int zero_bytes_launch(void* dst, size_t bytes, hipStream_t s);
-// weight prefetch (elementwise.hip): touch one word per 128-byte line of up to TOUCH_MAX_RANGES byte ranges
-#define TOUCH_MAX_RANGES 16
-struct TouchArgs { const void* p[TOUCH_MAX_RANGES]; int64_t lines[TOUCH_MAX_RANGES]; int n = 0; };
-int touch_ranges_launch(const TouchArgs& a, int blocks, hipStream_t s);
 int touch_bytes_launch(const void* src, size_t bytes, int blocks, hipStream_t s);
 int copy_bytes_launch(void* dst, const void* src, size_t bytes, hipStream_t s);
 int dup_pair_launch(void* a, const void* b, void* b2, size_t bytes, hipStream_t s);   // a[bytes..] := a[0..bytes); b2[0..bytes) = b2[bytes..] := b[0..bytes)

@@ -150,20 +150,8 @@ struct gill_unet {
   // The denoise loop runs on the handle's private stream, fenced to the caller's stream by events (capture needs a
   // non-NULL stream anyway; see DESIGN.md "hipGraph replay and the NULL stream").
   StreamFence fence;
-  // Weight prefetch (GILL_UNET_PREFETCH=0 turns it off): the forward's weight-bearing launches in order, cut into segments of
-  // ~pf_seg_bytes.  When the launch stream reaches the first launch of segment k, a side stream (forked and joined by events, so it
-  // is a parallel branch of the captured graph) touches the weights of segment k + 1 (the last segment: of segment 0, for the next
-  // forward of the loop) — they are in the Infinity Cache when their GEMMs arrive.
-  struct PfSeg { int first_launch = 0; std::vector<TouchArgs> touches; size_t bytes = 0; };
-  std::map<GraphKey, std::vector<PfSeg>> pf_plans;
-  hipStream_t pf_stream = nullptr;
-  hipEvent_t pf_fork = nullptr, pf_join = nullptr;
-  bool pf_on = true; size_t pf_seg_bytes = (size_t)48 << 20; int pf_blocks = 64;
   ~gill_unet() {
     for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
-    if (pf_fork) (void)hipEventDestroy(pf_fork);
-    if (pf_join) (void)hipEventDestroy(pf_join);
-    if (pf_stream) (void)hipStreamDestroy(pf_stream);
   }
 };
 
@@ -555,37 +543,6 @@ struct UNetRun {
   // classifier-free-guidance pair: samples b and b + Bx/2 carry the same latents and timestep and differ only in the prompt,
   // so everything before the first cross-attention runs once on the first half (gill_sd_denoise sets this)
   bool cfg_pair = false;
-  // weight prefetch: `pf_rec` (recording pass: every weight-bearing launch notes its byte range) or `pf_plan` (see gill_unet::PfSeg)
-  struct PfNote { int launch; const void* p; size_t bytes; };
-  std::vector<PfNote>* pf_rec = nullptr;
-  const std::vector<gill_unet::PfSeg>* pf_plan = nullptr;
-  int pf_launch = 0, pf_next = 0;
-  bool pf_forked = false;
-  int note_weights(const void* w, size_t bytes) {
-    if (dry) return 0;
-    if (pf_rec) pf_rec->push_back(PfNote{pf_launch, w, bytes});
-    if (pf_plan) {
-      const int nseg = (int)pf_plan->size();
-      while (pf_next < nseg && (*pf_plan)[pf_next].first_launch == pf_launch) {
-        const gill_unet::PfSeg& tgt = (*pf_plan)[(pf_next + 1) % nseg];
-        GILL_CHECK_HIP(hipEventRecord(m->pf_fork, s));
-        GILL_CHECK_HIP(hipStreamWaitEvent(m->pf_stream, m->pf_fork, 0));
-        for (const TouchArgs& t : tgt.touches) GILL_TRY(touch_ranges_launch(t, m->pf_blocks, m->pf_stream));
-        pf_forked = true;
-        ++pf_next;
-      }
-    }
-    ++pf_launch;
-    return 0;
-  }
-  int pf_finish() {      // join the side stream back (a capture must end with every forked stream joined)
-    if (!pf_forked) return 0;
-    GILL_CHECK_HIP(hipEventRecord(m->pf_join, m->pf_stream));
-    GILL_CHECK_HIP(hipStreamWaitEvent(s, m->pf_join, 0));
-    pf_forked = false;
-    return 0;
-  }
-
   // GILL_DEBUG_SYNC=1 (tools): synchronise after every launch of the forward and say which one it was, to attribute a device fault
   int dbg_sync(const char* what, int a = 0, int b = 0, int c = 0) {
     static const bool on = getenv("GILL_DEBUG_SYNC") != nullptr;
@@ -638,9 +595,10 @@ struct UNetRun {
     pick_sk(g);
     if (rs) { g.row_stats = rs->p; rs->planes = gemm_row_planes(g); }
     if (ys && ys->stats) ys->nslab = ys->H * ys->W / gemm_gn_slab_rows(g);
-    GILL_TRY(note_weights(g.W, sizeof(bf16_t) * (size_t)g.N * g.K * ((g.conv && g.ups == 2) ? 4 : 1)));
     {   // tools: GILL_UNET_TOUCH_W=1 pulls every GEMM's weights into the Infinity Cache right before it (on the same stream) — the
-        // kernel trace then shows what each GEMM costs with warm weights, i.e. what an ideal weight prefetcher could buy
+        // kernel trace then shows what each GEMM costs with warm weights (-3.4 % of a forward), i.e. what an ideal weight prefetcher could
+        // buy.  A real one — a side stream touching the next ~48 MB of weights as a parallel branch of the captured graph — was built and
+        // measured: the loop got 4.5-15 % SLOWER, eager or captured, at any rate (profiles/r04_weight_prefetch.md); removed
       static const bool touch = getenv("GILL_UNET_TOUCH_W") != nullptr;
       if (touch) GILL_TRY(touch_bytes_launch(g.W, sizeof(bf16_t) * (size_t)g.N * g.K * ((g.conv && g.ups == 2) ? 4 : 1), 1024, s));
     }
@@ -814,7 +772,6 @@ struct UNetRun {
     lp.Cq = q; lp.Ck = k; lp.Cvt = vt; lp.qscale = 1.4426950408889634f / sqrtf((float)w.d);
     if (lnproj) {
       lp.mode = 0; lp.X = n.p; lp.W1 = w.proj_in.w; lp.b1 = w.proj_in.b; lp.W2p = w.wqkv1p; lp.c2 = w.c_qkv1;
-      GILL_TRY(note_weights(w.wqkv1p, sizeof(bf16_t) * (size_t)3 * hdp * C));
       if (!dry) GILL_TRY(lnproj_launch(lp, s));
     } else {
       GemmArgs g;
@@ -867,7 +824,6 @@ struct UNetRun {
         if (ffn_pre) { fa.X = o; fa.Wo = w.out2.w; fa.bo2 = w.out2.b; fa.Wpp = w.wpp; }
         if (out->stats && out->sbin == 5) { fa.gn_stats = out->stats; fa.rows_per_batch = HW; out->nslab = HW / GN_SLAB_ROWS; }
         else out->stats = nullptr;        // (no partials from this producer: the consumer runs its own statistics pass)
-        GILL_TRY(note_weights(w.w1c, sizeof(bf16_t) * (size_t)8 * C * C));
         GILL_TRY(ffn_fused_launch(fa, s));
       }
       m->arena.release(mk);
@@ -954,7 +910,6 @@ struct UNetRun {
     GILL_TRY(dbg_sync("last groupnorm"));
     if (!dry) GILL_TRY(conv_out_launch(n.p, m->conv_out_w, m->conv_out_b, Bx, ch[0], L, L, c.out_channels, eps_out, s));
     GILL_TRY(dbg_sync("conv_out"));
-    GILL_TRY(pf_finish());
     // (a real run must never need more than the dry run of unet_plan_and_alloc() counted)
     GILL_REQUIRE(dry || m->arena.high <= m->arena.cap, "internal: activation arena overflow (the dry run and the real run allocate differently)");
     return 0;
@@ -1018,9 +973,6 @@ static int unet_plan_and_alloc(gill_unet* m) {
   GILL_TRY(m->pool.alloc(&m->step_ctr, (size_t)2));
   GILL_TRY(m->pool.alloc(&m->guidance_dev, (size_t)4));
   { const char* e = getenv("GILL_NO_GRAPH"); m->use_graph = !(e && e[0] == '1'); }
-  { const char* e = getenv("GILL_UNET_PREFETCH"); m->pf_on = !(e && e[0] == '0'); }
-  { const char* e = getenv("GILL_PF_SEG_MB"); if (e && atoi(e) > 0) m->pf_seg_bytes = (size_t)atoi(e) << 20; }
-  { const char* e = getenv("GILL_PF_BLOCKS"); if (e && atoi(e) > 0) m->pf_blocks = atoi(e); }
   if (getenv("GILL_DEBUG_SYNC")) m->use_graph = false;   // dbg_sync() synchronises the stream after every launch: illegal inside a capture
   return 0;
 }
@@ -1131,32 +1083,6 @@ extern "C" int gill_sd_denoise(gill_unet* m, const void* cond_bf16, const void* 
   return rc;
 }
 
-// Cut the recorded weight ranges of one forward into prefetch segments (gill_unet::PfSeg).
-static int unet_pf_plan(gill_unet* m, const GraphKey& key, const std::vector<UNetRun::PfNote>& notes) {
-  if (!m->pf_stream) {
-    GILL_CHECK_HIP(hipStreamCreateWithFlags(&m->pf_stream, hipStreamNonBlocking));
-    GILL_CHECK_HIP(hipEventCreateWithFlags(&m->pf_fork, hipEventDisableTiming));
-    GILL_CHECK_HIP(hipEventCreateWithFlags(&m->pf_join, hipEventDisableTiming));
-  }
-  std::vector<gill_unet::PfSeg> plan;
-  gill_unet::PfSeg cur;
-  TouchArgs ta;
-  auto flush_touch = [&]() { if (ta.n > 0) { cur.touches.push_back(ta); ta = TouchArgs(); } };
-  auto flush_seg = [&]() { flush_touch(); if (cur.bytes > 0) plan.push_back(cur); cur = gill_unet::PfSeg(); };
-  for (const UNetRun::PfNote& nt : notes) {
-    if (nt.bytes < 128) continue;
-    if (cur.bytes == 0) cur.first_launch = nt.launch;
-    if (ta.n == TOUCH_MAX_RANGES) flush_touch();
-    ta.p[ta.n] = nt.p; ta.lines[ta.n] = (int64_t)(nt.bytes / 128); ++ta.n;
-    cur.bytes += nt.bytes;
-    if (cur.bytes >= m->pf_seg_bytes) flush_seg();
-  }
-  flush_seg();
-  if (plan.size() < 2) plan.clear();     // (a model whose weights fit one segment stays cached anyway)
-  m->pf_plans[key] = plan;
-  return 0;
-}
-
 static int sd_denoise_on(gill_unet* m, const void* cond_bf16, const void* uncond_bf16, int n_uncond, const float* latents0, int B,
                          int num_steps, float guidance, float* latents_out, hipStream_t s) {
   GILL_REQUIRE(num_steps >= 2 && num_steps <= 1000, "num_steps out of range");
@@ -1245,18 +1171,11 @@ static int sd_denoise_on(gill_unet* m, const void* cond_bf16, const void* uncond
   la.B = B; la.n = n_lat; la.guidance = m->guidance_dev; la.cfg = cfg ? 1 : 0;
   // the graph bakes in B and the CFG flag besides the buffer addresses
   const GraphKey gkey{Bx, cfg ? 1 : 0};
-  std::vector<UNetRun::PfNote> pf_notes;
   auto one_step = [&](hipStream_t st) -> int {
     GILL_TRY(sd_stage_launch(la, st));
     UNetRun r{m, st, Bx, m->temb_cur, 0, false};
     r.cfg_pair = cfg;
-    if (m->pf_on) {
-      auto pit = m->pf_plans.find(gkey);
-      if (pit != m->pf_plans.end()) r.pf_plan = &pit->second;    // (an empty plan: no segment ever matches)
-      else r.pf_rec = &pf_notes;                                  // first forward of this batch size: record
-    }
     GILL_TRY(r.forward(m->lat2, m->eps));
-    if (r.pf_rec) GILL_TRY(unet_pf_plan(m, gkey, pf_notes));
     return plms_step_launch(la, st);
   };
   for (int i = 0; i < ncalls; ++i) {
