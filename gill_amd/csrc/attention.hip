@@ -334,6 +334,10 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
 //   * The tile loop is unrolled by two so that the ring stage is a compile-time constant: every LDS address is a loop-invariant lane
 //     offset + an immediate.
 // Everything else (transposed S^T / O^T, P in registers, ones-row of V^T carrying the row sum, XCD map, rotated tile walk) is as above.
+// Measured (8 x 8 heads x 4096^2, rocprofv3): 241-246 us against 290 us for the register-staged kernel; loop 479.8 -> 473.6 ms.
+// Two software-pipelined forms (scores of TWO tiles live: QK^T of tile t + 1 beside the softmax of tile t) were built, parity-green,
+// and measured no faster (profiles/r04_attention.md): left to hipcc's own order (which clusters the six QK^T MFMAs) 260-273 us and
+// loop +0.8 %; with a sched_group_barrier order "1 MFMA, 1 LDS read, 7 VALU" over the whole tile (148 VGPRs) loop +-0.3 %.  Removed.
 template <int DP, int ATT_THREADS>
 __global__ __launch_bounds__(ATT_THREADS, 4) void attention_dma_kernel(const AttnArgs p) {
   static_assert(DP == 48, "QF3 needs three padding dims behind d = 40");
@@ -544,254 +548,6 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attention_dma_kernel(const Att
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Software-pipelined form of attention_dma_kernel: the QK^T MFMAs of tile t + 1 are issued BESIDE the softmax of tile t.
-//
-// In the kernel above a wave's tile is three dependent phases — QK^T (6 MFMAs, matrix pipe only), running max (18 dependent VALU
-// operations, VALU only), exp / pack interleaved with PV (8 MFMAs) — and the one barrier per tile keeps all waves of a workgroup in the
-// same phase, so the matrix pipe idles through every max / exp phase: 448 cycles of MFMA in a ~960-cycle tile.  Here a wave holds the
-// scores of TWO tiles (s_cur: being exponentiated, s_next: being accumulated), so its own instruction stream always has independent
-// MFMA and VALU work to interleave.  K runs one tile ahead of V in the rings (both two stages deep: K(t + 2) lands in the stage K(t)
-// left, V(t + 1) in the stage V(t - 1) left); a slow-path update of the running max also shifts the already computed s_next.
-template <int DP, int ATT_THREADS, int WPE>
-__global__ __launch_bounds__(ATT_THREADS, WPE) void attention_dma2_kernel(const AttnArgs p) {
-  static_assert(DP == 48, "QF3 needs three padding dims behind d = 40");
-  constexpr int NW = ATT_THREADS / 64;
-  constexpr int ATT_QB = ATT_THREADS / 2;
-  constexpr int KS = DP / 16, NDT = (DP + 31) / 32, NCH = DP / 8;
-  constexpr int PPW = 8 / NW;
-  constexpr int IMG = 64 * 128;                       // one [64 rows][128 B] tile image
-  constexpr int K_OFF = 0, V_OFF = 2 * IMG, CONST_OFF = 4 * IMG;      // [K stage 0 | K stage 1 | V stage 0 | V stage 1 | const]
-  extern __shared__ __attribute__((aligned(16))) unsigned char att_smem_raw[];
-  unsigned char* smem = att_smem_raw;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nqt = p.nq / ATT_QB;
-  int pair, qtile;
-  if (p.xcd_map) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    pair = xcd + 8 * (slot / nqt);
-    qtile = slot - (slot / nqt) * nqt;
-  } else {
-    pair = blockIdx.x / nqt;
-    qtile = blockIdx.x - pair * nqt;
-  }
-  if (pair >= p.B * p.H) return;
-  const int b = pair / p.H, h = pair - b * p.H;
-  const int q0 = qtile * ATT_QB + w * 32;
-  const int lq = lane & 31;
-  const int hi = lane >> 5;
-  const int kvb = p.kv_bstride_zero ? 0 : b;
-
-  const bf16_t* Qb = p.Q + (size_t)(b * p.H + h) * p.nq_pad * DP;
-  const bf16_t* Kb = p.K + (size_t)(kvb * p.H + h) * p.nkv_pad * DP;
-  const bf16_t* Vb = p.Vt + (size_t)(kvb * p.H + h) * p.dpv * p.nkv_pad;
-  const int qrow = q0 + lq;
-
-  if (tid == 0) *reinterpret_cast<uint4*>(smem + CONST_OFF) = make_uint4(0x3F803F80u, 0x00003F80u, 0u, 0u);
-
-  bf16x8 qf[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Qb + (size_t)qrow * DP + s * 16 + hi * 8);
-
-  const int r8 = lane >> 3, pch = lane & 7;
-  unsigned koff[PPW], voff[PPW];
-#pragma unroll
-  for (int j = 0; j < PPW; ++j) {
-    const int i = (w * PPW + j) * 8 + r8;
-    const int c = pch ^ ((i >> 1) & 7);
-    const int key = (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
-    const int ck = c >= NCH ? c - NCH : c;
-    koff[j] = (unsigned)((key * DP + ck * 8) * 2);
-    voff[j] = (unsigned)((i * p.nkv_pad + c * 8) * 2);
-  }
-  const int ntiles = (p.nkv + ATT_KVT - 1) / ATT_KVT;
-  const int rot = p.xcd_map ? (qtile * 5) % ntiles : 0;
-  auto tile_of = [&](int it) { int t = it + rot; return t >= ntiles ? t - ntiles : t; };
-  auto issue_k = [&](int it, int stage) {
-    const char* kbase = (const char*)(Kb + (size_t)tile_of(it) * ATT_KVT * DP);
-    unsigned char* dst = smem + K_OFF + stage * IMG + (w * PPW) * 1024;
-#pragma unroll
-    for (int j = 0; j < PPW; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + koff[j]),
-                                       (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
-  };
-  auto issue_v = [&](int it, int stage) {
-    const char* vbase = (const char*)(Vb + (size_t)tile_of(it) * ATT_KVT);
-    unsigned char* dst = smem + V_OFF + stage * IMG + (w * PPW) * 1024;
-#pragma unroll
-    for (int j = 0; j < PPW; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + voff[j]),
-                                       (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
-  };
-  int fo[4];
-#pragma unroll
-  for (int c4 = 0; c4 < 4; ++c4) fo[c4] = lq * 128 + (((2 * c4 + hi) ^ ((lq >> 1) & 7)) * 16);
-  int k2a[2][2];
-#pragma unroll
-  for (int st = 0; st < 2; ++st)
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) k2a[st][hh] = hi ? CONST_OFF : K_OFF + st * IMG + hh * 4096 + fo[2];
-
-  // S^T of one tile from K stage `stg` (compile-time) on a zero accumulator; the running max rides in q[40..42] (QF3)
-  auto qk = [&](f32x16 (&sc)[2], auto stg) {
-    constexpr int STG = decltype(stg)::value;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const bf16x8 kf = (ks == 2) ? *reinterpret_cast<const bf16x8*>(smem + k2a[STG][hh])
-                                    : *reinterpret_cast<const bf16x8*>(smem + K_OFF + STG * IMG + hh * 4096 + fo[ks]);
-        if (ks == 0) sc[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
-        else sc[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[hh], 0, 0, 0);
-      }
-    }
-  };
-
-  f32x16 oacc[NDT];
-#pragma unroll
-  for (int t = 0; t < NDT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-  float m_run = 0.f;
-  f32x16 sA[2], sB[2];
-
-  issue_k(0, 0);
-  issue_v(0, 0);
-  if (ntiles > 1) issue_k(1, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  qk(sA, std::integral_constant<int, 0>{});
-  __builtin_amdgcn_s_barrier();           // every wave has read K stage 0 before iteration 0 refills it
-  asm volatile("" ::: "memory");
-
-  // iteration `it`: cur = scores of tile it (already accumulated), nxt = scores of tile it + 1 (accumulated here); PAR = it & 1:
-  // K(it + 1) sits in K stage PAR ^ 1, V(it) in V stage PAR; K(it + 2) is loaded into K stage PAR, V(it + 1) into V stage PAR ^ 1
-  auto body = [&](int it, f32x16 (&cur)[2], f32x16 (&nxt)[2], auto par) {
-    constexpr int PAR = decltype(par)::value;
-    const int kv0 = tile_of(it) * ATT_KVT;
-    const bool has_next = it + 1 < ntiles;
-    if (it + 2 < ntiles) issue_k(it + 2, PAR);
-    if (has_next) issue_v(it + 1, PAR ^ 1);
-    if (has_next) qk(nxt, std::integral_constant<int, PAR ^ 1>{});
-    if (kv0 + ATT_KVT > p.nkv) {      // ragged last tile (wave-uniform)
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kv = kv0 + hh * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-          cur[hh][r] = (kv >= p.nkv) ? -INFINITY : cur[hh][r];
-        }
-    }
-    float mx = cur[0][0];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, cur[hh][r]);
-    const bool first = (it == 0);
-    if (first || __any(mx > 8.0f)) {
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float delta;
-      if (first) delta = (mx > -INFINITY) ? mx : 0.f;
-      else delta = fmaxf(mx, 0.f);
-      m_run += delta;
-      {
-        const float x = -m_run;
-        const bf16_t a0 = f2bf(x);
-        const float r1 = x - bf2f(a0);
-        const bf16_t a1 = f2bf(r1);
-        const float r2 = r1 - bf2f(a1);
-        const bf16_t a2 = f2bf(r2);
-        union { bf16x8 v; uint32_t u[4]; } xq;
-        xq.v = qf[2];
-        if (hi) { xq.u[0] = (uint32_t)a0 | ((uint32_t)a1 << 16); xq.u[1] = (uint32_t)a2; }
-        qf[2] = xq.v;
-      }
-      if (!first) {
-        const float alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-        for (int t = 0; t < NDT; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
-      }
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cur[hh][r] -= delta;
-      if (has_next) {       // the next tile's scores were accumulated against the old offset
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) nxt[hh][r] -= delta;
-      }
-    }
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) cur[hh][r] = __builtin_amdgcn_exp2f(cur[hh][r]);
-    bf16x8 pa[4];
-#pragma unroll
-    for (int h4 = 0; h4 < 4; ++h4) {
-      union { bf16x8 v; uint32_t u[4]; } pk;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) pk.u[j] = pack_bf2(cur[h4 >> 1][(h4 & 1) * 8 + 2 * j], cur[h4 >> 1][(h4 & 1) * 8 + 2 * j + 1]);
-      pa[h4] = pk.v;
-    }
-#pragma unroll
-    for (int t = 0; t < NDT; ++t) {
-#pragma unroll
-      for (int h4 = 0; h4 < 4; ++h4) {
-        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(smem + V_OFF + PAR * IMG + t * 4096 + fo[h4]);
-        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pa[h4], oacc[t], 0, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  };
-  for (int it = 0; it < ntiles; it += 2) {
-    body(it, sA, sB, std::integral_constant<int, 0>{});
-    if (it + 1 < ntiles) body(it + 1, sB, sA, std::integral_constant<int, 1>{});
-  }
-
-  static_assert(DP % 32 == 16, "ones-row position");
-  const float l_run = __shfl(oacc[DP / 32][8], lq, 64);
-  const float inv = 1.f / l_run;
-  bf16_t* orow = p.O + (size_t)(b * p.nq + qrow) * p.ldo + h * DP;
-#pragma unroll
-  for (int t = 0; t < NDT; ++t) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int d = t * 32 + 8 * g + 4 * hi;
-      if (d < DP) {
-        uint2 o;
-        o.x = pack_bf2(oacc[t][g * 4 + 0] * inv, oacc[t][g * 4 + 1] * inv);
-        o.y = pack_bf2(oacc[t][g * 4 + 2] * inv, oacc[t][g * 4 + 3] * inv);
-        *reinterpret_cast<uint2*>(orow + d) = o;
-      }
-    }
-  }
-}
-
-template <int DP, int NTHR, int WPE>
-static int attention_dma2_launch(const AttnArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  constexpr int smem = 4 * 64 * 128 + 64;
-  if (!attr_set) {
-    GILL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_dma2_kernel<DP, NTHR, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
-  static const int xcd_on = [] { const char* e = getenv("GILL_ATT_XCD"); return e ? atoi(e) : 1; }();
-  AttnArgs b = a;
-  b.xcd_map = xcd_on;
-  dim3 grid((xcd_on ? 8 * cdiv(a.H * a.B, 8) : a.H * a.B) * (a.nq / (NTHR / 2)), 1, 1);
-  hipLaunchKernelGGL((attention_dma2_kernel<DP, NTHR, WPE>), grid, dim3(NTHR), smem, s, b);
-  GILL_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
 template <int DP, int NTHR>
 static int attention_dma_launch(const AttnArgs& a, hipStream_t s) {
   static bool attr_set = false;
@@ -841,11 +597,6 @@ static int attention_launch_dp(const AttnArgs& a, hipStream_t s) {
   static const int forced = [] { const char* e = getenv("GILL_ATT_THREADS"); return e ? atoi(e) : 0; }();   // tests / tools
   const bool big = forced == 512 || (forced != 256 && cdiv(a.nq, 256) * bh >= 256);
   if constexpr (DP == 48) {
-    // GILL_ATT_DMA: 0 register-staged kernel, 1 LDS-DMA kernel, 2 (default) its software-pipelined form (256-query workgroups where the
-    // grid fills the chip, as before; 3: always 128-query workgroups, three per CU)
-    static const int mode = [] { const char* e = getenv("GILL_ATT_DMA"); return e ? atoi(e) : 2; }();
-    if (mode >= 2 && attention_dma_ok(a, (big && mode == 2) ? 512 : 256))
-      return (big && mode == 2) ? attention_dma2_launch<DP, 512, 2>(a, s) : attention_dma2_launch<DP, 256, 3>(a, s);
     if (attention_dma_ok(a, big ? 512 : 256)) return big ? attention_dma_launch<DP, 512>(a, s) : attention_dma_launch<DP, 256>(a, s);
   }
   if (big) return attention_launch_inst<DP, 512>(a, s);
