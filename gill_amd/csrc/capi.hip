@@ -105,6 +105,32 @@ extern "C" int gill_op_conv3x3(const void* x1, int C1, const void* x2, int C2, c
   return 0;
 }
 
+// 3x3 convolution whose split-K reducer also runs the GroupNorm (+ SiLU) that consumes the output (gemm.hip "REDUCE + GROUPNORM"):
+// y_raw (optional) = conv(x) + bias + resid, y_norm = [silu](GroupNorm(y_raw; groups, gamma, beta, eps)).  H * W must be 64 or 256,
+// Cout / groups a multiple of 4 dividing 80, splitk >= 2.  For the operator tests.
+extern "C" int gill_op_conv3x3_gn(const void* x, const float* w_oihw, const float* bias, const void* resid, const float* gamma,
+                                  const float* beta, int groups, float eps, int silu, void* y_raw, void* y_norm, int B, int H, int W,
+                                  int Cin, int Cout, int splitk, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GILL_REQUIRE(x && w_oihw && gamma && beta && y_norm && groups > 0 && Cout % groups == 0 && splitk >= 2, "bad argument");
+  DevBuf wr, ws;
+  GILL_TRY(wr.alloc(sizeof(bf16_t) * (size_t)Cout * 9 * Cin));
+  GILL_TRY(conv_weight_relayout_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wr.p, s));
+  GemmArgs g;
+  g.conv = 1; g.IH = H; g.IW = W; g.OH = H; g.OW = W; g.Cin = Cin; g.stride = 1;
+  g.M = B * H * W; g.N = Cout; g.K = 9 * Cin;
+  g.A = (const bf16_t*)x; g.K1 = Cin; g.W = (const bf16_t*)wr.p; g.bias = bias;
+  g.rows_per_batch = H * W; g.resid = resid; g.ldr = Cout; g.C = y_raw; g.ldc = Cout;
+  g.splitk = splitk;
+  GILL_TRY(ws.alloc(sizeof(float) * (size_t)splitk * g.M * g.N));
+  g.ws = (float*)ws.p;
+  g.fn_Y = (bf16_t*)y_norm; g.fn_gamma = gamma; g.fn_beta = beta; g.fn_eps = eps; g.fn_silu = silu; g.fn_cg = Cout / groups;
+  GILL_REQUIRE(gemm_fused_norm_ok(g), "conv3x3_gn: unsupported geometry (H * W in {64, 256}, Cout % 80 == 0, group width | 80)");
+  for (int r = 0; r < op_repeat(); ++r) GILL_TRY(gemm_launch(g, s));
+  GILL_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 // ResnetBlock2D's conv2 with the 1x1 conv_shortcut of the raw block input fused as extra K channels (the engine's c2f weights):
 // y = conv3x3(x1 ++ x2) + bias + conv1x1(xs1 ++ xs2), one implicit GEMM with K = 9 (C1 + C2) + CS1 + CS2.  For the operator tests.
 extern "C" int gill_op_conv3x3_shortcut(const void* x1, int C1, const void* x2, int C2, const float* w_oihw, const float* bias,

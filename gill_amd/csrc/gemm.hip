@@ -1089,6 +1089,128 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
   }
 }
 
+// REDUCE + GROUPNORM.  Where a split-K GEMM's output feeds a single-source GroupNorm (every 3x3 convolution of UNet levels 2-3 at
+// the 8-sample batch: conv1 -> norm2 inside a ResnetBlock2D, and a block's last GEMM -> the next block's first norm), the reducer is
+// the first kernel that holds complete output values — and a block that owns ALL rows of one sample for a run of whole groups holds
+// complete GroupNorm statistics too.  Block = (sample b, 80 output columns = whole groups of fn_cg channels): sums the split slices
+// in slice order, applies the GEMM epilogue (bias, per-sample row vector, bf16 residual), optionally stores the raw tensor, totals
+// {sum, sum of squares} per group in a fixed order (thread -> 16 row lanes -> the group's column quads), and writes the normalised
+// (+ SiLU) tensor: the GroupNorm-apply launch of that norm (5.5-7.5 us each, 24 per forward) and its read of the raw tensor disappear.
+// Also files the fused-statistics partials of the raw output (gn_stats: one slab = the whole sample) for a later two-source consumer.
+// RPT rows per thread: rows_per_batch = 16 * RPT (256 -> 16, 64 -> 4).  Block = W columns (80 | 40): W / 4 column quads x 16 row lanes.
+template <int RPT, int W>
+__global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_gn_kernel(const GemmArgs p) {
+  constexpr int QW = W / 4, ROWS = 16 * RPT;
+  __shared__ float2 part[16][QW];        // per (row lane, column quad) {sum, sum of squares} over the thread's rows
+  __shared__ float2 quad[QW];            // per column quad, over the 16 row lanes
+  __shared__ float2 mr[QW];              // per group of the block: {mean, rstd}   (fn_cg >= 4)
+  const int tx = threadIdx.x % QW, ty = threadIdx.x / QW;
+  const int n = blockIdx.x * W + tx * 4;
+  const int b = blockIdx.y;
+  const int mbase = b * ROWS;
+  // every global load of the block goes out before the first use: the partials of the first slices, the epilogue's vectors, the
+  // residual rows, the norm's parameters — one memory round trip in front of the reduction, not four
+  float4 v[RPT];
+  const float* src = p.ws + (size_t)(mbase + ty) * p.N + n;
+  const size_t zstride = (size_t)p.M * p.N, rstride = (size_t)16 * p.N;
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) v[r] = *reinterpret_cast<const float4*>(src + (size_t)r * rstride);
+  float4 t1[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) t1[r] = *reinterpret_cast<const float4*>(src + zstride + (size_t)r * rstride);      // (splitk >= 2)
+  float4 add = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
+  const float4 rv = p.rowvec ? *reinterpret_cast<const float4*>(p.rowvec + (size_t)b * p.rowvec_bstride + n) : make_float4(0, 0, 0, 0);
+  const float4 gam = *reinterpret_cast<const float4*>(p.fn_gamma + n), bet = *reinterpret_cast<const float4*>(p.fn_beta + n);
+  uint2 rr[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r)
+    rr[r] = p.resid ? *reinterpret_cast<const uint2*>((const bf16_t*)p.resid + (size_t)(mbase + ty + 16 * r) * p.ldr + n) : make_uint2(0u, 0u);
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) { v[r].x += t1[r].x; v[r].y += t1[r].y; v[r].z += t1[r].z; v[r].w += t1[r].w; }
+  for (int z = 2; z < p.splitk; ++z) {
+    float4 t[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) t[r] = *reinterpret_cast<const float4*>(src + (size_t)z * zstride + (size_t)r * rstride);
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) { v[r].x += t[r].x; v[r].y += t[r].y; v[r].z += t[r].z; v[r].w += t[r].w; }
+  }
+  add.x += rv.x; add.y += rv.y; add.z += rv.z; add.w += rv.w;
+  float ps = 0.f, pq = 0.f;
+  uint2 raw[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const int m = mbase + ty + 16 * r;
+    v[r].x += add.x; v[r].y += add.y; v[r].z += add.z; v[r].w += add.w;
+    v[r].x += bf2f((bf16_t)(rr[r].x & 0xffff)); v[r].y += bf2f((bf16_t)(rr[r].x >> 16));        // (zeros without a residual)
+    v[r].z += bf2f((bf16_t)(rr[r].y & 0xffff)); v[r].w += bf2f((bf16_t)(rr[r].y >> 16));
+    ps += (v[r].x + v[r].y) + (v[r].z + v[r].w);
+    pq += (v[r].x * v[r].x + v[r].y * v[r].y) + (v[r].z * v[r].z + v[r].w * v[r].w);
+    raw[r].x = pack_bf2(v[r].x, v[r].y); raw[r].y = pack_bf2(v[r].z, v[r].w);
+    if (p.C) *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + n) = raw[r];
+  }
+  part[ty][tx] = make_float2(ps, pq);
+  __syncthreads();
+  if ((int)threadIdx.x < QW) {
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float2 t = part[r][threadIdx.x]; a += t.x; q += t.y; }
+    quad[threadIdx.x] = make_float2(a, q);
+  }
+  __syncthreads();
+  const int qpg = p.fn_cg / 4;             // column quads per group
+  const int ngrp = W / p.fn_cg;
+  if ((int)threadIdx.x < ngrp) {
+    float a = 0.f, q = 0.f;
+    for (int t = 0; t < qpg; ++t) { const float2 u = quad[threadIdx.x * qpg + t]; a += u.x; q += u.y; }
+    const float inv_n = 1.f / ((float)p.fn_cg * (float)ROWS);
+    const float sm = a * inv_n, sq = q * inv_n;
+    const float var = fmaxf(sq - sm * sm, 0.f);
+    mr[threadIdx.x] = make_float2(sm, rsqrtf(var + p.fn_eps));
+  }
+  if (p.gn_stats) {      // partials of the raw output for a later (two-source) GroupNorm: bins of gn_cg channels, one slab per sample
+    const int qpb = p.gn_cg / 4, nbin = W / p.gn_cg;
+    const int t2 = (int)threadIdx.x - 32;
+    if (t2 >= 0 && t2 < 2 * nbin) {
+      const int which = t2 & 1, lb = t2 >> 1;
+      float a = 0.f;
+      for (int t = 0; t < qpb; ++t) { const float2 u = quad[lb * qpb + t]; a += which ? u.y : u.x; }
+      p.gn_stats[((size_t)b * p.gn_groups + blockIdx.x * nbin + lb) * 2 + which] = a;
+    }
+  }
+  __syncthreads();
+  const float2 g = mr[(tx * 4) / p.fn_cg];
+  const float s0 = g.y * gam.x, s1 = g.y * gam.y, s2 = g.y * gam.z, s3 = g.y * gam.w;
+  const float h0 = bet.x - g.x * s0, h1 = bet.y - g.x * s1, h2 = bet.z - g.x * s2, h3 = bet.w - g.x * s3;
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const int m = mbase + ty + 16 * r;
+    // (the consumer of the unfused path reads the bf16 tensor: normalise the rounded values)
+    float o0 = fmaf(bf2f((bf16_t)(raw[r].x & 0xffff)), s0, h0), o1 = fmaf(bf2f((bf16_t)(raw[r].x >> 16)), s1, h1);
+    float o2 = fmaf(bf2f((bf16_t)(raw[r].y & 0xffff)), s2, h2), o3 = fmaf(bf2f((bf16_t)(raw[r].y >> 16)), s3, h3);
+    if (p.fn_silu) { o0 = silu_f(o0); o1 = silu_f(o1); o2 = silu_f(o2); o3 = silu_f(o3); }
+    uint2 o; o.x = pack_bf2(o0, o1); o.y = pack_bf2(o2, o3);
+    *reinterpret_cast<uint2*>(p.fn_Y + (size_t)m * p.N + n) = o;
+  }
+}
+// blocks of 40 columns where 80-column blocks would leave half the CUs without one and the groups / bins allow it
+static inline int reduce_gn_width(const GemmArgs& a) {
+  static const int forced = [] { const char* e = getenv("GILL_RED_GN_W"); return e ? atoi(e) : 0; }();     // tools
+  const bool ok40 = 40 % a.fn_cg == 0 && (a.gn_stats == nullptr || 40 % a.gn_cg == 0) && a.N % 40 == 0;
+  if (forced == 80 || !ok40) return 80;
+  if (forced == 40) return 40;
+  return ((int64_t)(a.N / 80) * (a.M / a.rows_per_batch) < 256) ? 40 : 80;
+}
+// geometries the fused reducer takes: whole samples of 64 or 256 rows, 80-column blocks of whole groups, the plain bf16 epilogue
+bool gemm_fused_norm_ok(const GemmArgs& a) {
+  static const bool on = [] { const char* e = getenv("GILL_GEMM_RED_GN"); return !(e && e[0] == '0'); }();     // A/B switch
+  if (!on) return false;
+  const int rows = a.rows_per_batch;
+  const int M = (a.conv && a.ups == 2) ? 0 : a.M;      // (not the 4-tap upsample form: its partials are filed per parity class)
+  return (rows == 64 || rows == 256) && M > 0 && M % rows == 0 && a.N % 80 == 0 && a.fn_cg >= 4 && a.fn_cg % 4 == 0 && 80 % a.fn_cg == 0 &&
+         a.out_mode == OUT_BF16 && a.act == ACT_NONE && !a.resid_f32 && !a.row_stats && !a.ln_stats && a.alpha == 1.f && a.ldc == a.N &&
+         (a.gn_stats == nullptr || (a.gn_cg >= 4 && a.gn_cg % 4 == 0 && 80 % a.gn_cg == 0));
+}
+
 static int env_int(const char* name) {
   const char* v = getenv(name);
   return v ? atoi(v) : 0;
@@ -1126,7 +1248,10 @@ int gemm_row_planes(const GemmArgs& a) {
   if (a.splitk > 1) return cdiv(a.N, reduce_width(a));
   return 2 * cdiv(a.N, tile_width(a));
 }
-int gemm_gn_slab_rows(const GemmArgs& a) { return a.splitk > 1 ? reduce_rows(a) : GN_SLAB_ROWS; }
+int gemm_gn_slab_rows(const GemmArgs& a) {
+  if (a.splitk > 1 && a.fn_Y) return a.rows_per_batch;      // the fused reducer files one partial per (sample, bin)
+  return a.splitk > 1 ? reduce_rows(a) : GN_SLAB_ROWS;
+}
 bool gemm_fused_gn_ok(int N, int cg) {
   if (cg < 1 || N % cg != 0 || N / cg > 64) return false;
   const int bn = (N % 160 == 0) ? 160 : 128;
@@ -1184,6 +1309,17 @@ int gemm_pick_splitk(int M, int N, int K, int act, bool plain, bool generic) {
 
 int gemm_splitk_reduce_launch(const GemmArgs& a, hipStream_t s) {
   GILL_REQUIRE(a.splitk > 1 && a.ws != nullptr, "split-K reducer: no partials");
+  if (a.fn_Y) {
+    GILL_REQUIRE(gemm_fused_norm_ok(a) && a.fn_gamma && a.fn_beta, "split-K reducer: unsupported fused GroupNorm geometry");
+    const int w = reduce_gn_width(a);
+    const dim3 rg(a.N / w, a.M / a.rows_per_batch);
+    if (a.rows_per_batch == 256 && w == 80) hipLaunchKernelGGL((gemm_splitk_reduce_gn_kernel<16, 80>), rg, dim3(320), 0, s, a);
+    else if (a.rows_per_batch == 256) hipLaunchKernelGGL((gemm_splitk_reduce_gn_kernel<16, 40>), rg, dim3(160), 0, s, a);
+    else if (w == 80) hipLaunchKernelGGL((gemm_splitk_reduce_gn_kernel<4, 80>), rg, dim3(320), 0, s, a);
+    else hipLaunchKernelGGL((gemm_splitk_reduce_gn_kernel<4, 40>), rg, dim3(160), 0, s, a);
+    GILL_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   const int rw = reduce_width(a), rr = reduce_rows(a);
   const dim3 rg(cdiv(a.N, rw), cdiv(a.M, rr));
   if (rw == 160 && rr == 64) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<160, 4>), rg, dim3(640), 0, s, a);
@@ -1376,6 +1512,8 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
     GILL_REQUIRE(a.act == ACT_GEGLU || a.out_mode == OUT_QKV, "folded LayerNorm is implemented in the GEGLU and QKV epilogues");
     GILL_REQUIRE(a.alpha == 1.f, "folded LayerNorm: alpha must be 1");
   }
+  GILL_REQUIRE(a.fn_Y == nullptr || (a.splitk > 1 && gemm_fused_norm_ok(a)), "fused GroupNorm output: split-K GEMMs of a supported geometry only");
+  GILL_REQUIRE(a.C != nullptr || a.fn_Y != nullptr || a.out_mode == OUT_QKV, "no output tensor");
   if (a.splitk > 1) {
     GILL_REQUIRE(a.ws != nullptr, "split-K workspace missing");
     GILL_REQUIRE(a.act != ACT_GEGLU, "split-K cannot be combined with GEGLU");

@@ -60,7 +60,12 @@ struct GemmArgs {
   //            ln_rows (0 = M): rows per plane; rows m >= ln_rows read the sums of row m - ln_rows (a batch whose second half
   //            repeats the first: the shared classifier-free-guidance prefix).
   const float* ln_stats = nullptr; int ln_planes = 1; int ln_rows = 0; const float* ln_colsum = nullptr; float ln_eps = 1e-5f;
+  // split-K only: the GroupNorm (+ SiLU) that consumes this output, run by the reducer itself (gemm.hip "REDUCE + GROUPNORM"):
+  // fn_Y [M][N] bf16 = [silu]((C - mean) * rstd * fn_gamma + fn_beta) with mean / rstd over (rows_per_batch rows, fn_cg channels).
+  // C may then be null (the raw tensor has no other reader).  gemm_fused_norm_ok() says which geometries the reducer takes.
+  bf16_t* fn_Y = nullptr; const float* fn_gamma = nullptr; const float* fn_beta = nullptr; float fn_eps = 1e-5f; int fn_silu = 0; int fn_cg = 0;
 };
+bool gemm_fused_norm_ok(const GemmArgs& a);
 int gemm_launch(const GemmArgs& a, hipStream_t s);
 #define GN_SLAB_ROWS 64        // rows per fused GroupNorm-statistics partial of the in-kernel epilogue
 #define GN_SLAB_ROWS_MIN 16    // ... of the smallest producer (size statistics buffers for rows / GN_SLAB_ROWS_MIN partials)

@@ -590,9 +590,24 @@ struct UNetRun {
     g.ws = m->splitk_ws;
     return 0;
   }
-  int gemm(GemmArgs& g, RowStats* rs = nullptr, Tensor* ys = nullptr) {
+  // The GroupNorm (+ SiLU) that consumes a GEMM's output, offered to the producer: a split-K launch of a supported geometry runs it in
+  // its reducer (gemm.hip "REDUCE + GROUPNORM") and sets `done`; otherwise the consumer runs its GroupNorm-apply as before.
+  // raw_needed = false: nobody else reads the raw output (conv1 -> norm2 inside a ResnetBlock2D): it is not even written.
+  struct FusedNorm { const NormW* n; float eps; int silu; Tensor y; bool raw_needed; bool done; };
+  int gemm(GemmArgs& g, RowStats* rs = nullptr, Tensor* ys = nullptr, FusedNorm* fn = nullptr) {
     if (dry) return 0;
     pick_sk(g);
+    if (fn && g.splitk > 1) {
+      g.rows_per_batch = fn->y.H * fn->y.W;
+      g.fn_Y = fn->y.p; g.fn_gamma = fn->n->g; g.fn_beta = fn->n->b; g.fn_eps = fn->eps; g.fn_silu = fn->silu;
+      g.fn_cg = g.N / m->cfg.norm_num_groups;
+      if (gemm_fused_norm_ok(g)) {
+        fn->done = true;
+        if (!fn->raw_needed) { g.C = nullptr; g.gn_stats = nullptr; if (ys) ys->stats = nullptr; }
+      } else {
+        g.fn_Y = nullptr;
+      }
+    }
     if (rs) { g.row_stats = rs->p; rs->planes = gemm_row_planes(g); }
     if (ys && ys->stats) ys->nslab = ys->H * ys->W / gemm_gn_slab_rows(g);
     {   // tools: GILL_UNET_TOUCH_W=1 pulls every GEMM's weights into the Infinity Cache right before it (on the same stream) — the
@@ -653,7 +668,7 @@ struct UNetRun {
   }
   // 3x3 conv (pad 1) over x1 (++ x2): stride 1|2, optional fused nearest-2x upsample
   int conv(const Tensor& x1, const Tensor* x2, const ConvW& w, int stride, int ups, const float* rowvec, int rv_bstride,
-           const bf16_t* resid, Tensor& y) {
+           const bf16_t* resid, Tensor& y, FusedNorm* fn = nullptr) {
     GemmArgs g;
     g.conv = 1; g.IH = x1.H; g.IW = x1.W; g.OH = y.H; g.OW = y.W; g.Cin = w.cin; g.stride = stride; g.ups = ups;
     g.M = Bx * y.H * y.W; g.N = w.cout; g.K = 9 * w.cin;
@@ -664,20 +679,23 @@ struct UNetRun {
     g.resid = resid; g.ldr = w.cout;
     g.C = y.p; g.ldc = w.cout;
     fuse_stats(g, y);
-    return gemm(g, nullptr, &y);
+    return gemm(g, nullptr, &y, fn);
   }
   int linear(const bf16_t* A, int lda, const bf16_t* A2, int lda2, int K1, int M, const bf16_t* W, const float* b, int N,
              int K, const bf16_t* resid, int act, bf16_t* out, int ldc, Tensor* ystats = nullptr,
-             RowStats* row_stats = nullptr) {
+             RowStats* row_stats = nullptr, FusedNorm* fn = nullptr) {
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.K1 = K1; g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.W = W; g.bias = b;
     g.resid = resid; g.ldr = N; g.act = act; g.C = out; g.ldc = ldc;
     if (ystats) fuse_stats(g, *ystats);
-    return gemm(g, row_stats, ystats);
+    return gemm(g, row_stats, ystats, fn);
   }
 
   // out_stats: the output feeds a single-source GroupNorm next (accumulate its sums in conv2's epilogue)
-  int resnet(const Tensor& x1, const Tensor* x2, const ResnetW& w, Tensor* out, bool out_stats) {
+  // pre: x1 already normalised by its producer's reducer (norm1 + SiLU of THIS block: single-source input only);
+  // next: the GroupNorm that consumes this block's output, offered to conv2's reducer
+  int resnet(const Tensor& x1, const Tensor* x2, const ResnetW& w, Tensor* out, bool out_stats, const Tensor* pre = nullptr,
+             FusedNorm* next = nullptr) {
     const int H = x1.H, Wd = x1.W;
     *out = talloc(H, Wd, w.cout, out_stats);
     const size_t mk = m->arena.mark();
@@ -701,11 +719,13 @@ struct UNetRun {
       return 0;
     }
     Tensor n1 = talloc(H, Wd, w.cin);
-    GILL_TRY(gnorm(x1, x2, w.n1, 1e-5f, 1, n1));
+    if (pre && !x2) n1 = *pre;
+    else GILL_TRY(gnorm(x1, x2, w.n1, 1e-5f, 1, n1));
     Tensor h = talloc(H, Wd, w.cout, true);   // -> norm2
-    GILL_TRY(conv(n1, nullptr, w.c1, 1, 0, temb_rows ? temb_rows + w.temb_off : nullptr, temb_bstride, nullptr, h));
     Tensor n2 = talloc(H, Wd, w.cout);
-    GILL_TRY(gnorm(h, nullptr, w.n2, 1e-5f, 1, n2));
+    FusedNorm f2{&w.n2, 1e-5f, 1, n2, false, false};      // norm2 + SiLU in conv1's split-K reducer where there is one
+    GILL_TRY(conv(n1, nullptr, w.c1, 1, 0, temb_rows ? temb_rows + w.temb_off : nullptr, temb_bstride, nullptr, h, &f2));
+    if (!f2.done) GILL_TRY(gnorm(h, nullptr, w.n2, 1e-5f, 1, n2));
     if (w.has_sc) {
       // out = conv2(n2) + conv_shortcut(x1 ++ x2): ONE implicit GEMM whose K runs over the 9 taps of n2 and then over
       // the raw input channels (no separate 1x1 GEMM, no shortcut tensor written and re-read as a residual)
@@ -718,9 +738,9 @@ struct UNetRun {
       g.rows_per_batch = H * Wd;
       g.C = out->p; g.ldc = w.cout;
       fuse_stats(g, *out);
-      GILL_TRY(gemm(g, nullptr, out));
+      GILL_TRY(gemm(g, nullptr, out, next));
     } else {
-      GILL_TRY(conv(n2, nullptr, w.c2, 1, 0, nullptr, 0, x1.p, *out));
+      GILL_TRY(conv(n2, nullptr, w.c2, 1, 0, nullptr, 0, x1.p, *out, next));
     }
     m->arena.release(mk);
     return 0;
@@ -739,7 +759,9 @@ struct UNetRun {
 
   // shared: `x` (and Bx on entry) cover only the first half of a CFG pair; the block runs at that half batch up to the end of
   // the self-attention, then the residual stream is duplicated and the rest runs on the full pair (Bx restored on return)
-  int xf(const Tensor& x, const XfW& w, Tensor* out, bool out_stats, bool shared = false) {
+  // pre: x already normalised (this block's GroupNorm, no SiLU) by its producer's reducer; next: see resnet()
+  int xf(const Tensor& x, const XfW& w, Tensor* out, bool out_stats, bool shared = false, const Tensor* pre = nullptr,
+         FusedNorm* next = nullptr) {
     const int Bpre = Bx, Bfull = shared ? 2 * Bx : Bx;
     Bx = Bfull;                    // every buffer is sized for the full batch
     const int H = x.H, Wd = x.W, C = w.C, HW = H * Wd, M = Bfull * HW, M1 = Bpre * HW;
@@ -754,7 +776,8 @@ struct UNetRun {
     Tensor xd = x;                 // the outer residual at full batch
     if (shared) xd = talloc(H, Wd, C);
     Bx = Bpre;
-    GILL_TRY(gnorm(x, nullptr, w.gn, 1e-6f, 0, n));
+    if (pre && !shared) n = *pre;
+    else GILL_TRY(gnorm(x, nullptr, w.gn, 1e-6f, 0, n));
     Bx = Bfull;
     Tensor t = talloc(H, Wd, C);   // transformer residual stream
     // norm1/2/3 never materialise: the GEMM that writes the residual stream also accumulates each row's sum and sum of
@@ -840,7 +863,7 @@ struct UNetRun {
     }
     // --- feed-forward output, its residual, proj_out and the outer residual: one GEMM over K = [h | t] (see ffo_fuse_kernel; the
     // reference graph's two GEMMs measured 604.3 -> 588.9 ms against it, profiles/HISTORY.md)
-    GILL_TRY(linear(ffh, 4 * C, tres, C, 4 * C, M, w.wfo, w.bfo, C, 5 * C, xd.p, ACT_NONE, out->p, C, out));
+    GILL_TRY(linear(ffh, 4 * C, tres, C, 4 * C, M, w.wfo, w.bfo, C, 5 * C, xd.p, ACT_NONE, out->p, C, out, nullptr, next));
     m->arena.release(mk);
     return 0;
   }
@@ -865,6 +888,15 @@ struct UNetRun {
       m->arena.release(mk);
     }
     skips.push_back(x);
+    // Where a block's last GEMM is a split-K launch (levels 2-3 at the 8-sample batch) and the next consumer's first op is a
+    // single-source GroupNorm, that norm is offered to the producer's reducer (FusedNorm): `pn` carries the normalised copy forward.
+    // The copy is allocated whether or not the offer is taken (same arena layout in the dry run and in every real run).
+    FusedNorm pn{nullptr, 0.f, 0, Tensor(), true, false};
+    auto offer = [&](const NormW& n, float eps, int silu, int H, int W, int C) -> FusedNorm* {
+      pn = FusedNorm{&n, eps, silu, talloc(H, W, C), true, false};
+      return &pn;
+    };
+    auto taken = [&]() -> const Tensor* { return pn.done ? &pn.y : nullptr; };
     for (int i = 0; i < 4; ++i) {
       for (int j = 0; j < 2; ++j) {
         Tensor y;
@@ -872,31 +904,67 @@ struct UNetRun {
         // both halves of the batch -> run them on the first half only (xf() widens back to the full batch)
         const bool share = cfg_pair && i == 0 && j == 0 && Bx % 2 == 0 && temb_bstride == 0;
         if (share) Bx /= 2;
-        GILL_TRY(resnet(x, nullptr, m->down_res[i][j], &y, true));
+        const Tensor* pre = taken();
+        Tensor pre_t; if (pre) { pre_t = *pre; pre = &pre_t; }
+        pn.done = false;
+        // this resnet's consumer: the transformer block's GroupNorm (i < 3), else the next resnet's / the mid block's norm1
+        FusedNorm* nx = nullptr;
+        if (!share && i >= 2) {
+          if (i < 3) nx = offer(m->down_xf[i][j].gn, 1e-6f, 0, x.H, x.W, ch[i]);
+          else nx = offer(j == 0 ? m->down_res[3][1].n1 : m->mid_res[0].n1, 1e-5f, 1, x.H, x.W, ch[i]);
+        }
+        GILL_TRY(resnet(x, nullptr, m->down_res[i][j], &y, true, pre, nx));
         x = y;
         // next consumer: resnet norm1 (j == 0) / the downsample conv or the mid block's norm1 (j == 1)
-        if (i < 3) { Tensor z; GILL_TRY(xf(x, m->down_xf[i][j], &z, true, share)); x = z; }   // next GroupNorm and / or a skip
+        if (i < 3) {
+          const Tensor* pre2 = taken();
+          Tensor pre2_t; if (pre2) { pre2_t = *pre2; pre2 = &pre2_t; }
+          pn.done = false;
+          FusedNorm* nx2 = (i >= 2 && j == 0) ? offer(m->down_res[i][1].n1, 1e-5f, 1, x.H, x.W, ch[i]) : nullptr;
+          Tensor z; GILL_TRY(xf(x, m->down_xf[i][j], &z, true, share, pre2, nx2)); x = z;   // next GroupNorm and / or a skip
+        }
         skips.push_back(x);
       }
       if (i < 3) {
         Tensor y = talloc(x.H / 2, x.W / 2, ch[i], true);
-        GILL_TRY(conv(x, nullptr, m->down_ds[i], 2, 0, nullptr, 0, nullptr, y));
+        pn.done = false;
+        FusedNorm* nx = (i >= 1) ? offer(m->down_res[i + 1][0].n1, 1e-5f, 1, y.H, y.W, ch[i]) : nullptr;
+        GILL_TRY(conv(x, nullptr, m->down_ds[i], 2, 0, nullptr, 0, nullptr, y, nx));
         x = y;
         skips.push_back(x);
       }
     }
     {
-      Tensor y; GILL_TRY(resnet(x, nullptr, m->mid_res[0], &y, true)); x = y;
-      Tensor z; GILL_TRY(xf(x, m->mid_xf, &z, true)); x = z;
-      Tensor u; GILL_TRY(resnet(x, nullptr, m->mid_res[1], &u, true)); x = u;   // -> two-source norm1 of up block 0
+      const Tensor* pre = taken();
+      Tensor pre_t; if (pre) { pre_t = *pre; pre = &pre_t; }
+      pn.done = false;
+      FusedNorm* nx = offer(m->mid_xf.gn, 1e-6f, 0, x.H, x.W, ch[3]);
+      Tensor y; GILL_TRY(resnet(x, nullptr, m->mid_res[0], &y, true, pre, nx)); x = y;
+      const Tensor* pre2 = taken();
+      Tensor pre2_t; if (pre2) { pre2_t = *pre2; pre2 = &pre2_t; }
+      pn.done = false;
+      FusedNorm* nx2 = offer(m->mid_res[1].n1, 1e-5f, 1, x.H, x.W, ch[3]);
+      Tensor z; GILL_TRY(xf(x, m->mid_xf, &z, true, false, pre2, nx2)); x = z;
+      const Tensor* pre3 = taken();
+      Tensor pre3_t; if (pre3) { pre3_t = *pre3; pre3 = &pre3_t; }
+      pn.done = false;
+      Tensor u; GILL_TRY(resnet(x, nullptr, m->mid_res[1], &u, true, pre3, nullptr)); x = u;   // -> two-source norm1 of up block 0
     }
     for (int i = 0; i < 4; ++i) {
       for (int j = 0; j < 3; ++j) {
         Tensor skip = skips.back(); skips.pop_back();
         Tensor y;
-        GILL_TRY(resnet(x, &skip, m->up_res[i][j], &y, true));
+        pn.done = false;
+        // (norm1 of an up-block resnet is two-source: never offered; its conv2 feeds the transformer block's GroupNorm)
+        FusedNorm* nx = (i == 1) ? offer(m->up_xf[i][j].gn, 1e-6f, 0, x.H, x.W, ch[3 - i]) : nullptr;
+        GILL_TRY(resnet(x, &skip, m->up_res[i][j], &y, true, nullptr, nx));
         x = y;
-        if (i > 0) { Tensor z; GILL_TRY(xf(x, m->up_xf[i][j], &z, true)); x = z; }
+        if (i > 0) {
+          const Tensor* pre = taken();
+          Tensor pre_t; if (pre) { pre_t = *pre; pre = &pre_t; }
+          pn.done = false;
+          Tensor z; GILL_TRY(xf(x, m->up_xf[i][j], &z, true, false, pre, nullptr)); x = z;
+        }
       }
       if (i < 3) {
         // (4-tap form: the epilogue's GroupNorm slabs are 64 SOURCE rows of one parity class — tiny grids leave the sums to the consumer)

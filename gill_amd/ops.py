@@ -76,6 +76,25 @@ def conv3x3(x1: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor]
   return y
 
 
+def conv3x3_gn(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+               groups: int = 32, eps: float = 1e-5, silu: bool = True, resid: Optional[torch.Tensor] = None, splitk: int = 2,
+               want_raw: bool = True):
+  """Split-K 3x3 convolution whose reducer also runs the consuming GroupNorm (+ SiLU).  x (B,H,W,Cin) bf16 NHWC with H * W in
+  {64, 256}; returns (y_raw or None, y_norm), both (B,H,W,Cout) bf16 — NaN-prefilled, so an unwritten element shows."""
+  x = _bf(x)
+  B, H, W, Cin = x.shape
+  Cout = w_oihw.shape[0]
+  nan = float("nan")
+  y_raw = torch.full((B, H, W, Cout), nan, device=x.device, dtype=torch.bfloat16) if want_raw else None
+  y_norm = torch.full((B, H, W, Cout), nan, device=x.device, dtype=torch.bfloat16)
+  f = lambda t: None if t is None else t.float().contiguous()   # noqa: E731
+  w, bias, gamma, beta = f(w_oihw), f(bias), f(gamma), f(beta)
+  resid = None if resid is None else _bf(resid)
+  N.check(N.lib().gill_op_conv3x3_gn(N.ptr(x), N.ptr(w), N.ptr(bias), N.ptr(resid), N.ptr(gamma), N.ptr(beta), groups, float(eps),
+                                     int(silu), N.ptr(y_raw), N.ptr(y_norm), B, H, W, Cin, Cout, splitk, N.current_stream()))
+  return y_raw, y_norm
+
+
 def conv3x3_shortcut(x1: torch.Tensor, w_oihw: torch.Tensor, xs1: torch.Tensor, w_sc: torch.Tensor, bias: Optional[torch.Tensor] = None,
                      x2: Optional[torch.Tensor] = None, xs2: Optional[torch.Tensor] = None, splitk: int = 0) -> torch.Tensor:
   """conv3x3(x1 ++ x2, w_oihw) + bias + conv1x1(xs1 ++ xs2, w_sc) as one implicit GEMM (ResnetBlock2D conv2 + conv_shortcut)."""

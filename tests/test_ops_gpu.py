@@ -328,6 +328,36 @@ def test_attention_dma_matches_register_staged(cuda):
   assert _report("attn dma vs register-staged", out, old) < 1e-2
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,splitk,silu,resid,raw", [
+  (2, 16, 16, 1280, 1280, 2, True, False, False),    # UNet level 2: conv1 -> norm2 (raw tensor not written)
+  (3, 8, 8, 1280, 1280, 8, True, False, False),      # level 3
+  (2, 16, 16, 1280, 1280, 2, False, True, True),     # conv2 + residual -> the transformer block's GroupNorm (no SiLU, eps 1e-6)
+  (2, 8, 8, 640, 640, 4, True, True, True),          # groups of 20 channels (Cout 640): 4 groups per 80-column block
+])
+def test_conv3x3_split_k_reducer_with_fused_groupnorm(cuda, B, H, W, Cin, Cout, splitk, silu, resid, raw):
+  """gemm.hip "REDUCE + GROUPNORM": the split-K reducer of a 3x3 convolution also runs the GroupNorm (+ SiLU) that consumes the
+  output (diffusers ResnetBlock2D conv1 -> norm2 -> silu; conv2 -> next block's norm), against F.conv2d + F.group_norm in fp32."""
+  from gill_amd import ops
+  x = _bf(_rnd((B, H, W, Cin), 90))
+  w = _rnd((Cout, Cin, 3, 3), 91, (9 * Cin) ** -0.5)
+  b = 0.1 * _rnd((Cout,), 92)
+  r = _bf(_rnd((B, H, W, Cout), 93)) if resid else None
+  gamma, beta = 1.0 + 0.2 * _rnd((Cout,), 94), 0.1 * _rnd((Cout,), 95)
+  eps = 1e-5 if silu else 1e-6
+  ref_raw = F.conv2d(x.float().permute(0, 3, 1, 2), _bf(w).float(), b, padding=1)
+  if resid:
+    ref_raw = ref_raw + r.float().permute(0, 3, 1, 2)
+  ref = F.group_norm(_bf(ref_raw).float(), 32, gamma, beta, eps)
+  if silu:
+    ref = F.silu(ref)
+  y_raw, y_norm = ops.conv3x3_gn(x.to(cuda), w.to(cuda), b.to(cuda), gamma.to(cuda), beta.to(cuda), 32, eps, silu,
+                                 None if r is None else r.to(cuda), splitk, raw)
+  assert torch.isfinite(y_norm.float()).all()
+  assert _report(f"conv+GN B{B} {H}x{W} {Cin}->{Cout} sk{splitk}", y_norm.permute(0, 3, 1, 2), ref) < 1.5e-2
+  if raw:
+    assert _report("  raw", y_raw.permute(0, 3, 1, 2), ref_raw) < 1.5e-2
+
+
 # ---------------------------------------------------------------- norms
 @pytest.mark.parametrize("rows,C,f32", [(37, 512, True), (64, 4096, True), (300, 320, False), (16, 1280, False),
                                         (5, 768, True)])
