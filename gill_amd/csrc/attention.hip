@@ -519,7 +519,11 @@ __global__ __launch_bounds__(ATT_THREADS, 4) void attention_dma_kernel(const Att
         oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pa[h4], oacc[t], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // own pieces of the next tile have landed
+    // own pieces of the next tile have landed, AND every LDS read of this tile has returned: hipcc sinks the last PV fragment read's
+    // lgkmcnt wait (and its MFMA) below the barrier, i.e. the read could still sit in the LDS queue when another wave, released by
+    // the barrier, refills this stage — with eight processes sharing the GPU (test_bench_eight_ranks_uneven_shards_gloo) that
+    // window was hit: steps differed by 1.4e-3.  The explicit lgkmcnt(0) closes it (tools/sessions/r04_b8.sh is the bisect).
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");                       // (the next tile's LDS reads stay behind the barrier)
   };
