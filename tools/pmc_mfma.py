@@ -13,7 +13,7 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     v = float(row["Counter_Value"])
     if row["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES": busy[k] += v; n[k] += 1
     elif row["Counter_Name"] == "GRBM_GUI_ACTIVE": act[k] += v
-HOT = ("gemm_kernel", "attention_kernel", "ffn_fused", "lnproj", "xattn_block", "dup_pair", "gemm_splitk", "groupnorm", "conv_out", "conv3x3_fp8", "plms", "sd_stage", "im2col", "copy_bytes")
+HOT = ("gemm_kernel", "attention_kernel", "attention_dma_kernel", "ffn_fused", "lnproj", "dup_pair", "gemm_splitk", "groupnorm", "conv_out", "conv3x3_fp8", "plms", "sd_stage", "im2col", "copy_bytes")
 lines = ["| kernel | dispatches | GPU-active cycles (sum / 8 XCDs) | MFMA-busy cycles / (1024 SIMDs) | MFMA pipe busy |", "|---|---|---|---|---|"]
 tb = ta = 0.0
 for k in sorted(act, key=lambda k: -act[k]):
