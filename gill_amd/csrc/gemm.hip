@@ -129,6 +129,7 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0
 //       3 nearest-2x upsample + conv3x3 as FOUR 2x2-tap convolutions of the source grid, one per output parity (see "UPS4")
 // EPI : 0 row-major (bf16 / fp32) epilogue, 1 GEGLU, 2 raw fp32 split-K partials, 3 QKV head-major scatter,
 //       4 = 0 without activation / fp32 output / fp32 residual (the UNet's plain GEMMs: half the epilogue's code and branches)
+//       5 folded-LayerNorm scores + softmax over each wave's 80 columns (OUT_SOFTMAX80; BN = 160)
 // STAGES: depth of the LDS ring.  2: two workgroups per CU hide each other's DMA waits.  3: one workgroup per CU,
 //         the DMA of K steps i+1 AND i+2 is in flight while step i is multiplied (counted s_waitcnt vmcnt(N), raw
 //         s_barrier) — for grids of ~one workgroup per CU where co-residency cannot do the hiding.
@@ -307,13 +308,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
     }
     return half * (BN / 2) + c;
   };
+  const bf16_t* Wb = p.W + (p.wb_rows ? (size_t)(m0 / p.wb_rows) * (size_t)p.wb_stride : (size_t)0);     // per-sample weights (GemmArgs::wb_rows)
   auto w_setup = [&]() {
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
       int row = tile_col((i * NWV + w) * RPI + srow);
       int n = n_issue + row;
       if (n > p.N - 1) n = p.N - 1;
-      w_ptr[i] = p.W + ((size_t)cls * p.N + n) * p.K + schunk * 8 + kt_beg * KT;
+      w_ptr[i] = Wb + ((size_t)cls * p.N + n) * p.K + schunk * 8 + kt_beg * KT;
     }
   };
   w_setup();
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
     if (s < total_steps) issue(s);
   // folded LayerNorm (GEGLU / QKV epilogues): the row factors are loaded here, under the first tile's DMA latency
   float ln_rr[4] = {1.f, 1.f, 1.f, 1.f}, ln_rm[4] = {0.f, 0.f, 0.f, 0.f};   // (first MI entries used)
-  if constexpr (EPI == 1 || EPI == 3) {
+  if constexpr (EPI == 1 || EPI == 3 || EPI == 5) {
     if (p.ln_stats) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
@@ -683,6 +685,65 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
         }
         uint4 ov; ov.x = pack_bf2(o[0], o[1]); ov.y = pack_bf2(o[2], o[3]); ov.z = pack_bf2(o[4], o[5]); ov.w = pack_bf2(o[6], o[7]);
         if (m < p.M) *reinterpret_cast<uint4*>((bf16_t*)p.C + (size_t)m * p.ldc + no) = ov;
+      }
+    }
+  } else if constexpr (EPI == 5) {
+    // scores of one (sample, head) per wave half: the wave's 80 columns ARE the head's keys (77 + 3 pads whose bias is -1e30), so the
+    // softmax of a row is a reduction over the lane's 20 values and the 4 lanes (fkc) that share the row.  exp2 domain (scale * log2(e)
+    // is folded into the per-sample weights).  P is stored row-major: the A operand of the second GEMM.
+    static_assert(EPI != 5 || BN == 160, "softmax epilogue: one 80-column head per wave half");
+    const size_t vb = p.wb_rows ? (size_t)(m0 / p.wb_rows) * (size_t)p.vb_stride : (size_t)0;
+    const float* bias = p.bias + vb;
+    const float* csum = p.ln_colsum + vb;
+    float4 bzs[NG][2], css[NG][2];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const bool pair = (2 * g + 1 < NT);
+      const int n = nbase + (pair ? g * 32 + fkc * 8 : (2 * g) * 16 + fkc * 4);
+      bzs[g][0] = *reinterpret_cast<const float4*>(bias + n);
+      css[g][0] = *reinterpret_cast<const float4*>(csum + n);
+      bzs[g][1] = pair ? *reinterpret_cast<const float4*>(bias + n + 4) : make_float4(0, 0, 0, 0);
+      css[g][1] = pair ? *reinterpret_cast<const float4*>(csum + n + 4) : make_float4(0, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): see the row-major epilogue
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = mrow + i * 16;
+      const float rr = ln_rr[i], rm = ln_rm[i];
+      float v[NG][8];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const bool pair = (2 * g + 1 < NT);
+        const f32x4 a0 = acc[i][2 * g], a1 = acc[i][pair ? 2 * g + 1 : 2 * g];
+        v[g][0] = a0[0] * rr - rm * css[g][0].x + bzs[g][0].x; v[g][1] = a0[1] * rr - rm * css[g][0].y + bzs[g][0].y;
+        v[g][2] = a0[2] * rr - rm * css[g][0].z + bzs[g][0].z; v[g][3] = a0[3] * rr - rm * css[g][0].w + bzs[g][0].w;
+        v[g][4] = pair ? a1[0] * rr - rm * css[g][1].x + bzs[g][1].x : -INFINITY; v[g][5] = pair ? a1[1] * rr - rm * css[g][1].y + bzs[g][1].y : -INFINITY;
+        v[g][6] = pair ? a1[2] * rr - rm * css[g][1].z + bzs[g][1].z : -INFINITY; v[g][7] = pair ? a1[3] * rr - rm * css[g][1].w + bzs[g][1].w : -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, v[g][e]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[g][e] = __builtin_amdgcn_exp2f(v[g][e] - mx); sum += v[g][e]; }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / sum;
+      if (m < p.M) {
+        bf16_t* crow = (bf16_t*)p.C + (size_t)m * p.ldc;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const bool pair = (2 * g + 1 < NT);
+          const int n = nbase + (pair ? g * 32 + fkc * 8 : (2 * g) * 16 + fkc * 4);
+          uint4 o; o.x = pack_bf2(v[g][0] * inv, v[g][1] * inv); o.y = pack_bf2(v[g][2] * inv, v[g][3] * inv);
+          o.z = pack_bf2(v[g][4] * inv, v[g][5] * inv); o.w = pack_bf2(v[g][6] * inv, v[g][7] * inv);
+          if (pair) *reinterpret_cast<uint4*>(crow + n) = o;
+          else *reinterpret_cast<uint2*>(crow + n) = make_uint2(o.x, o.y);
+        }
       }
     }
   } else if constexpr (EPI == 3) {
@@ -1241,7 +1302,7 @@ static inline int tile_width(const GemmArgs& a) {
   if (!a.conv && a.out_mode == OUT_QKV && a.N % 128 == 0) bn = 128;
   // ... except on the 64-row tile (plain GEMMs with few tiles, see gemm_launch_bn): 64 x 128 needs 48 KiB of LDS, i.e. three
   // workgroups (six waves) per CU instead of two (four) — loop 587.3 -> 584.7 ms
-  if (!a.conv && a.splitk <= 1 && a.N % 128 == 0 && !a.gn_stats && (int64_t)cdiv(a.M, 128) * cdiv(a.N, 160) < 300 && a.M > 64) bn = 128;
+  if (!a.conv && a.splitk <= 1 && a.N % 128 == 0 && !a.gn_stats && (int64_t)cdiv(a.M, 128) * cdiv(a.N, 160) < 300 && a.M > 64 && a.out_mode != OUT_SOFTMAX80) bn = 128;
   return bn;
 }
 int gemm_row_planes(const GemmArgs& a) {
@@ -1358,6 +1419,11 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
       return gemm_launch_inst<4, BN, CONV, EPI, 2, BK, 2>(d, grid, s);
     }
   }
+  if constexpr (CONV == 0 && EPI == 5) {
+    // 64 x 160 tile on four waves of 32 x 80, 2-deep ring.  Measured on the three UNet shapes of the 8-sample batch (tools/xalg_bench.py, 20
+    // launches each): two waves of 64 x 80 1177 us, this 1003-1013 us, 3-deep ring 1212 us (3-deep only on the <= 256-workgroup grids: 1051 us)
+    if (d.nwv == 4 && d.mi == 2) return gemm_launch_inst<4, BN, CONV, EPI, 2, BK, 2>(d, grid, s);
+  }
   if constexpr (CONV == 0 && (EPI == 0 || EPI == 3 || EPI == 4) && BN == 128) {
     if (d.nwv == 4 && d.mi == 2) {
       // 64-row tile on four waves, 3-deep ring (72 KB: two workgroups per CU).  These grids are 1-2 workgroups per CU, so the ring depth IS
@@ -1397,6 +1463,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   // — 256 vs 320 — therefore lands on the 4-wave 128 x 128 tile, not the 64-row one; measured better that way: 567.8 vs 575.5 ms)
   // (re-measured with the 3-deep ring below: < 300 493.8 ms, < 400 495.6, < 520 496.3, < 700 496.5)
   if (!a.conv && sk == 1 && (int64_t)cdiv(a.M, 128) * d.tiles_n < 300 && a.M > 64) d.nwv = 2;   // measured: < 300 +0.3 %, < 520 -3 % end to end
+  if (a.wb_rows % 128 != 0 && !a.conv && sk == 1) d.nwv = 2;      // per-sample weights on samples of 64 rows (GemmArgs::wb_rows): 64-row tiles
   d.mi = 4;
   // the 64-row tile on FOUR waves (2 x 2, wave tile 32 x 64) where its width is 128: same LDS, twice the waves per CU —
   // loop 580.4 -> 576.3 ms, 2048 x 1280 x 1280 19.8 -> 17.3 us
@@ -1404,6 +1471,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   // ... and where it is 160 (the feed-forward output GEMMs of levels 1-3 with their fused GroupNorm partials: bins of 20 / 40 channels
   // need the 160-wide tile): loop 492.4 -> 489.4 ms against the two-wave tile.
   if (d.nwv == 2 && BN == 160 && a.act == ACT_NONE && a.out_mode == OUT_BF16) { d.nwv = 4; d.mi = 2; }
+  if (a.out_mode == OUT_SOFTMAX80) { d.nwv = 4; d.mi = 2; }      // (see gemm_launch_stages)
   if (forced_bm == 128) { d.nwv = 4; d.mi = 4; }
   if (forced_bm == 64 && !a.conv && sk == 1) { d.nwv = 2; d.mi = 4; }
   // 3x3 convolutions: 256 x 160 tile with the ping-pong main loop, one workgroup per CU (GILL_GEMM_PP = 0 keeps the two
@@ -1438,6 +1506,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     const int64_t ael = (int64_t)a.M * (a.conv ? a.Cin + a.KX : a.K);
     d.n_major = (wel > ael && d.groups_n >= 8) ? 1 : 0;
   }
+  GILL_REQUIRE(a.wb_rows == 0 || (a.wb_rows % ((d.nwv / 2) * d.mi * 16) == 0 && !a.conv), "per-sample weights: tiles must not straddle samples");
   dim3 grid(tiles_m * d.groups_n, sk, ncls);
   if (BN == 160 && d.nwv == 8) GILL_REQUIRE(d.npw == 1, "internal: the ping-pong kernel walks one N tile per workgroup");
   if (a.conv) {
@@ -1456,6 +1525,10 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     else if (a.act == ACT_GEGLU) {
       if constexpr (BN == 128) GILL_TRY((gemm_launch_stages<BN, 0, 1>(d, grid, s)));
       else GILL_REQUIRE(BN == 128, "internal: GEGLU runs on 128-wide tiles");
+    }
+    else if (a.out_mode == OUT_SOFTMAX80) {
+      if constexpr (BN == 160) GILL_TRY((gemm_launch_stages<BN, 0, 5>(d, grid, s)));
+      else GILL_REQUIRE(BN == 160, "internal: the softmax epilogue runs on 160-wide tiles");
     }
     else if (a.out_mode == OUT_QKV) GILL_TRY((gemm_launch_stages<BN, 0, 3>(d, grid, s)));
     else if (a.act == ACT_NONE && a.out_mode == OUT_BF16 && !a.resid_f32) GILL_TRY((gemm_launch_stages<BN, 0, 4>(d, grid, s)));
@@ -1509,7 +1582,7 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   if (a.ln_stats) {
     GILL_REQUIRE(a.ln_planes >= 1 && a.ln_planes <= LN_MAX_PLANES, "folded LayerNorm: 1 <= ln_planes <= 20");
     GILL_REQUIRE(a.ln_colsum != nullptr && !a.conv && a.K1 == a.K, "folded LayerNorm: column sums missing / single-source plain GEMM only");
-    GILL_REQUIRE(a.act == ACT_GEGLU || a.out_mode == OUT_QKV, "folded LayerNorm is implemented in the GEGLU and QKV epilogues");
+    GILL_REQUIRE(a.act == ACT_GEGLU || a.out_mode == OUT_QKV || a.out_mode == OUT_SOFTMAX80, "folded LayerNorm is implemented in the GEGLU, QKV and softmax epilogues");
     GILL_REQUIRE(a.alpha == 1.f, "folded LayerNorm: alpha must be 1");
   }
   GILL_REQUIRE(a.fn_Y == nullptr || (a.splitk > 1 && gemm_fused_norm_ok(a)), "fused GroupNorm output: split-K GEMMs of a supported geometry only");
@@ -1522,6 +1595,9 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
     GILL_REQUIRE(a.N % 128 == 0 && a.out_mode == OUT_BF16, "GEGLU needs N % 128 == 0 and bf16 row-major output");
     return gemm_launch_bn<128>(a, s);
   }
+  if (a.out_mode == OUT_SOFTMAX80)
+    GILL_REQUIRE(a.N % 160 == 0 && a.splitk <= 1 && a.ln_stats && a.ln_colsum && a.bias && !a.conv && !a.gn_stats && !a.row_stats && a.C,
+                 "softmax epilogue: N % 160 == 0, no split-K, folded-LayerNorm operands and a bias vector required");
   if (a.out_mode == OUT_QKV) GILL_REQUIRE(a.dp % 8 == 0 && a.heads > 0 && a.ntok > 0, "bad QKV scatter geometry (padded head dim must be a multiple of 8)");
   const int bn = tile_width(a);
   if (bn == 160) return gemm_launch_bn<160>(a, s);

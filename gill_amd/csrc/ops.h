@@ -5,7 +5,7 @@
 #include "common.h"
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_GEGLU = 4, ACT_QUICK_GELU = 5 /* x*sigmoid(1.702x): CLIP */ };
-enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_QKV = 2 };
+enum { OUT_BF16 = 0, OUT_F32 = 1, OUT_QKV = 2, OUT_SOFTMAX80 = 3 };
 
 // C[M,N] = epilogue( alpha * A[M,K] . W[N,K]^T )       (bf16 operands, fp32 MFMA accumulate)
 //  A is either a plain row-major matrix (optionally the K-concatenation of two matrices) or the
@@ -60,6 +60,12 @@ struct GemmArgs {
   //            ln_rows (0 = M): rows per plane; rows m >= ln_rows read the sums of row m - ln_rows (a batch whose second half
   //            repeats the first: the shared classifier-free-guidance prefix).
   const float* ln_stats = nullptr; int ln_planes = 1; int ln_rows = 0; const float* ln_colsum = nullptr; float ln_eps = 1e-5f;
+  // Per-sample operands (the cross-attention of UNet levels 1-3 as two GEMMs, unet.hip "XALG"): rows [b * wb_rows, (b + 1) * wb_rows)
+  // multiply W + b * wb_stride (elements); OUT_SOFTMAX80 also reads bias / ln_colsum at + b * vb_stride.  Tiles must not straddle
+  // samples (wb_rows % tile rows == 0).  0 = one weight matrix for all rows.
+  int wb_rows = 0; int64_t wb_stride = 0; int vb_stride = 0;
+  // OUT_SOFTMAX80 (folded-LayerNorm consumer, like OUT_QKV): C[m][80 h .. 80 h + 79] = softmax over the 80 columns of group h of
+  // exp2-domain scores rstd (A W^T - mean colsum) + bias; N % 160 == 0; no split-K.  Columns that must not take part carry bias -1e30.
   // split-K only: the GroupNorm (+ SiLU) that consumes this output, run by the reducer itself (gemm.hip "REDUCE + GROUPNORM"):
   // fn_Y [M][N] bf16 = [silu]((C - mean) * rstd * fn_gamma + fn_beta) with mean / rstd over (rows_per_batch rows, fn_cg channels).
   // C may then be null (the raw tensor has no other reader).  gemm_fused_norm_ok() says which geometries the reducer takes.

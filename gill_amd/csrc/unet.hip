@@ -62,6 +62,7 @@ struct XfW {  // Transformer2DModel with one BasicTransformerBlock
   bf16_t *wqkv1p = nullptr, *wq2p = nullptr;   // wqkv1 / wq2 (LayerNorm-folded) with the K order of the fused projection pairs (lnproj.hip; C = 320 only)
   // norm1/2/3 are folded into wqkv1 / wq2 / wff1 at load (GemmArgs::ln_stats): column sums of g*W and beta.W^T (+ bias)
   float *s_qkv1 = nullptr, *c_qkv1 = nullptr, *s_q2 = nullptr, *c_q2 = nullptr, *s_ff1 = nullptr;
+  bf16_t* xg = nullptr; float* xgb = nullptr;   // XALG (see xalg_fold_kernel): [2 H C][ctx_dim] = G | G2, and gb [H][ctx_dim]; null = attention-kernel form
   LinW ff2;                   // [C][4C]
   bf16_t* wfo = nullptr; float* bfo = nullptr;   // ff2 and proj_out as one map: [C][4C + C] = [Wp W2 | Wp], bias Wp b2 + bp
 };
@@ -125,6 +126,9 @@ struct gill_unet {
   float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
   std::vector<bf16_t*> kcache, vcache;   // per transformer layer: [Bx][H][ctx_pad][dp] / [Bx][H][dpv][ctx_pad]
   int ctx_pad = 0;
+  // XALG layers (XfW::xg): per-sample operands of the two cross-attention GEMMs — scores [Bx][80 H][C] + its folded-LayerNorm
+  // column sums and constants [Bx][80 H], values [Bx][C][80 H]
+  std::vector<bf16_t*> xq_w, xo_w; std::vector<float*> xq_cs, xq_b;
   // time embedding scratch
   float* t_dev = nullptr;       // [rows]
   bf16_t* t_sin = nullptr;      // [rows][320]
@@ -218,6 +222,98 @@ __global__ __launch_bounds__(256) void ffo_fuse_kernel(const void* wp, int dt_p,
   }
 }
 
+// CROSS-ATTENTION AS TWO GEMMs ("XALG": UNet levels 1-3, head dim >= 80).  The keys and values of attn2 are linear maps of the 77 prompt
+// tokens, fixed for the whole denoising loop, so per sample b and head h
+//   scores[m][j] = qs LN(t)[m] . Wq_h^T K_bh[j]            = LN(t)[m] . (ctx_b[j] G_h)^T,     G_h  = qs (g o Wq_h)^T Wk_h      [C][768]
+//   out[m]       = sum_h softmax(scores)[m][h][:] V_bh Wo_h^T = sum_h P[m][h][:] (ctx_b G2_h)^T, G2_h = Wo_h Wv_h             [C][768]
+// G / G2 depend on the weights only (built here at load, fp32 products of the bf16 weights, one rounding); once per prompt the
+// context turns them into per-sample weight matrices (unet_ctx_cache) and every UNet call then runs attn2 as
+//   P = softmax80(LN(t) Mq_b^T)  (GEMM, N = 80 H: GemmArgs::OUT_SOFTMAX80)   and   t += P Wo_b^T + bias  (GEMM, K = 80 H)
+// instead of to_q + the attention kernel + to_out: at d = 160 (levels 2-3) both GEMMs are half the size of the projections they
+// replace, and the attention launch is gone.  GILL_UNET_XALG = 0 keeps the three-kernel form.
+// rows [0, H C): G[h][c][:]; rows [H C, 2 H C): G2[h][co][:].  8 rows per workgroup (one head), threads over the 768 context features.
+__global__ __launch_bounds__(256) void xalg_fold_kernel(const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wkv, const bf16_t* __restrict__ wo,
+                                                        int H, int C, int dp, int E, float qs, bf16_t* __restrict__ G) {
+  __shared__ float a[8][160];
+  const int r0 = blockIdx.x * 8;                  // first of 8 rows (C % 8 == 0: one head, one half)
+  const int half = r0 >= H * C;
+  const int rr = r0 - half * H * C;
+  const int h = rr / C, c0 = rr - h * C;
+  const int hdp = H * dp;
+  for (int i = threadIdx.x; i < 8 * dp; i += 256) {
+    const int r = i / dp, n = i - r * dp;
+    a[r][n] = half ? bf2f(wo[(size_t)(c0 + r) * hdp + h * dp + n]) : qs * bf2f(wq[(size_t)(h * dp + n) * C + c0 + r]);
+  }
+  __syncthreads();
+  const bf16_t* wb = wkv + (size_t)(half * hdp + h * dp) * E;      // Wk_h | Wv_h: [dp][E]
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int n = 0; n < dp; ++n) {
+      const float b = bf2f(wb[(size_t)n * E + e]);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] = fmaf(a[r][n], b, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) G[(size_t)(r0 + r) * E + e] = f2bf(acc[r]);
+  }
+}
+// gb[h][e] = qs sum_n c_q[h dp + n] Wk[h dp + n][e]   (c_q = beta . Wq^T: the constant part of the folded norm2 -> to_q)
+__global__ __launch_bounds__(256) void xalg_fold_bias_kernel(const float* __restrict__ cq, const bf16_t* __restrict__ wk, int dp, int E, float qs,
+                                                             float* __restrict__ gb) {
+  const int h = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  float acc = 0.f;
+  for (int n = 0; n < dp; ++n) acc = fmaf(cq[h * dp + n], bf2f(wk[(size_t)(h * dp + n) * E + e]), acc);
+  gb[(size_t)h * E + e] = qs * acc;
+}
+// Once per prompt: T [Bx ctx_len][2 H C] = ctx [G | G2]^T (one GEMM) is dealt into the per-sample operands of the two GEMMs.
+// Scores operand: Mq[b][80 h + j][:] = T[b ctx_len + j][h C ..], its row sums (folded LayerNorm) and the constant term ctx_b[j] . gb[h];
+// key slots j >= ctx_len: zero rows with constant -1e30 (softmax weight 0).  One workgroup per (b, h, j).
+__global__ __launch_bounds__(256) void xalg_scores_operand_kernel(const bf16_t* __restrict__ T, const bf16_t* __restrict__ ctx, const float* __restrict__ gb,
+                                                                  int H, int C, int E, int ctx_len, bf16_t* __restrict__ Mq, float* __restrict__ cs,
+                                                                  float* __restrict__ cb) {
+  __shared__ float red[2][4];
+  const int j = blockIdx.x % 80, h = (blockIdx.x / 80) % H, b = blockIdx.x / (80 * H);
+  bf16_t* dst = Mq + (size_t)blockIdx.x * C;
+  float sum = 0.f, dot = 0.f;
+  if (j < ctx_len) {
+    const bf16_t* src = T + (size_t)(b * ctx_len + j) * (2 * H * C) + (size_t)h * C;
+    for (int c = threadIdx.x * 8; c < C; c += 2048) {
+      const uint4 v = *reinterpret_cast<const uint4*>(src + c);
+      *reinterpret_cast<uint4*>(dst + c) = v;
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sum += __uint_as_float(w[i] << 16) + __uint_as_float(w[i] & 0xffff0000u);
+    }
+    const bf16_t* cr = ctx + (size_t)(b * ctx_len + j) * E;
+    for (int e = threadIdx.x; e < E; e += 256) dot = fmaf(bf2f(cr[e]), gb[(size_t)h * E + e], dot);
+  } else {
+    for (int c = threadIdx.x * 8; c < C; c += 2048) *reinterpret_cast<uint4*>(dst + c) = make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); dot += __shfl_xor(dot, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sum; red[1][threadIdx.x >> 6] = dot; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cs[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    cb[blockIdx.x] = j < ctx_len ? red[1][0] + red[1][1] + red[1][2] + red[1][3] : -1e30f;
+  }
+}
+// Values operand: Wo_b[co][80 h + j] = T[b ctx_len + j][H C + h C + co] (0 for j >= ctx_len): an 80 x 64 transpose per workgroup (b, h, co / 64).
+__global__ __launch_bounds__(256) void xalg_values_operand_kernel(const bf16_t* __restrict__ T, int H, int C, int ctx_len, bf16_t* __restrict__ Wo) {
+  __shared__ bf16_t tile[80][66];
+  const int cb = blockIdx.x % (C / 64), h = (blockIdx.x / (C / 64)) % H, b = blockIdx.x / ((C / 64) * H);
+  for (int i = threadIdx.x; i < 80 * 64; i += 256) {
+    const int j = i >> 6, c = i & 63;
+    tile[j][c] = j < ctx_len ? T[(size_t)(b * ctx_len + j) * (2 * H * C) + (size_t)H * C + (size_t)h * C + cb * 64 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 80; i += 256) {
+    const int c = i / 80, j = i - c * 80;
+    Wo[((size_t)b * C + cb * 64 + c) * (80 * H) + h * 80 + j] = tile[j][c];
+  }
+}
+
 // The feed-forward sub-blocks at C = 320 (level 0) run as one kernel (ffn.hip) instead of GEGLU + the two-source ffo GEMM: loop
 // 528.9 -> 522.8 ms.  GILL_UNET_FFN_FUSED = 0 restores the two GEMMs.
 // GILL_UNET_LNPROJ=0: proj_in / QKV and attn1.to_out / attn2.to_q of the level-0 blocks as the separate GEMMs
@@ -228,6 +324,11 @@ static bool lnproj_on() {
 // GILL_UNET_FFN_PRE=0: attn2.to_out + residual of the level-0 blocks as its own GEMM in front of the fused feed-forward kernel
 static bool ffn_pre_on() {
   static const bool on = [] { const char* e = getenv("GILL_UNET_FFN_PRE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+// GILL_UNET_XALG=0: attn2 of levels 1-3 as to_q + attention kernel + to_out instead of the two per-sample GEMMs (xalg_fold_kernel)
+static bool xalg_on() {
+  static const bool on = [] { const char* e = getenv("GILL_UNET_XALG"); return !(e && e[0] == '0'); }();
   return on;
 }
 static bool ffn_fused_on() {
@@ -241,6 +342,7 @@ struct Loader {
   const WeightTable& wt;
   DevPool& pool;
   hipStream_t s;
+  int ctx_len = 0;
   int norm(const std::string& p, int c, NormW* n) {
     n->c = c;
     GILL_TRY(load_f32(wt, pool, p + ".weight", c, &n->g, s));
@@ -387,6 +489,16 @@ struct Loader {
     GILL_TRY(ln_fold_rows_launch(x->wqkv1, 3 * hdp, C, x->ln1.g, x->ln1.b, x->s_qkv1, x->c_qkv1, s));
     GILL_TRY(ln_fold_rows_launch(x->wq2, hdp, C, x->ln2.g, x->ln2.b, x->s_q2, x->c_q2, s));
     GILL_TRY(ln_fold_rows_launch(x->wff1, 8 * C, C, x->ln3.g, x->ln3.b, x->s_ff1, x->bff1, s));
+    // cross-attention as two GEMMs: where the 80 key slots per head are no wider than the head itself (d >= 80: SD-1.5 levels 1-3)
+    if (xalg_on() && H % 2 == 0 && ctx_len <= 80 && 80 * H <= hdp && x->dp <= 160 && C % 64 == 0 && ctx_dim % 64 == 0) {
+      GILL_TRY(pool.alloc(&x->xg, (size_t)2 * H * C * ctx_dim, false));
+      GILL_TRY(pool.alloc(&x->xgb, (size_t)H * ctx_dim));
+      const float qs = 1.4426950408889634f / sqrtf((float)x->d);
+      hipLaunchKernelGGL(xalg_fold_kernel, dim3(2 * H * C / 8), dim3(256), 0, s, x->wq2, x->wkv2, x->out2.w, H, C, x->dp, ctx_dim, qs, x->xg);
+      GILL_CHECK_HIP(hipGetLastError());
+      hipLaunchKernelGGL(xalg_fold_bias_kernel, dim3(cdiv(ctx_dim, 256), H), dim3(256), 0, s, x->c_q2, x->wkv2, x->dp, ctx_dim, qs, x->xgb);
+      GILL_CHECK_HIP(hipGetLastError());
+    }
     if (ffn_fused_on() && ffn_fused_supported(C, 128)) {
       GILL_TRY(pool.alloc(&x->w1c, (size_t)8 * C * C, false));
       GILL_TRY(pool.alloc(&x->b1c, (size_t)8 * C, false));
@@ -423,7 +535,7 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
   auto fail = [&](int r) { delete m; return r; };
   WeightTable wt(weights, n_weights);
   hipStream_t s = nullptr;
-  Loader L{wt, m->pool, s};
+  Loader L{wt, m->pool, s, cfg->ctx_len};
   const int* ch = cfg->block_out_channels;
   const int ctxd = cfg->cross_attention_dim;
   // heads per resolution level: SD-1.x uses num_heads everywhere, SD-2.x a fixed head dim of 64 (5, 10, 20, 20 heads)
@@ -597,6 +709,8 @@ struct UNetRun {
   int gemm(GemmArgs& g, RowStats* rs = nullptr, Tensor* ys = nullptr, FusedNorm* fn = nullptr) {
     if (dry) return 0;
     pick_sk(g);
+    // (split-K partials come from 128-row tiles: not where a sample's rows are fewer — the 8 x 8 maps of the mid block)
+    if (g.out_mode == OUT_SOFTMAX80 || (g.wb_rows && g.wb_rows % 128 != 0)) g.splitk = 1;
     if (fn && g.splitk > 1) {
       g.rows_per_batch = fn->y.H * fn->y.W;
       g.fn_Y = fn->y.p; g.fn_gamma = fn->n->g; g.fn_beta = fn->n->b; g.fn_eps = fn->eps; g.fn_silu = fn->silu;
@@ -618,7 +732,7 @@ struct UNetRun {
       if (touch) GILL_TRY(touch_bytes_launch(g.W, sizeof(bf16_t) * (size_t)g.N * g.K * ((g.conv && g.ups == 2) ? 4 : 1), 1024, s));
     }
     GILL_TRY(gemm_launch(g, s));
-    return dbg_sync(g.conv ? "conv" : (g.act == ACT_GEGLU ? "geglu" : (g.out_mode == OUT_QKV ? "qkv" : "gemm")), g.M, g.N, g.K);
+    return dbg_sync(g.conv ? "conv" : (g.act == ACT_GEGLU ? "geglu" : (g.out_mode == OUT_QKV ? "qkv" : (g.out_mode == OUT_SOFTMAX80 ? "scores+softmax" : "gemm"))), g.M, g.N, g.K);
   }
   // y8_scale > 0: y holds fp8(y8_scale * value) instead of bf16 (same shape; the A operand of conv8())
   int gnorm(const Tensor& x1, const Tensor* x2, const NormW& n, float eps, int silu, const Tensor& y, float y8_scale = 0.f) {
@@ -810,8 +924,10 @@ struct UNetRun {
     Bx = Bfull;
     const bf16_t* tres = t.p;         // the residual stream after the two attention sub-blocks
     bool ffn_pre = false;             // ... or, PRE: before attn2.to_out, which the feed-forward kernel then runs itself
+    bool xalg_done = false;
     {
     if (lnproj) {
+      GILL_REQUIRE(!w.xg, "internal: the fused projection pairs and the two-GEMM cross-attention are alternatives");
       lp.mode = 1; lp.X = o; lp.W1 = w.out1.w; lp.b1 = w.out1.b; lp.W2p = w.wq2p; lp.c2 = w.c_q2;
       if (!dry) GILL_TRY(lnproj_launch(lp, s));
     } else {
@@ -822,7 +938,22 @@ struct UNetRun {
       GILL_TRY(dup_pair_launch(t.p, x.p, xd.p, sizeof(bf16_t) * (size_t)M1 * C, s));
     }
     // --- cross attention (K/V cached per prompt)
-    {
+    if (w.xg) {
+      // ... as P = softmax80(LN(t) Mq_b^T), t += P Wo_b^T + bias on per-sample weights (xalg_fold_kernel)
+      const int n80 = 80 * nh, id = w.layer_id;
+      GemmArgs g;
+      g.M = M; g.N = n80; g.K = C; g.K1 = C; g.A = t.p; g.lda = C; g.W = m->xq_w[id];
+      g.wb_rows = HW; g.wb_stride = (int64_t)n80 * C; g.vb_stride = n80;
+      g.ln_stats = st2.p; g.ln_planes = st2.planes; g.ln_rows = M1; g.ln_colsum = m->xq_cs[id]; g.bias = m->xq_b[id];
+      g.out_mode = OUT_SOFTMAX80; g.C = o; g.ldc = n80;
+      GILL_TRY(gemm(g));
+      GemmArgs g2;
+      g2.M = M; g2.N = C; g2.K = n80; g2.K1 = n80; g2.A = o; g2.lda = n80; g2.W = m->xo_w[id]; g2.bias = w.out2.b;
+      g2.wb_rows = HW; g2.wb_stride = (int64_t)n80 * C;
+      g2.resid = t.p; g2.ldr = C; g2.C = t.p; g2.ldc = C;
+      GILL_TRY(gemm(g2, &st3));
+      xalg_done = true;
+    } else {
       GemmArgs g;
       g.M = M; g.N = hdp; g.K = C; g.K1 = C; g.A = t.p; g.lda = C; g.W = w.wq2;
       g.ln_stats = st2.p; g.ln_planes = st2.planes; g.ln_rows = M1; g.ln_colsum = w.s_q2; g.bias = w.c_q2;
@@ -832,11 +963,14 @@ struct UNetRun {
       GILL_TRY(gemm(g));
     }
     }
+    if (!xalg_done) {
+    GILL_REQUIRE(m->kcache[w.layer_id] != nullptr || dry, "internal: cross-attention K/V cache missing");
     GILL_TRY(attend(q, m->kcache[w.layer_id], m->vcache[w.layer_id], o, HW, m->cfg.ctx_len, hw_pad, m->ctx_pad, w));
     // (with the fused feed-forward kernel's PRE form, attn2.to_out + residual run inside it: ffn.hip)
     ffn_pre = ffn_fused && w.wpp != nullptr;
     GILL_REQUIRE(!ffn_fused || ffn_pre == w.w1c_kperm, "internal: fused feed-forward kernel form does not match the layout its weights were written in");
     if (!ffn_pre) GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M, w.out2.w, w.out2.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, &st3));
+    }
     }
     if (ffn_fused) {
       // --- GEGLU feed-forward, its residual, proj_out and the outer residual as ONE kernel (ffn.hip)
@@ -995,6 +1129,7 @@ static int unet_plan_and_alloc(gill_unet* m) {
   // dry run to size the activation arena
   m->arena.dry = true; m->arena.off = 0; m->arena.high = 0;
   m->kcache.assign(m->n_xf, nullptr); m->vcache.assign(m->n_xf, nullptr);
+  m->xq_w.assign(m->n_xf, nullptr); m->xo_w.assign(m->n_xf, nullptr); m->xq_cs.assign(m->n_xf, nullptr); m->xq_b.assign(m->n_xf, nullptr);
   UNetRun r{m, nullptr, Bx, nullptr, 0, true};
   GILL_TRY(r.forward(nullptr, nullptr));
   if (Bx % 2 == 0) {               // the CFG shared-prefix path allocates differently: size for the larger of the two
@@ -1004,7 +1139,9 @@ static int unet_plan_and_alloc(gill_unet* m) {
     if (gn1 > m->gn_next) m->gn_next = gn1;
     if (ln1 > m->ln_next) m->ln_next = ln1;
   }
-  const size_t need = m->arena.high + (1 << 20);
+  // (unet_ctx_cache stages the XALG layers' T = ctx [G | G2]^T here: at most ctx_len x 2 x 8 x 1280 bf16 per sample)
+  const size_t t_stage = sizeof(bf16_t) * (size_t)Bx * c.ctx_len * 2 * 8 * c.block_out_channels[3];
+  const size_t need = (m->arena.high > t_stage ? m->arena.high : t_stage) + (1 << 20);
   GILL_TRY(m->pool.alloc(&m->arena_mem, need, true));
   m->arena.base = m->arena_mem; m->arena.cap = need; m->arena.dry = false; m->arena.off = 0;
   m->gn_floats = m->gn_next + 64;           // counted by the dry run
@@ -1015,6 +1152,16 @@ static int unet_plan_and_alloc(gill_unet* m) {
   GILL_TRY(m->pool.alloc(&m->splitk_ws, m->splitk_ws_floats, false));
   // cross-attention K/V caches
   auto alloc_cache = [&](const XfW& w) -> int {
+    if (w.xg) {
+      const size_t n80 = (size_t)80 * w.heads;
+      GILL_TRY(m->pool.alloc(&m->xq_w[w.layer_id], (size_t)Bx * n80 * w.C, false));
+      GILL_TRY(m->pool.alloc(&m->xo_w[w.layer_id], (size_t)Bx * n80 * w.C, false));
+      GILL_TRY(m->pool.alloc(&m->xq_cs[w.layer_id], (size_t)Bx * n80));
+      GILL_TRY(m->pool.alloc(&m->xq_b[w.layer_id], (size_t)Bx * n80));
+      // (unet_ctx_cache stages T = ctx [G | G2]^T in the activation arena, which is idle between forwards)
+      GILL_REQUIRE(m->arena.cap >= sizeof(bf16_t) * (size_t)Bx * c.ctx_len * 2 * w.heads * w.C, "internal: arena smaller than the cross-attention staging tensor");
+      return 0;
+    }
     GILL_TRY(m->pool.alloc(&m->kcache[w.layer_id], (size_t)Bx * w.heads * m->ctx_pad * w.dp, true));
     GILL_TRY(m->pool.alloc(&m->vcache[w.layer_id], (size_t)Bx * w.heads * w.dpv * m->ctx_pad, true));
     return 0;
@@ -1071,6 +1218,19 @@ static int unet_time_table(gill_unet* m, const float* t_host, int rows, hipStrea
 static int unet_ctx_cache(gill_unet* m, const bf16_t* ctx, int Bx, hipStream_t s) {
   const gill_unet_config& c = m->cfg;
   auto one = [&](const XfW& w) -> int {
+    if (w.xg) {
+      const int H = w.heads, C = w.C, E = c.cross_attention_dim, id = w.layer_id;
+      bf16_t* T = (bf16_t*)m->arena.base;
+      GemmArgs g;
+      g.M = Bx * c.ctx_len; g.N = 2 * H * C; g.K = E; g.K1 = E; g.A = ctx; g.lda = E; g.W = w.xg; g.C = T; g.ldc = g.N;
+      GILL_TRY(gemm_launch(g, s));
+      hipLaunchKernelGGL(xalg_scores_operand_kernel, dim3(Bx * H * 80), dim3(256), 0, s, T, ctx, w.xgb, H, C, E, c.ctx_len, m->xq_w[id], m->xq_cs[id],
+                         m->xq_b[id]);
+      GILL_CHECK_HIP(hipGetLastError());
+      hipLaunchKernelGGL(xalg_values_operand_kernel, dim3(Bx * H * (C / 64)), dim3(256), 0, s, T, H, C, c.ctx_len, m->xo_w[id]);
+      GILL_CHECK_HIP(hipGetLastError());
+      return 0;
+    }
     GemmArgs g;
     g.M = Bx * c.ctx_len; g.N = 2 * w.heads * w.dp; g.K = c.cross_attention_dim; g.K1 = g.K;
     g.A = ctx; g.lda = c.cross_attention_dim; g.W = w.wkv2;
@@ -1377,6 +1537,65 @@ extern "C" int gill_op_lnproj(int mode, const void* x, void* t, const void* W1, 
   }
   static const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
   for (int r = 0; r < rep; ++r) GILL_TRY(lnproj_launch(a, s));
+  GILL_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// Op-level entry of the two-GEMM cross-attention (xalg_fold_kernel) on a torch-layout attn2 (to_q / to_out [C][C], to_k / to_v [C][E], heads
+// of d = C / H >= 80 features, norm2's gain and bias): folds the weights as the loader does, builds the per-sample operands from `ctx`
+// [B][ctx_len][E] as unet_ctx_cache does, then out = t + softmax(LN(t) Wq^T K^T / sqrt(d)) V Wo^T + bo on t [B * HW][C].  `P` (optional)
+// receives the softmax weights [B * HW][80 H] (key slot j of head h at column 80 h + j).  For tests and tools; synchronises.
+extern "C" int gill_op_cross_attention_folded(const void* t, const float* ln_g, const float* ln_b, const void* Wq, const void* Wk, const void* Wv,
+                                              const void* Wo, const float* bo, const void* ctx, void* out, void* P, int B, int HW, int C, int H,
+                                              int ctx_len, int E, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GILL_REQUIRE(t && ln_g && ln_b && Wq && Wk && Wv && Wo && bo && ctx && out, "null argument");
+  GILL_REQUIRE(H > 0 && H % 2 == 0 && C % H == 0, "cross_attention_folded: an even number of heads dividing C");
+  const int d = C / H, M = B * HW, n80 = 80 * H;
+  GILL_REQUIRE(d % 16 == 0 && d >= 80 && d <= 160 && C % 64 == 0 && E % 64 == 0 && ctx_len >= 1 && ctx_len <= 80 && HW % 64 == 0,
+               "cross_attention_folded: head dim 80..160 (multiple of 16), C and E multiples of 64, at most 80 context tokens, HW a multiple of 64");
+  DevBuf wq, wkv, cs, cq, xg, xgb, T, mq, mcs, mb, wo, st, p;
+  GILL_TRY(wq.alloc(sizeof(bf16_t) * (size_t)C * C));
+  GILL_TRY(wkv.alloc(sizeof(bf16_t) * (size_t)2 * C * E));
+  GILL_CHECK_HIP(hipMemcpyAsync(wq.p, Wq, sizeof(bf16_t) * (size_t)C * C, hipMemcpyDeviceToDevice, s));
+  GILL_CHECK_HIP(hipMemcpyAsync(wkv.p, Wk, sizeof(bf16_t) * (size_t)C * E, hipMemcpyDeviceToDevice, s));
+  GILL_CHECK_HIP(hipMemcpyAsync((bf16_t*)wkv.p + (size_t)C * E, Wv, sizeof(bf16_t) * (size_t)C * E, hipMemcpyDeviceToDevice, s));
+  GILL_TRY(cs.alloc(sizeof(float) * C)); GILL_TRY(cq.alloc_zero(sizeof(float) * C, s));      // (ln_fold_rows ADDS beta . W^T to the bias it is given)
+  GILL_TRY(ln_fold_rows_launch((bf16_t*)wq.p, C, C, ln_g, ln_b, (float*)cs.p, (float*)cq.p, s));
+  GILL_TRY(xg.alloc(sizeof(bf16_t) * (size_t)2 * H * C * E)); GILL_TRY(xgb.alloc(sizeof(float) * (size_t)H * E));
+  const float qs = 1.4426950408889634f / sqrtf((float)d);
+  hipLaunchKernelGGL(xalg_fold_kernel, dim3(2 * H * C / 8), dim3(256), 0, s, (const bf16_t*)wq.p, (const bf16_t*)wkv.p, (const bf16_t*)Wo, H, C, d, E, qs,
+                     (bf16_t*)xg.p);
+  hipLaunchKernelGGL(xalg_fold_bias_kernel, dim3(cdiv(E, 256), H), dim3(256), 0, s, (const float*)cq.p, (const bf16_t*)wkv.p, d, E, qs, (float*)xgb.p);
+  GILL_CHECK_HIP(hipGetLastError());
+  GILL_TRY(T.alloc(sizeof(bf16_t) * (size_t)B * ctx_len * 2 * H * C));
+  GILL_TRY(mq.alloc(sizeof(bf16_t) * (size_t)B * n80 * C)); GILL_TRY(wo.alloc(sizeof(bf16_t) * (size_t)B * n80 * C));
+  GILL_TRY(mcs.alloc(sizeof(float) * (size_t)B * n80)); GILL_TRY(mb.alloc(sizeof(float) * (size_t)B * n80));
+  {
+    GemmArgs g;
+    g.M = B * ctx_len; g.N = 2 * H * C; g.K = E; g.K1 = E; g.A = (const bf16_t*)ctx; g.lda = E; g.W = (const bf16_t*)xg.p; g.C = T.p; g.ldc = g.N;
+    GILL_TRY(gemm_launch(g, s));
+  }
+  hipLaunchKernelGGL(xalg_scores_operand_kernel, dim3(B * H * 80), dim3(256), 0, s, (const bf16_t*)T.p, (const bf16_t*)ctx, (const float*)xgb.p, H, C, E,
+                     ctx_len, (bf16_t*)mq.p, (float*)mcs.p, (float*)mb.p);
+  hipLaunchKernelGGL(xalg_values_operand_kernel, dim3(B * H * (C / 64)), dim3(256), 0, s, (const bf16_t*)T.p, H, C, ctx_len, (bf16_t*)wo.p);
+  GILL_CHECK_HIP(hipGetLastError());
+  GILL_TRY(st.alloc(sizeof(float) * (size_t)M * 2));
+  hipLaunchKernelGGL(ffn_op_rowsums_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, (const bf16_t*)t, M, C, (float*)st.p);
+  GILL_CHECK_HIP(hipGetLastError());
+  void* pp = P;
+  if (!pp) { GILL_TRY(p.alloc(sizeof(bf16_t) * (size_t)M * n80)); pp = p.p; }
+  GemmArgs g;
+  g.M = M; g.N = n80; g.K = C; g.K1 = C; g.A = (const bf16_t*)t; g.lda = C; g.W = (const bf16_t*)mq.p;
+  g.wb_rows = HW; g.wb_stride = (int64_t)n80 * C; g.vb_stride = n80;
+  g.ln_stats = (const float*)st.p; g.ln_planes = 1; g.ln_colsum = (const float*)mcs.p; g.bias = (const float*)mb.p;
+  g.out_mode = OUT_SOFTMAX80; g.C = pp; g.ldc = n80;
+  GemmArgs g2;
+  g2.M = M; g2.N = C; g2.K = n80; g2.K1 = n80; g2.A = (const bf16_t*)pp; g2.lda = n80; g2.W = (const bf16_t*)wo.p; g2.bias = bo;
+  g2.wb_rows = HW; g2.wb_stride = (int64_t)n80 * C;
+  g2.resid = t; g2.ldr = C; g2.C = out; g2.ldc = C;
+  static const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
+  for (int r = 0; r < rep; ++r) { GILL_TRY(gemm_launch(g, s)); GILL_TRY(gemm_launch(g2, s)); }
   GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
 }

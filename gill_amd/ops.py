@@ -222,3 +222,22 @@ def lnproj(mode: int, x: torch.Tensor, t, w1: torch.Tensor, b1: torch.Tensor, ln
   N.check(N.lib().gill_op_lnproj(mode, N.ptr(x), N.ptr(t), N.ptr(w1), N.ptr(b1), N.ptr(ln_g), N.ptr(ln_b), N.ptr(w2), N.ptr(q), N.ptr(k),
                                  N.ptr(vt), B, HW, N.current_stream()))
   return t, q, k, vt
+
+
+def cross_attention_folded(t: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor,
+                           wo: torch.Tensor, bo: torch.Tensor, ctx: torch.Tensor, heads: int, B: int, HW: int):
+  """norm2 + attn2 + residual of a BasicTransformerBlock with heads of 80..160 features as the engine runs it at UNet levels 1-3
+  (csrc/unet.hip "XALG"): out = t + softmax(LN(t) wq.T (ctx wk.T).T / sqrt(d)) (ctx wv.T) wo.T + bo, computed as two GEMMs on per-sample
+  weights folded from (wq, wk) and (wo, wv).  t (B * HW, C); wq, wo (C, C); wk, wv (C, E); ctx (B, ctx_len <= 80, E).
+  Returns (out (B * HW, C) bf16, P (B * HW, 80 * heads) bf16: the softmax weights, key j of head h at column 80 h + j)."""
+  t, wq, wk, wv, wo, ctx = (_bf(v) for v in (t, wq, wk, wv, wo, ctx))
+  M, C = t.shape
+  E = ctx.shape[-1]
+  f = lambda v: v.float().contiguous()
+  ln_g, ln_b, bo = f(ln_g), f(ln_b), f(bo)
+  nan = float("nan")      # (the engine passes stale arena memory: every element must be written)
+  out = torch.full((M, C), nan, device=t.device, dtype=torch.bfloat16)
+  P = torch.full((M, 80 * heads), nan, device=t.device, dtype=torch.bfloat16)
+  N.check(N.lib().gill_op_cross_attention_folded(N.ptr(t), N.ptr(ln_g), N.ptr(ln_b), N.ptr(wq), N.ptr(wk), N.ptr(wv), N.ptr(wo), N.ptr(bo),
+                                                 N.ptr(ctx), N.ptr(out), N.ptr(P), B, HW, C, heads, ctx.shape[1], E, N.current_stream()))
+  return out, P

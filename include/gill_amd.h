@@ -262,6 +262,17 @@ int gill_op_ffn_fused(const void* t_bf16, const float* ln_g, const float* ln_b, 
 int gill_op_lnproj(int mode, const void* x_bf16, void* t_bf16, const void* W1_bf16, const float* b1, const float* ln_g, const float* ln_b,
                    const void* W2_bf16, void* q_bf16, void* k_bf16, void* vt_bf16, int B, int HW, void* stream);
 
+/* attn2 (cross-attention) of a UNet transformer block with heads of 80..160 features, as the two GEMMs on per-sample weights the engine
+ * runs at UNet levels 1-3 (csrc/unet.hip "XALG"): K and V are linear in the prompt context, so qs (g o Wq_h)^T Wk_h and Wo_h Wv_h are
+ * folded at load, multiplied by ctx once per prompt, and each UNet call computes P = softmax(LN(t) Mq_b^T) and out = t + P Wo_b^T + bo.
+ * Operands in diffusers layout: t (B * HW, C) bf16, norm2 gain / bias (C) fp32, to_q / to_out.0 weights (C, C) bf16, to_k / to_v (C, E)
+ * bf16, to_out.0 bias (C) fp32, ctx (B, ctx_len <= 80, E) bf16 -> out (B * HW, C) bf16; P_bf16 (optional, B * HW x 80 H): the softmax
+ * weights, key j of head h at column 80 h + j.  Replaces norm2 + CrossAttention(attn2) + residual of diffusers' BasicTransformerBlock inside
+ * gill_unet_forward (reference call site: gill/custom_sd.py:633-638).  Synchronises. */
+int gill_op_cross_attention_folded(const void* t_bf16, const float* ln_g, const float* ln_b, const void* Wq_bf16, const void* Wk_bf16,
+                                   const void* Wv_bf16, const void* Wo_bf16, const float* bo, const void* ctx_bf16, void* out_bf16,
+                                   void* P_bf16, int B, int HW, int C, int H, int ctx_len, int E, void* stream);
+
 /* fp8 (OCP e4m3) 3x3 convolution on CDNA4's v_mfma_scale_f32_16x16x128_f8f6f4 — BASELINE.json configs[4]; no reference
  * counterpart (the reference runs SD in fp16, gill/models.py:550-551).  x (B,H,W,Cin) bf16 NHWC, w (Cout,Cin,3,3) fp32,
  * optional bias (Cout) fp32 and residual (B,H,W,Cout) bf16 -> y (B,H,W,Cout) bf16.  Operands are quantised inside

@@ -481,6 +481,40 @@ def test_lnproj_proj_in_qkv_vs_torch(cuda, B, HW):
   assert float(vt[:, :, d:48, :HW].float().abs().max()) == 0
 
 
+# ---------------------------------------------------------------- cross-attention as two GEMMs on per-sample weights (csrc/unet.hip "XALG")
+@pytest.mark.parametrize("B,HW,C,nh,ctx_len", [(2, 64, 1280, 8, 77), (3, 256, 1280, 8, 77), (2, 1024, 640, 8, 77), (2, 128, 640, 4, 80), (1, 64, 640, 8, 5)])
+def test_cross_attention_folded_vs_torch(cuda, B, HW, C, nh, ctx_len):
+  """norm2 -> attn2 (to_q, to_k / to_v of the prompt context, softmax, to_out) -> residual of a BasicTransformerBlock, computed by the two
+  GEMMs the engine runs at UNet levels 1-3 — P = softmax80(LN(t) Mq_b^T) and out = t + P Wo_b^T + bo on weights folded per sample from
+  (to_q, to_k, ctx) and (to_out, to_v, ctx) — against the fp32 attention on the same bf16-rounded operands.  The softmax weights themselves
+  are checked too (key slots >= ctx_len must be exactly 0, rows must sum to 1).  Ref: diffusers CrossAttention as restated in
+  oracle/unet_ref.py:_attention / _transformer."""
+  from gill_amd import ops
+  E, d, M = 768, C // nh, B * HW
+  t = _bf(_rnd((M, C), 90, 1.5) + 0.3)
+  ln_g, ln_b = 1.0 + 0.2 * _rnd((C,), 91), 0.1 * _rnd((C,), 92)
+  wq, wk, wv = _bf(_rnd((C, C), 93, 0.05)), _bf(_rnd((C, E), 94, 0.05)), _bf(_rnd((C, E), 95, 0.05))
+  wo, bo = _bf(_rnd((C, C), 96, 0.05)), 0.2 * _rnd((C,), 97)
+  ctx = _bf(_rnd((B, ctx_len, E), 98))
+  q = F.layer_norm(t.float(), (C,), ln_g, ln_b, 1e-5) @ wq.float().T                                       # (M, C)
+  k, v = ctx.float() @ wk.float().T, ctx.float() @ wv.float().T                                            # (B, ctx_len, C)
+  hq = q.view(B, HW, nh, d).permute(0, 2, 1, 3)
+  hk, hv = (x.view(B, ctx_len, nh, d).permute(0, 2, 1, 3) for x in (k, v))
+  p_ref = torch.softmax(hq @ hk.transpose(2, 3) / d ** 0.5, dim=-1)                                        # (B, h, HW, ctx_len)
+  o_ref = (p_ref @ hv).permute(0, 2, 1, 3).reshape(M, C)
+  out_ref = t.float() + o_ref @ wo.float().T + bo
+  out, P = ops.cross_attention_folded(t.to(cuda), ln_g.to(cuda), ln_b.to(cuda), wq.to(cuda), wk.to(cuda), wv.to(cuda), wo.to(cuda), bo.to(cuda),
+                                      ctx.to(cuda), nh, B, HW)
+  assert torch.isfinite(out.float()).all() and torch.isfinite(P.float()).all()        # (NaN-prefilled by the wrapper: all written)
+  Pv = P.float().cpu().view(B, HW, nh, 80).permute(0, 2, 1, 3)
+  assert float(Pv[..., ctx_len:].abs().max()) == 0 if ctx_len < 80 else True
+  assert float((Pv.sum(-1) - 1).abs().max()) < 2e-2                                   # (bf16 weights: 80 roundings of <= 2^-9 relative)
+  assert _report(f"xalg softmax weights B={B} HW={HW} C={C}", Pv[..., :ctx_len], p_ref) < 2e-2
+  # the attention term alone (what the two GEMMs add to the residual stream), then the sum
+  assert _report("xalg attention term", out.float().cpu() - t.float(), out_ref - t.float()) < 2e-2
+  assert _report("xalg out", out, out_ref) < 6e-3
+
+
 @pytest.mark.parametrize("B,HW", [(1, 128), (2, 1024)])
 def test_lnproj_to_out_to_q_vs_torch(cuda, B, HW):
   """attn1.to_out + residual -> norm2 -> attn2.to_q as one kernel, against the fp32 restatement on the same bf16-rounded operands."""
