@@ -175,8 +175,8 @@ template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT, int MI>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void gemm_kernel(const GemmDev d) {
   constexpr int BM = (NWV / 2) * MI * 16;
   static_assert(MI == 4 || (MI == 2 && NWV == 4 && CONV == 0 && (STAGES == 2 || STAGES == 3) && KT == 64) ||
-                    (MI == 2 && NWV == 8 && BN == 160 && CONV != 0 && STAGES == 3 && KT == 64),
-                "MI = 2: the 4-wave 64-row plain tile, or the 128 x 160 ping-pong conv tile (8 waves of 32 x 80)");
+                    (MI == 2 && NWV == 8 && BN == 160 && STAGES == 3 && KT == 64),
+                "MI = 2: the 4-wave 64-row plain tile, or the 128 x 160 ping-pong tile (8 waves of 32 x 80)");
   constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
   constexpr bool PP = (NWV == 8 && BN == 160 && STAGES == 3 && KT == 64);   // ping-pong main loop (see there)
   static_assert(KT == 64 || KT == 32, "stage depth");
@@ -1289,6 +1289,14 @@ static inline int reduce_width(const GemmArgs& a) {
 static inline int reduce_rows(const GemmArgs& a) {
   return ((int64_t)cdiv(a.N, reduce_width(a)) * cdiv(a.M, 64) >= 1024) ? 64 : 16;
 }
+// Long-K plain GEMMs whose width tiles by 160 (the feed-forward output GEMMs of UNet levels 1-3: K = 5 C) run on the convolutions'
+// ping-pong kernel too: their 64 x 160 / 128 x 160 four-wave tiles fetch 22 / 14 KiB per MFLOP through a 64 B/clk L2 port, the 8-wave
+// tiles 14 / 10 (GILL_GEMM_PLAIN_PP = 0: the four-wave tiles)
+static bool gemm_plain_pingpong(int M, int N, int K) {
+  static const int on = [] { const char* v = getenv("GILL_GEMM_PLAIN_PP"); return v ? atoi(v) : 1; }();
+  return on != 0 && N % 160 == 0 && M % 128 == 0 && K >= 2560 && K % 64 == 0;
+}
+
 // Tile width.  Tried and removed (numbers in profiles/r02_big_tile.md, profiles/r01_sweep_gemm_tiles.md): a 256 x 256 8-wave tile for
 // the wide plain GEMMs (GEGLU 94 -> 100 us, QKV 46.6 -> 48.3 us: those kernels are bound by their epilogues), a 4-deep ring of
 // 32-wide K stages (+7 % on the loop), a 3-deep ring on the 4-wave tiles.
@@ -1302,7 +1310,8 @@ static inline int tile_width(const GemmArgs& a) {
   if (!a.conv && a.out_mode == OUT_QKV && a.N % 128 == 0) bn = 128;
   // ... except on the 64-row tile (plain GEMMs with few tiles, see gemm_launch_bn): 64 x 128 needs 48 KiB of LDS, i.e. three
   // workgroups (six waves) per CU instead of two (four) — loop 587.3 -> 584.7 ms
-  if (!a.conv && a.splitk <= 1 && a.N % 128 == 0 && !a.gn_stats && (int64_t)cdiv(a.M, 128) * cdiv(a.N, 160) < 300 && a.M > 64 && a.out_mode != OUT_SOFTMAX80) bn = 128;
+  if (!a.conv && a.splitk <= 1 && a.N % 128 == 0 && !a.gn_stats && (int64_t)cdiv(a.M, 128) * cdiv(a.N, 160) < 300 && a.M > 64 && a.out_mode != OUT_SOFTMAX80 &&
+      !gemm_plain_pingpong(a.M, a.N, a.K)) bn = 128;
   return bn;
 }
 int gemm_row_planes(const GemmArgs& a) {
@@ -1345,7 +1354,7 @@ int gemm_pick_splitk(int M, int N, int K, int act, bool plain, bool generic) {
   const int ksteps = K / BK;
   if (tiles >= 384 || ksteps < 8) return 1;
   {   // convs that gemm_launch_bn puts on 128 x 160 ping-pong tiles: one workgroup per CU, 256 slots
-    if (pp128_on() && !plain && !generic && gemm_conv_pingpong(M, N) && tiles <= 256 && M % 128 == 0) {
+    if (pp128_on() && !generic && (plain ? gemm_plain_pingpong(M, N, K) : gemm_conv_pingpong(M, N)) && tiles <= 256 && M % 128 == 0) {
       int s = (256 + tiles / 2) / tiles;
       const int min_steps = (M <= 256 || tiles < 64) ? 4 : 24;
       if (s > ksteps / min_steps) s = ksteps / min_steps;
@@ -1420,9 +1429,15 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
     }
   }
   if constexpr (CONV == 0 && EPI == 5) {
-    // 64 x 160 tile on four waves of 32 x 80, 2-deep ring.  Measured on the three UNet shapes of the 8-sample batch (tools/xalg_bench.py, 20
-    // launches each): two waves of 64 x 80 1177 us, this 1003-1013 us, 3-deep ring 1212 us (3-deep only on the <= 256-workgroup grids: 1051 us)
-    if (d.nwv == 4 && d.mi == 2) return gemm_launch_inst<4, BN, CONV, EPI, 2, BK, 2>(d, grid, s);
+    // 64 x 160 tile on four waves of 32 x 80.  Measured on the three UNet shapes of the 8-sample batch back to back (tools/xalg_bench.py, 20
+    // launches each, operands warm): two waves of 64 x 80 1177 us, this with a 2-deep ring 1003-1013 us, 3-deep 1212 us, 3-deep only on
+    // the <= 256-workgroup grids 1051 us.  In the UNet forward the per-sample weights are cold (13 MB per layer, read once per call) and
+    // a workgroup's K walk is a chain of HBM round trips: there the 3-deep ring on the one-workgroup-per-CU grids (levels 2-3) wins,
+    // loop 446.7 -> 444.1 ms (4-deep: 444.7).
+    if (d.nwv == 4 && d.mi == 2) {
+      if ((int)(grid.x * grid.y) <= 256) return gemm_launch_inst<4, BN, CONV, EPI, 3, BK, 2>(d, grid, s);
+      return gemm_launch_inst<4, BN, CONV, EPI, 2, BK, 2>(d, grid, s);
+    }
   }
   if constexpr (CONV == 0 && (EPI == 0 || EPI == 3 || EPI == 4) && BN == 128) {
     if (d.nwv == 4 && d.mi == 2) {
@@ -1434,7 +1449,7 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
       return gemm_launch_inst<4, BN, CONV, EPI, 3, BK, 2>(d, grid, s);
     }
   }
-  if constexpr (BN == 160 && CONV != 0) {
+  if constexpr (BN == 160 && (CONV != 0 || EPI == 2 || EPI == 4)) {
     if (d.nwv == 8 && d.mi == 2) return gemm_launch_inst<8, BN, CONV, EPI, 3, BK, 2>(d, grid, s);   // ping-pong 128 x 160 tile
     if (d.nwv == 8) return gemm_launch_inst<8, BN, CONV, EPI, 3>(d, grid, s);     // ping-pong 256 x 160 tile
   }
@@ -1472,6 +1487,8 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   // need the 160-wide tile): loop 492.4 -> 489.4 ms against the two-wave tile.
   if (d.nwv == 2 && BN == 160 && a.act == ACT_NONE && a.out_mode == OUT_BF16) { d.nwv = 4; d.mi = 2; }
   if (a.out_mode == OUT_SOFTMAX80) { d.nwv = 4; d.mi = 2; }      // (see gemm_launch_stages)
+  // (round 4: the 64-row four-wave tile with its 3-deep ring — 96 instead of 64 KB in flight per CU — on ALL GEGLU / QKV / 128-wide plain
+  // GEMMs, not only the few-tile ones: loop 460.4 -> 469.4 / 464.8 / 460.7 ms.  Not kept.)
   if (forced_bm == 128) { d.nwv = 4; d.mi = 4; }
   if (forced_bm == 64 && !a.conv && sk == 1) { d.nwv = 2; d.mi = 4; }
   // 3x3 convolutions: 256 x 160 tile with the ping-pong main loop, one workgroup per CU (GILL_GEMM_PP = 0 keeps the two
@@ -1483,6 +1500,11 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     // split factor: half the fp32 partials (none at level 1)
     // (loop 561.1 -> 558.0 ms; GILL_GEMM_PP128 = 0 keeps the 256-row tile with twice the split)
     if (pp128_on() && (int64_t)cdiv(Mk, 256) * ncls * d.tiles_n * sk <= 128 && Mk % 128 == 0) d.mi = 2;
+  }
+  if (BN == 160 && !a.conv && gemm_plain_pingpong(a.M, a.N, a.K) && a.act == ACT_NONE && a.out_mode == OUT_BF16 && !a.resid_f32 && !a.wb_rows &&
+      !a.ln_stats && forced_bm == 0) {
+    d.nwv = 8; d.mi = 4;
+    if (((int64_t)cdiv(Mk, 256) * d.tiles_n * sk <= 128 && pp128_on()) || Mk % 256 != 0) d.mi = 2;
   }
   d.kt = 64;
   d.ksteps = a.K / d.kt;

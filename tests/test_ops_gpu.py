@@ -44,7 +44,7 @@ def test_gemm_plain(cuda, M, N, K):
 @pytest.mark.parametrize("M,N,K,sk", [(4096, 320, 1600, 1), (1024, 640, 3200, 1), (512, 1280, 6400, 2), (384, 320, 1600, 3)])
 def test_gemm_long_k_with_residual(cuda, M, N, K, sk):
   """The shapes of the UNet's fused feed-forward output GEMMs (N = 320 .. 1280, K = 5 N), with residual, unsplit and split-K.
-  (Running them on the convolutions' ping-pong tiles was measured: 541.5 vs 542.7 ms on the loop, inside the noise — not kept.)"""
+  N % 160 == 0, M % 128 == 0, K >= 2560 run on the convolutions' 8-wave ping-pong tiles (GILL_GEMM_PLAIN_PP, gemm.hip): cases 2 and 3."""
   from gill_amd import ops
   a, w = _bf(_rnd((M, K), 11)), _bf(_rnd((N, K), 12, 0.05))
   bias, resid = _rnd((N,), 13), _bf(_rnd((M, N), 14))

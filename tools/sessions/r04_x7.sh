@@ -1,0 +1,4 @@
+#!/bin/bash
+O=gpurun_out/r04_x7; mkdir -p $O
+one() { env "$@" timeout 600 python bench.py --no-cpu-baseline --no-pmc --no-scale-origin --steps 6 --warmup 2 2>/dev/null | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.readline()); print('$*: %.3f images/s, loop %.1f ms, frac %.4f' % (r['value'], r['roofline']['avg_launch_ms'], r['roofline']['frac']))"; }
+for r in 1 2 3; do one GILL_XALG_STAGES=2; one GILL_XALG_STAGES=3; one GILL_XALG_STAGES=4; done
