@@ -1506,6 +1506,8 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     d.nwv = 8; d.mi = 4;
     if (((int64_t)cdiv(Mk, 256) * d.tiles_n * sk <= 128 && pp128_on()) || Mk % 256 != 0) d.mi = 2;
   }
+  // (round 4: the short-K GEGLU / QKV GEMMs on 256 x 128 / 128 x 128 ping-pong tiles, one N tile per workgroup: loop 464.0 -> 478.0 / 480.4 ms
+  // (GEGLU), 467.0 / 468.8 ms (QKV) — ten K steps do not amortise a prologue and an epilogue that no second workgroup covers.  Not kept.)
   d.kt = 64;
   d.ksteps = a.K / d.kt;
   d.ksteps_per_split = cdiv(d.ksteps, sk);
@@ -1530,7 +1532,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   }
   GILL_REQUIRE(a.wb_rows == 0 || (a.wb_rows % ((d.nwv / 2) * d.mi * 16) == 0 && !a.conv), "per-sample weights: tiles must not straddle samples");
   dim3 grid(tiles_m * d.groups_n, sk, ncls);
-  if (BN == 160 && d.nwv == 8) GILL_REQUIRE(d.npw == 1, "internal: the ping-pong kernel walks one N tile per workgroup");
+  if (d.nwv == 8) GILL_REQUIRE(d.npw == 1, "internal: the ping-pong kernel walks one N tile per workgroup");
   if (a.conv) {
     if (a.ups == 2) {
       if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 3, 2>(d, grid, s)));
