@@ -162,16 +162,23 @@ def pmc_traffic_live(a):
 def kernel_rooflines(dev):
   """The three dominant device kernels of the UNet loop, each timed alone with HIP events on its level-0 shape of the CFG
   batch 8 through the operator C ABI (gill_op_*): algorithmic FLOPs / average launch time."""
-  os.environ["GILL_OP_REPEAT"] = "20"      # read once by libgill_amd at the first gill_op_* call
   from gill_amd import ops
   out = []
+  R1, R2 = 5, 45      # GILL_OP_REPEAT is read by libgill_amd at every gill_op_* call: a call launches its kernel that many times
 
   def timed(fn, flops, name):
-    fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); fn(); e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / 20
+    # per-launch time = (call at R2 repeats - call at R1 repeats) / (R2 - R1): the wrapper's own work (weight re-layout, scratch
+    # allocation, layout conversions) is in both calls and cancels
+    ms = {}
+    for r in (R1, R2, R1, R2):
+      os.environ["GILL_OP_REPEAT"] = str(r)
+      fn()
+      torch.cuda.synchronize()
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+      ms[r] = e0.elapsed_time(e1)
+    os.environ["GILL_OP_REPEAT"] = "1"
+    us = (ms[R2] - ms[R1]) * 1e3 / (R2 - R1)
     out.append({"kernel": name, "avg_launch_us": us, "achieved": flops / us / 1e6, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": flops / us / 1e6 / PEAK_BF16_TFLOPS, "bound": "mfma"})
 
@@ -179,10 +186,10 @@ def kernel_rooflines(dev):
   w = torch.randn(320, 320, 3, 3, device=dev) * 0.02
   timed(lambda: ops.conv3x3(x, w), 2.0 * 8 * 4096 * 320 * 2880, "gemm_kernel<8,160,1,0,3>: 3x3 conv 320->320 @ 64x64 x 8 (implicit GEMM, 256x160 ping-pong tile)")
   q = torch.randn(8, 4096, 320, device=dev).bfloat16()
-  timed(lambda: ops.attention(q, q, q, 8), 4.0 * 8 * 8 * 4096 * 4096 * 40, "attention_kernel<48>: self-attention N=4096, 8 heads x d=40, x 8 (incl. head re-layout wrappers)")
+  timed(lambda: ops.attention(q, q, q, 8), 4.0 * 8 * 8 * 4096 * 4096 * 40, "attention_dma_kernel<48,512>: self-attention N=4096, 8 heads x d=40, x 8")
   a = torch.randn(32768, 1280, device=dev).bfloat16()
   wl = (torch.randn(320, 1280, device=dev) * 0.03).bfloat16()
-  timed(lambda: ops.gemm(a, wl), 2.0 * 32768 * 320 * 1280, "gemm_kernel<4,160,0,0,2>: GEMM 32768 x 320 x 1280 (level-0 feed-forward output shape)")
+  timed(lambda: ops.gemm(a, wl), 2.0 * 32768 * 320 * 1280, "gemm_kernel<4,160,0,4,2>: GEMM 32768 x 320 x 1280 (level-0 feed-forward output shape)")
   return out
 
 

@@ -16,7 +16,8 @@ extern "C" int gill_version(void) { return 100; }
 // GILL_OP_REPEAT=n makes the operator entry points launch their kernel n times per call (tools/bench_ops.py: amortises
 // the wrapper's allocation / re-layout so the kernel itself can be timed); default 1.
 static int op_repeat() {
-  static const int r = [] { const char* v = getenv("GILL_OP_REPEAT"); int n = v ? atoi(v) : 1; return n < 1 ? 1 : n; }();
+  const char* v = getenv("GILL_OP_REPEAT");     // read at every call: bench.py times a call at two repeat counts and takes the difference
+  const int r = v ? (atoi(v) < 1 ? 1 : atoi(v)) : 1;
   return r;
 }
 

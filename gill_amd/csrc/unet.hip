@@ -1490,7 +1490,7 @@ extern "C" int gill_op_ffn_fused(const void* t, const float* ln_g, const float* 
   fa.Wfo = (const bf16_t*)wfo.p; fa.bo = (const float*)bfo.p; fa.resid = (const bf16_t*)resid; fa.out = (bf16_t*)out;
   fa.gn_stats = gn_stats; fa.rows_per_batch = rows_per_batch;
   if (o2) { fa.X = (const bf16_t*)o2p.p; fa.Wo = (const bf16_t*)wop.p; fa.bo2 = bo2; fa.Wpp = (const bf16_t*)wpp.p; }
-  static const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
+  const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
   for (int r = 0; r < rep; ++r) GILL_TRY(ffn_fused_launch(fa, s));
   GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
@@ -1535,7 +1535,7 @@ extern "C" int gill_op_lnproj(int mode, const void* x, void* t, const void* W1, 
     GILL_CHECK_HIP(hipGetLastError());
     a.X = (const bf16_t*)xp.p; a.W1 = (const bf16_t*)w1p.p;
   }
-  static const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
+  const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
   for (int r = 0; r < rep; ++r) GILL_TRY(lnproj_launch(a, s));
   GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
@@ -1594,7 +1594,7 @@ extern "C" int gill_op_cross_attention_folded(const void* t, const float* ln_g, 
   g2.M = M; g2.N = C; g2.K = n80; g2.K1 = n80; g2.A = (const bf16_t*)pp; g2.lda = n80; g2.W = (const bf16_t*)wo.p; g2.bias = bo;
   g2.wb_rows = HW; g2.wb_stride = (int64_t)n80 * C;
   g2.resid = t; g2.ldr = C; g2.C = out; g2.ldc = C;
-  static const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
+  const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
   for (int r = 0; r < rep; ++r) { GILL_TRY(gemm_launch(g, s)); GILL_TRY(gemm_launch(g2, s)); }
   GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;

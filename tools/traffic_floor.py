@@ -48,9 +48,10 @@ def xf(tag, hw, c):
     r += c; w += 2 * hq + heads * dpv                     # QKV: reads t, writes q, k, vt
     r += 2 * hq + heads * dpv; w += hq                    # self-attention
     r += hq + c; w += c                                   # out1 (+ residual t)
-    r += c; w += hq                                       # to_q of the cross-attention
-    r += hq; w += hq                                      # cross-attention
-    r += hq + c; w += c                                   # out2
+    # cross-attention as two GEMMs on per-sample folded weights (unet.hip "XALG"): P = softmax80(LN(t) Mq^T) [80 x heads wide], t += P Wo^T
+    # (+ per call and sample the operands Mq, Wo: 2 x 80 x heads x c bf16 elements, added below as "weights")
+    r += c; w += 80 * heads                               # scores + softmax GEMM: reads t, writes P
+    r += 80 * heads + c; w += c                           # values + to_out GEMM (+ residual t)
     r += c; w += 4 * c                                    # GEGLU
     r += 4 * c + c + c; w += c                            # [Wp W2 | Wp] GEMM over [h | t] + outer residual x -> out
   add(tag + " transformer", px * r, px * w)
@@ -84,6 +85,8 @@ for i in range(4):
     hw *= 4
 add("conv_norm_out + conv_out", B * hw * ch[0] * bf * 2, B * hw * (ch[0] * bf + 4 * 4))
 weights = 859_520_964 * bf
+# XALG layers (5 at C = 640, 6 at C = 1280) read per-sample operands instead of to_q / to_out weights: 2 x 80 x heads x C per sample
+weights += sum(n * (B * 2 * 80 * heads * c - 2 * c * c) * bf for n, c in ((5, 640), (6, 1280)))
 act = tot_r + tot_w
 print(f"SD-1.5 UNet forward, batch {B}: weights {weights / 1e9:.2f} GB + activations {tot_r / 1e9:.2f} GB read + {tot_w / 1e9:.2f} GB written "
       f"= {(weights + act) / 1e9:.2f} GB algorithmic HBM bytes")
