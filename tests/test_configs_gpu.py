@@ -216,6 +216,9 @@ def test_bench_eight_ranks_uneven_shards_gloo(cuda):
   assert rec["n_gpus"] == 8 and rec["config"]["global_batch"] == 5 and rec["value"] > 0
 
 
+_SWITCH_DEFAULT_OUT = {}
+
+
 @pytest.mark.parametrize("switch", ["GILL_UNET_FFN_FUSED", "GILL_UNET_LNPROJ", "GILL_UNET_FFN_PRE", "GILL_ATT_DMA", "GILL_GEMM_RED_GN", "GILL_UNET_XALG"])
 def test_fused_block_switches_full_size_forward(cuda, switch):
   """GILL_UNET_FFN_FUSED / GILL_UNET_LNPROJ / GILL_ATT_DMA (the level-0 attention on the LDS-DMA kernel, default, or on the register-staged
@@ -237,11 +240,15 @@ def test_fused_block_switches_full_size_forward(cuda, switch):
   outs = []
   with tempfile.TemporaryDirectory() as d:
     for sw in ("0", "1"):
+      if sw == "1" and "default" in _SWITCH_DEFAULT_OUT:      # every switch defaults to on: the all-defaults forward is run once
+        outs.append(_SWITCH_DEFAULT_OUT["default"])
+        continue
       f = os.path.join(d, f"y{sw}.pt")
       r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **{switch: sw}), capture_output=True, text=True,
                          timeout=900)
       assert r.returncode == 0, r.stderr[-2000:]
       outs.append(torch.load(f))
+      if sw == "1": _SWITCH_DEFAULT_OUT["default"] = outs[-1]
   assert torch.isfinite(outs[1]).all() and not torch.equal(outs[0], outs[1])       # (the switch did switch)
   _, rel, cos = _stats(f"full-size forward: {switch} on vs off", outs[1], outs[0])
   assert rel < 1.5e-2 and cos > 0.9995
