@@ -1339,6 +1339,8 @@ static bool pp128_on() {
   static const int v = [] { const char* e = getenv("GILL_GEMM_PP128"); return e ? atoi(e) : 1; }();
   return v != 0;
 }
+// (round 4: 256 x 128 ping-pong tiles for the widths 160 does not divide — the VAE decoder's 128 / 256 / 512-channel convolutions: 484.8 /
+// 403.2 / 303.9 us against 464.8 / 406.1 / 301.0 us on the four-wave 128 x 128 tiles, VAE decode 12.74 vs 12.69 ms.  Not kept.)
 bool gemm_conv_pingpong(int rows_multiple_of, int Cout) {
   static const int pp_env = [] { const char* v = getenv("GILL_GEMM_PP"); return v ? atoi(v) : 1; }();
   return pp_env != 0 && rows_multiple_of % 256 == 0 && Cout % 160 == 0;
