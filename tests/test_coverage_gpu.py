@@ -40,7 +40,7 @@ def test_sd_driver_vs_reference_pipeline_call_golden(cuda):
   kw = dict(guidance_scale=float(g["guidance"]), num_inference_steps=int(g["steps"]))
   lat = pipe(prompt_embeds=cond, negative_prompt_embeds=neg, latents=lat0, output_type="latent", **kw).images
   _, rel, cos = _stats("F8 latents (10-step CFG, per-sample negatives)", lat, torch.from_numpy(g["latents"]))
-  assert rel < 8e-2 and cos > 0.995          # 11 recurrent bf16 UNet calls vs the fp32 reference-driven run
+  assert rel < 5e-2 and cos > 0.995          # 11 recurrent bf16 UNet calls vs the fp32 reference-driven run
   img = pipe(prompt_embeds=cond, negative_prompt_embeds=neg, latents=lat0, output_type="np", **kw).images
   ref_img = g["images"].astype(np.float32)
   assert img.shape == ref_img.shape == (2, 128, 128, 3)
@@ -118,7 +118,7 @@ def test_sd15_full_size_10step_loop_vs_oracle(cuda, sd15_pipe):
   got = pipe(prompt_embeds=cond, latents=lat0, guidance_scale=7.5, num_inference_steps=10).images
   ref = pipeline_ref.denoise(sd, cond, uncond, lat0, 10, 7.5)
   _, rel, cos = _stats("SD-1.5 full size, 10-step CFG loop, 1 prompt", got, ref)
-  assert rel < 8e-2 and cos > 0.995
+  assert rel < 4e-2 and cos > 0.995
   # a second call replays the graph captured by the first: same answer up to the statistics atomics
   again = pipe(prompt_embeds=cond, latents=lat0, guidance_scale=7.5, num_inference_steps=10).images
   rr = ((again - got).norm() / got.norm()).item()

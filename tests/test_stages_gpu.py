@@ -401,7 +401,7 @@ def test_denoise_tiny_vs_oracle(cuda):
   ref = pipeline_ref.denoise(sd, cond, uncond, lat0, 10, 7.5, cfg.block_out_channels, cfg.num_heads, cfg.norm_num_groups)
   got = pipe(prompt_embeds=cond, latents=lat0, guidance_scale=7.5, num_inference_steps=10).images
   mse, rel, cos = _stats("denoise tiny 10 steps", got, ref)
-  assert rel < 8e-2 and cos > 0.995     # 11 recurrent bf16 UNet calls; guidance 7.5 amplifies eps differences
+  assert rel < 4e-2 and cos > 0.995     # 11 recurrent bf16 UNet calls; guidance 7.5 amplifies eps differences
   # no-CFG path (guidance <= 1: custom_sd.py:588)
   ref1 = pipeline_ref.denoise(sd, cond, None, lat0, 5, 1.0, cfg.block_out_channels, cfg.num_heads, cfg.norm_num_groups)
   got1 = pipe(prompt_embeds=cond, latents=lat0, guidance_scale=1.0, num_inference_steps=5).images
@@ -412,7 +412,7 @@ def test_denoise_tiny_vs_oracle(cuda):
   _, relb, _ = _stats("batch invariance", got_b0, got[:1])
   # not bitwise: the split-K factor (hence the fp32 summation order) depends on the batch; 11 recurrent steps at
   # guidance 7.5 amplify that rounding noise to the same level as the distance to the fp32 oracle above
-  assert relb < 8e-2
+  assert relb < 2e-2
 
 
 def test_sd2_geometry_tiny_vs_oracle(cuda):
@@ -439,7 +439,7 @@ def test_sd2_geometry_tiny_vs_oracle(cuda):
   gotl = pipe(prompt_embeds=cond, latents=lat0, guidance_scale=7.5, num_inference_steps=8).images
   _, rell, cosl = _stats("SD-2.x v-prediction denoise 8 steps", gotl, refl)
   # v-prediction feeds sqrt(1 - a_t) * sample back through the update: bf16 differences compound faster than with epsilon
-  assert rell < 1.5e-1 and cosl > 0.99
+  assert rell < 1.2e-1 and cosl > 0.99
 
 
 @pytest.mark.skipif(os.environ.get("GILL_SKIP_SLOW") == "1", reason="slow CPU oracle")
