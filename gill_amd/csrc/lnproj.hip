@@ -130,6 +130,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // Branch-free (clamped index, the surplus threads rewrite the last entry): under a predicate the compiler sinks the load into the
   // branch, where it is the newest memory operation and its wait a full vmcnt(0).
   float tb1[2], tc2[(NSEG * LSEG + 255) / 256];
+  // (mode 0 with the block's GroupNorm folded in: its scale / shift rows, 640 floats of this workgroup's sample — 128 rows, ntok % 128 == 0)
+  float tgn[MODE == 0 ? 3 : 1];
+  const bool gn_fold = MODE == 0 && p.gn_ss != nullptr;       // (uniform)
+  if constexpr (MODE == 0) {
+    if (gn_fold) {
+      const float* ss = p.gn_ss + (size_t)((blockIdx.x * LTM) / p.ntok) * 2 * LC;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) tgn[j] = ss[min(tid + 256 * j, 2 * LC - 1)];
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) tb1[j] = p.b1[min(tid + 256 * j, LC - 1)];
 #pragma unroll
@@ -162,6 +172,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int j = 0; j < 2; ++j) lds_write_b32(bt_lds + 4 * min(tid + 256 * j, LC - 1), tb1[j]);
 #pragma unroll
     for (int j = 0; j < (NSEG * LSEG + 255) / 256; ++j) lds_write_b32(bt_lds + 4 * (LC + min(tid + 256 * j, NSEG * LSEG - 1)), tc2[j]);
+    if constexpr (MODE == 0) {
+      // the GroupNorm table sits in the LAST 4 KiB of the ring slot no stage has been issued into yet (slot LDEPTH): those bytes belong
+      // to the fifth piece of stage LDEPTH, which every wave issues behind the first barrier of stage 0 — after all have read the table
+      if (gn_fold) {
+        const unsigned gt = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(smem + LDEPTH * LSLOT + 16 * 1024);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) lds_write_b32(gt + 4 * min(tid + 256 * j, 2 * LC - 1), tgn[j]);
+      }
+    }
   }
   const float* b1t = reinterpret_cast<const float*>(smem + LBIAS_OFF);
   const float* c2t = b1t + LC;
@@ -207,6 +226,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the tables' ds_writes
   __builtin_amdgcn_s_barrier();
+  if constexpr (MODE == 0) {
+    if (gn_fold) {
+      // x := bf16(x * scale[c] + shift[c]) on the fragments in registers: lane (m, hi) holds channels 16 s + 8 hi .. + 7 of k16 step s
+      const float* gsc = reinterpret_cast<const float*>(smem + LDEPTH * LSLOT + 16 * 1024);
+      const float* gsh = gsc + LC;
+#pragma unroll
+      for (int s = 0; s < K1 / 16; ++s) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(gsc + 16 * s + 8 * hi), s1 = *reinterpret_cast<const f32x4*>(gsc + 16 * s + 8 * hi + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(gsh + 16 * s + 8 * hi), h1 = *reinterpret_cast<const f32x4*>(gsh + 16 * s + 8 * hi + 4);
+        union { bf16x8 v; uint32_t u[4]; } x;
+        x.v = xf[s];
+        x.u[0] = pack_bf2(fmaf(bf2f((bf16_t)(x.u[0] & 0xffff)), s0[0], h0[0]), fmaf(bf2f((bf16_t)(x.u[0] >> 16)), s0[1], h0[1]));
+        x.u[1] = pack_bf2(fmaf(bf2f((bf16_t)(x.u[1] & 0xffff)), s0[2], h0[2]), fmaf(bf2f((bf16_t)(x.u[1] >> 16)), s0[3], h0[3]));
+        x.u[2] = pack_bf2(fmaf(bf2f((bf16_t)(x.u[2] & 0xffff)), s1[0], h1[0]), fmaf(bf2f((bf16_t)(x.u[2] >> 16)), s1[1], h1[1]));
+        x.u[3] = pack_bf2(fmaf(bf2f((bf16_t)(x.u[3] & 0xffff)), s1[2], h1[2]), fmaf(bf2f((bf16_t)(x.u[3] >> 16)), s1[3], h1[3]));
+        xf[s] = x.v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the table reads have returned before this wave issues anything into the slot
+    }
+  }
 
   // per-wave 3.5 KiB of LDS behind the tables: every tile this wave writes goes through it, so that the global stores are 16 B per lane
   // over contiguous runs (the accumulator layout itself gives 8-B pieces of 32 different rows per instruction: measured, the memory
@@ -417,6 +456,7 @@ int lnproj_launch(const LnProjArgs& a, hipStream_t s) {
   GILL_REQUIRE(lnproj_supported(LC, a.M, a.heads, a.dp), "lnproj: C = 320, M % 128 == 0, 8 heads of padded dim 48 only");
   GILL_REQUIRE(a.X && a.T && a.W1 && a.b1 && a.W2p && a.c2 && a.Cq, "lnproj: null operand");
   GILL_REQUIRE(a.ntok > 0 && a.ntok % 32 == 0 && a.ntok_pad >= a.ntok && a.ntok_pad % 8 == 0, "lnproj: tokens per sample must be a multiple of 32");
+  GILL_REQUIRE(a.gn_ss == nullptr || (a.mode == 0 && a.ntok % LTM == 0), "lnproj: the folded GroupNorm needs mode 0 and whole 128-row tiles per sample");
   if (a.mode == 0) {
     GILL_REQUIRE(a.Ck && a.Cvt && a.seg_base == 0 && a.dpv >= a.dp, "lnproj: QKV outputs missing");
     return lnproj_launch_mode<0>(a, s);

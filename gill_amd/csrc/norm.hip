@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
                                                               const float* __restrict__ beta, float eps, int silu,
                                                               const float* __restrict__ stats1, int nb1, int r1, int ns1, int bs1,
                                                               const float* __restrict__ stats2, int nb2, int r2, int o2, int ns2, int bs2,
-                                                              bf16_t* __restrict__ y, int rows, int cc, float out8_scale) {
+                                                              bf16_t* __restrict__ y, int rows, int cc, float out8_scale, float* __restrict__ ss_out) {
   // block = (slab of `rows` pixels, sample b, chunk of cc <= 256 channels).  Phase 1: fold statistics and affine into
   // per-channel (scale, shift) in LDS — one channel per thread, so the dependent loads of the prologue are paid once,
   // not C/256 times; phase 2: y = [silu](x * scale + shift), 16-B loads and stores.
@@ -321,6 +321,13 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
     shift[ch] = beta[ch] - sm * sc;
   }
   __syncthreads();
+  if (ss_out) {      // scale / shift table only ([b][scale | shift][C]): the consumer applies them itself (lnproj.hip: the transformer's GroupNorm)
+    for (int ch = c0 + threadIdx.x; ch < c0 + cc; ch += blockDim.x) {
+      ss_out[((size_t)b * 2 + 0) * C + ch] = scale[ch];
+      ss_out[((size_t)b * 2 + 1) * C + ch] = shift[ch];
+    }
+    return;
+  }
   const int p0 = blockIdx.x * rows;
   int p1 = p0 + rows;
   if (p1 > HW) p1 = HW;
@@ -391,7 +398,7 @@ int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, 
   // `stats` holds nslab partial {sum, sum of squares} per group of the whole (concatenated) input
   // (the totals scratch is the tail of `stats`: groupnorm_stats_floats() counts it)
   return groupnorm_apply_launch(x1, C1, x2, C2, B, HW, groups, gamma, beta, eps, silu, y, stats, C / groups, C, nslab, nullptr, 0, 0, s,
-                                out8_scale, stats + (size_t)B * nslab * groups * 2);
+                                out8_scale, stats + (size_t)B * nslab * groups * 2, nullptr);
 }
 
 // Partial counts beyond GN_MAX_PARTIALS (the VAE's 128^2 .. 512^2 maps, the SD-2.1-768 UNet's 96^2 maps): total them once, in slab
@@ -422,7 +429,7 @@ static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t
 // stats2 = [B][(C - sc1) / bin2][2] over the rest (nullptr when stats1 covers everything).
 int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups, const float* gamma,
                            const float* beta, float eps, int silu, bf16_t* y, const float* stats1, int bin1, int sc1, int nslab1,
-                           const float* stats2, int bin2, int nslab2, hipStream_t s, float out8_scale, float* tot_scratch) {
+                           const float* stats2, int bin2, int nslab2, hipStream_t s, float out8_scale, float* tot_scratch, float* ss_out) {
   const int C = C1 + C2;
   GILL_REQUIRE(groups <= 64 && C % groups == 0 && (C / groups) % 2 == 0, "groupnorm: channels/group must be even");
   GILL_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "groupnorm: channel counts must be multiples of 8");
@@ -456,10 +463,10 @@ int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, i
   // grid is short of ~4 blocks per CU
   int rows = 64;
   while (rows > 4 && (int64_t)cdiv(HW, rows) * B * nch < 1024) rows >>= 1;
-  dim3 g2(cdiv(HW, rows), B, nch);
+  dim3 g2(ss_out ? 1 : cdiv(HW, rows), B, nch);
   hipLaunchKernelGGL(groupnorm_apply_kernel, g2, dim3(256), 0, s, x1, C1, x2, C2, HW, groups, gamma, beta,
                      eps, silu, stats1, sc1 / bin1, cg / bin1, ns1, bs1, stats2, stats2 ? (C - sc1) / bin2 : 0,
-                     stats2 ? cg / bin2 : 0, stats2 ? sc1 / bin2 : 0, stats2 ? ns2 : 0, stats2 ? bs2 : 0, y, rows, cc, out8_scale);
+                     stats2 ? cg / bin2 : 0, stats2 ? sc1 / bin2 : 0, stats2 ? ns2 : 0, stats2 ? bs2 : 0, y, rows, cc, out8_scale, ss_out);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }

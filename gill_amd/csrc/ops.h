@@ -165,6 +165,9 @@ struct LnProjArgs {
   bf16_t *Cq = nullptr, *Ck = nullptr, *Cvt = nullptr;       // GemmArgs' OUT_QKV layout
   int heads = 0, dp = 0, dpv = 0, ntok = 0, ntok_pad = 0, seg_base = 0;
   float qscale = 1.f;
+  // mode 0: X is the RAW block input and gn_ss [B][2][320] its GroupNorm scale / shift (groupnorm_apply_launch(..., ss_out)): the kernel
+  // normalises the rows it has just loaded, y = bf16(x * scale + shift) as the stand-alone pass rounds it (ntok % 128 == 0)
+  const float* gn_ss = nullptr;
 };
 bool lnproj_supported(int C, int M, int heads, int dp);
 int lnproj_kperm_launch(const bf16_t* src, int N, bf16_t* dst, hipStream_t s);
@@ -194,7 +197,9 @@ int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, 
 int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, int HW, int groups, const float* gamma,
                            const float* beta, float eps, int silu, bf16_t* y, const float* stats1, int bin1, int sc1, int nslab1,
                            const float* stats2, int bin2, int nslab2, hipStream_t s, float out8_scale = 0.f,
-                           float* tot_scratch = nullptr);
+                           float* tot_scratch = nullptr, float* ss_out = nullptr);
+// ss_out != nullptr: nothing is normalised — the per-(sample, channel) scale and shift are written as [B][2][C] floats for a consumer
+// that applies y = bf16(x * scale + shift) itself (lnproj.hip mode 0: the transformer block's GroupNorm on its way into proj_in)
 // out8_scale > 0: y is an fp8 (e4m3) tensor [B][HW][C] holding fp8(out8_scale * value) — the A operand of conv3x3_fp8_launch
 bool groupnorm_bins_align(int cg, int sc1, int bin1, int bin2);
 

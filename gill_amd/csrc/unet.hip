@@ -326,6 +326,11 @@ static bool ffn_pre_on() {
   static const bool on = [] { const char* e = getenv("GILL_UNET_FFN_PRE"); return !(e && e[0] == '0'); }();
   return on;
 }
+// GILL_UNET_GNFOLD=0: the level-0 transformer blocks' GroupNorm as its own pass in front of the fused projection kernel
+static bool gnfold_on() {
+  static const bool on = [] { const char* e = getenv("GILL_UNET_GNFOLD"); return !(e && e[0] == '0'); }();
+  return on;
+}
 // GILL_UNET_XALG=0: attn2 of levels 1-3 as to_q + attention kernel + to_out instead of the two per-sample GEMMs (xalg_fold_kernel)
 static bool xalg_on() {
   static const bool on = [] { const char* e = getenv("GILL_UNET_XALG"); return !(e && e[0] == '0'); }();
@@ -735,7 +740,10 @@ struct UNetRun {
     return dbg_sync(g.conv ? "conv" : (g.act == ACT_GEGLU ? "geglu" : (g.out_mode == OUT_QKV ? "qkv" : (g.out_mode == OUT_SOFTMAX80 ? "scores+softmax" : "gemm"))), g.M, g.N, g.K);
   }
   // y8_scale > 0: y holds fp8(y8_scale * value) instead of bf16 (same shape; the A operand of conv8())
-  int gnorm(const Tensor& x1, const Tensor* x2, const NormW& n, float eps, int silu, const Tensor& y, float y8_scale = 0.f) {
+  // ss_out: write the per-(sample, channel) scale / shift table instead of normalising (single-source inputs whose producer filed the
+  // statistics; *folded says whether that was possible — if not, y is normalised as usual)
+  int gnorm(const Tensor& x1, const Tensor* x2, const NormW& n, float eps, int silu, const Tensor& y, float y8_scale = 0.f,
+            float* ss_out = nullptr, bool* folded = nullptr) {
     // single-source input whose producer already accumulated the sums: no statistics pass
     const int C = x1.C + (x2 ? x2->C : 0);
     const bool ready = x1.stats != nullptr && (x2 == nullptr || x2->stats != nullptr) &&
@@ -748,10 +756,13 @@ struct UNetRun {
     if (dry) return 0;
     GILL_REQUIRE(m->gn_next <= m->gn_floats, "internal: GroupNorm stats pool exhausted");
     GILL_TRY(dbg_sync("before groupnorm", x1.C, x2 ? x2->C : 0, HW));
-    if (ready)
+    if (ready) {
+      const bool fold = ss_out != nullptr && x2 == nullptr;
+      if (folded) *folded = fold;
       return groupnorm_apply_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, HW, m->cfg.norm_num_groups,
                                     n.g, n.b, eps, silu, y.p, x1.stats, x1.sbin, x1.C, x1.nslab,
-                                    x2 ? x2->stats : nullptr, x2 ? x2->sbin : 0, x2 ? x2->nslab : 0, s, y8_scale, tot);
+                                    x2 ? x2->stats : nullptr, x2 ? x2->sbin : 0, x2 ? x2->nslab : 0, s, y8_scale, tot, fold ? ss_out : nullptr);
+    }
     return groupnorm_launch(x1.p, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, Bx, HW, m->cfg.norm_num_groups, n.g,
                             n.b, eps, silu, y.p, stats, s, y8_scale);
   }
@@ -890,8 +901,13 @@ struct UNetRun {
     Tensor xd = x;                 // the outer residual at full batch
     if (shared) xd = talloc(H, Wd, C);
     Bx = Bpre;
+    // the fused projection kernel applies this GroupNorm itself to the rows it loads (lnproj.hip: gn_ss) where the producer filed the
+    // statistics: the stand-alone pass (13 us, 21 MB read + 21 MB written per level-0 block) becomes a 640-float table per sample
+    float* gn_ss = nullptr;
+    bool gn_folded = false;
+    if (lnproj && gnfold_on() && HW % 128 == 0) gn_ss = (float*)m->arena.alloc(sizeof(float) * (size_t)Bx * 2 * C);
     if (pre && !shared) n = *pre;
-    else GILL_TRY(gnorm(x, nullptr, w.gn, 1e-6f, 0, n));
+    else GILL_TRY(gnorm(x, nullptr, w.gn, 1e-6f, 0, n, 0.f, gn_ss, &gn_folded));
     Bx = Bfull;
     Tensor t = talloc(H, Wd, C);   // transformer residual stream
     // norm1/2/3 never materialise: the GEMM that writes the residual stream also accumulates each row's sum and sum of
@@ -908,7 +924,7 @@ struct UNetRun {
     lp.M = M; lp.T = t.p; lp.heads = nh; lp.dp = w.dp; lp.dpv = w.dpv; lp.ntok = HW; lp.ntok_pad = hw_pad;
     lp.Cq = q; lp.Ck = k; lp.Cvt = vt; lp.qscale = 1.4426950408889634f / sqrtf((float)w.d);
     if (lnproj) {
-      lp.mode = 0; lp.X = n.p; lp.W1 = w.proj_in.w; lp.b1 = w.proj_in.b; lp.W2p = w.wqkv1p; lp.c2 = w.c_qkv1;
+      lp.mode = 0; lp.X = gn_folded ? x.p : n.p; lp.gn_ss = gn_folded ? gn_ss : nullptr; lp.W1 = w.proj_in.w; lp.b1 = w.proj_in.b; lp.W2p = w.wqkv1p; lp.c2 = w.c_qkv1;
       if (!dry) GILL_TRY(lnproj_launch(lp, s));
     } else {
       GemmArgs g;
@@ -928,7 +944,7 @@ struct UNetRun {
     {
     if (lnproj) {
       GILL_REQUIRE(!w.xg, "internal: the fused projection pairs and the two-GEMM cross-attention are alternatives");
-      lp.mode = 1; lp.X = o; lp.W1 = w.out1.w; lp.b1 = w.out1.b; lp.W2p = w.wq2p; lp.c2 = w.c_q2;
+      lp.mode = 1; lp.X = o; lp.gn_ss = nullptr; lp.W1 = w.out1.w; lp.b1 = w.out1.b; lp.W2p = w.wq2p; lp.c2 = w.c_q2;
       if (!dry) GILL_TRY(lnproj_launch(lp, s));
     } else {
     GILL_TRY(linear(o, hdp, nullptr, 0, hdp, M1, w.out1.w, w.out1.b, C, hdp, t.p, ACT_NONE, t.p, C, nullptr, &st2));
