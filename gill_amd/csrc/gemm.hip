@@ -512,6 +512,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
         }
       }
       // (the pointers of this stage were prepared during the previous MMA phase: only the DMA instructions here)
+      // (round 4: only the A rows' pieces here and the W rows' at the tail of the wave's MMA phase, behind its 40 MFMAs — to shorten the
+      // memory phase, the longer of the two by the cycle model: loop 477.7 -> 492.6 ms, A/B of two builds.  Not kept.)
       if (k + STAGES - 1 < nsteps) { issue_dma((k + STAGES - 1) % STAGES); ++issued; }
     };
     auto mma = [&](int k) {
