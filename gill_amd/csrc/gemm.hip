@@ -491,8 +491,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
     int issued = total_steps < STAGES - 1 ? total_steps : STAGES - 1;     // stages this wave has issued so far
     bf16x8 af[KK][MI];
     bf16x8 bfr[KK][NT];
-    auto landed = [&](int k) {         // own pieces of stage k have landed
-      if (k < nsteps) wait_vm((issued - 1 - k) * lw);
+    // own pieces of stage k have landed.  With a 3-deep ring at most ONE younger stage is in flight at that point, so the count is 0 or
+    // this wave's pieces per stage (AI + WI, or one fewer on the waves whose last W piece has no row group): immediates behind a
+    // two-way test — wait_vm()'s general switch is a chain of ~13 compare-and-branch pairs, twice per K step, at the END of group A's MMA phase
+    auto landed = [&](int k) {
+      if (k >= nsteps) return;
+      if (issued - 1 - k <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (w_last_ok) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + WI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + WI - 1) : "memory");
     };
     auto mem = [&](int k) {
       const int sb = k % STAGES;
