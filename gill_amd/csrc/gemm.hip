@@ -567,6 +567,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
     // wait for stage `flat` only: the up to STAGES - 2 younger stages (lw instructions each) stay in flight
     if constexpr (STAGES == 2) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if constexpr (STAGES == 3) {
+      // at most one younger stage in flight: 0 or this wave's pieces per stage, as immediates (see the ping-pong loop's landed())
+      if (total_steps - 1 - flat <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (w_last_ok) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + WI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + WI - 1) : "memory");
     } else {
       int ahead = total_steps - 1 - flat;
       if (ahead > STAGES - 2) ahead = STAGES - 2;
