@@ -523,6 +523,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       if (k + STAGES - 1 < nsteps) { issue_dma((k + STAGES - 1) % STAGES); ++issued; }
     };
     auto mma = [&](int k) {
+      // the K walk's pointer advance is straight-line code: it goes out BETWEEN the MFMAs (one scalar / vector instruction per MFMA: the
+      // matrix pipe paces the MFMAs at 16 cycles each, an in-order wave that issues them back to back and the bookkeeping behind them
+      // pays for the bookkeeping in full at the tail of the phase).  (Past the last issued stage the advanced pointers are never used.)
+      issue_post();
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
@@ -530,11 +534,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
-      // the K walk's bookkeeping (pointer advance, next segment's set-up) rides in the MMA phase, behind the MFMAs
-      if (k + STAGES - 1 < nsteps) {
-        issue_post();
-        if (k + STAGES < nsteps) issue_prepare();
+#pragma unroll
+      for (int q = 0; q < KK * MI * NT; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 1, 0);
       }
+      // ... the next segment's set-up (branches) behind them
+      if (k + STAGES < nsteps) issue_prepare();
     };
     if (STAGES - 1 < nsteps) issue_prepare();
     landed(0);
