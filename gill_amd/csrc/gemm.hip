@@ -171,6 +171,8 @@ __device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& 
 // launcher keeps KT = 64 unless GILL_GEMM_KT = 32).
 // MI: 16-row M sub-tiles per wave (4 | 2).  MI = 2 with NWV = 4 is a 64-row tile on FOUR waves (2 x 2, wave tile 32 x BN/2) for the
 // small plain GEMMs: the same 48 KiB of LDS as the 2-wave 64 x 128 tile (three workgroups per CU), twice the waves per CU.
+// PP_ABL (timing-only builds: tools/sessions/r04_x27.sh, profiles/r04_pingpong_ablations.md): bit 0 no fragment reads, 1 no LDS-DMA, 2 no MFMAs,
+// 3 no pointer bookkeeping in the ping-pong loop after its first K step
 template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT, int MI>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void gemm_kernel(const GemmDev d) {
   constexpr int BM = (NWV / 2) * MI * 16;
@@ -504,6 +506,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       const int sb = k % STAGES;
       const bf16_t* As = smem + sb * BUF_ELEMS;
       const bf16_t* Bs = As + A_ELEMS;
+#ifdef PP_ABL
+      if (!((PP_ABL & 1) && k > 0))
+#endif
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
@@ -520,13 +525,23 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       // (the pointers of this stage were prepared during the previous MMA phase: only the DMA instructions here)
       // (round 4: only the A rows' pieces here and the W rows' at the tail of the wave's MMA phase, behind its 40 MFMAs — to shorten the
       // memory phase, the longer of the two by the cycle model: loop 477.7 -> 492.6 ms, A/B of two builds.  Not kept.)
+#ifdef PP_ABL
+      if ((PP_ABL & 2) && k > 0) return;
+#endif
+      // (the pieces BEFORE the fragment reads instead of behind them: loop 448.6 -> 449.7 ms.  Not kept.)
       if (k + STAGES - 1 < nsteps) { issue_dma((k + STAGES - 1) % STAGES); ++issued; }
     };
     auto mma = [&](int k) {
       // the K walk's pointer advance is straight-line code: it goes out BETWEEN the MFMAs (one scalar / vector instruction per MFMA: the
       // matrix pipe paces the MFMAs at 16 cycles each, an in-order wave that issues them back to back and the bookkeeping behind them
       // pays for the bookkeeping in full at the tail of the phase).  (Past the last issued stage the advanced pointers are never used.)
+#ifdef PP_ABL
+      if (!((PP_ABL & 8) && k > 0))
+#endif
       issue_post();
+#ifdef PP_ABL
+      if (!((PP_ABL & 4) && k > 0))
+#endif
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
@@ -540,6 +555,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
         __builtin_amdgcn_sched_group_barrier(0x006, 1, 0);
       }
       // ... the next segment's set-up (branches) behind them
+#ifdef PP_ABL
+      if (!((PP_ABL & 8) && k > 0))
+#endif
       if (k + STAGES < nsteps) issue_prepare();
     };
     if (STAGES - 1 < nsteps) issue_prepare();
