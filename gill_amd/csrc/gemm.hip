@@ -171,6 +171,11 @@ __device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& 
 // launcher keeps KT = 64 unless GILL_GEMM_KT = 32).
 // MI: 16-row M sub-tiles per wave (4 | 2).  MI = 2 with NWV = 4 is a 64-row tile on FOUR waves (2 x 2, wave tile 32 x BN/2) for the
 // small plain GEMMs: the same 48 KiB of LDS as the 2-wave 64 x 128 tile (three workgroups per CU), twice the waves per CU.
+#if defined(PP_ABL) && (PP_ABL & 32)
+#define PP_BAR() do {} while (0)
+#else
+#define PP_BAR() __builtin_amdgcn_s_barrier()
+#endif
 // PP_ABL (timing-only builds: tools/sessions/r04_x27.sh, profiles/r04_pingpong_ablations.md): bit 0 no fragment reads, 1 no LDS-DMA, 2 no MFMAs,
 // 3 no pointer bookkeeping in the ping-pong loop after its first K step
 template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT, int MI>
@@ -567,11 +572,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       for (int k = 0; k < nsteps; ++k) {
         mem(k);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        PP_BAR();
         mma(k);
         landed(k + 1);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        PP_BAR();
       }
       __builtin_amdgcn_s_barrier();
     } else {
@@ -580,10 +585,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
         mem(k);
         landed(k + 1);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        PP_BAR();
         mma(k);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        PP_BAR();
       }
     }
   } else
@@ -653,6 +658,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
     }
   }
 
+#ifdef PP_ABL
+  if constexpr (PP) { if (PP_ABL & 16) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f; return; } }      // (bit 4: no epilogue)
+#endif
   // ---- epilogue.  acc[i][j][r]: m = m0 + wm*(MI*16) + i*16 + (lane&15); column: see tile_col() — sub-tiles (2g, 2g+1) of a lane
   // hold the 8 consecutive columns nbase + g*32 + fkc*8 .. +7 (registers r of sub-tile 2g, then of 2g+1); an unpaired last
   // sub-tile (NT odd) holds nbase + j*16 + fkc*4 .. +3
