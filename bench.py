@@ -23,13 +23,14 @@ import subprocess
 import sys
 import time
 
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before HIP initialises: see gill_amd/__init__.py
 
 import torch                      # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import gill_amd                   # noqa: E402
+gill_amd.configure_hip_runtime()  # entry point: opt in to the process-wide hipGraph setting before HIP initialises (see its docstring)
 
 UNET_TFLOP_PER_SAMPLE_FORWARD = 0.8032   # 401.6 GMAC, SD-1.5, 64x64 latents
 UNET_TFLOP_SD21_768 = 2.149              # 1074.6 GMAC, SD-2.1-768, 96x96 latents (--config c4)

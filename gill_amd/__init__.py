@@ -5,10 +5,24 @@ import os as _os
 
 __version__ = "0.1.0"
 
-# ROCm 7.2's hipGraph "packet capture" costs the captured denoise loop 1.2 % (469.0 vs 463.4 ms per 4-prompt loop: profiles/
-# r04_weight_prefetch.md) and was the mechanism behind round 1's mis-replayed memset nodes (profiles/r02_soak_bisect.md).  The runtime
-# reads the flag once, when HIP initialises: importing gill_amd before the first CUDA call makes it effective; later it is a no-op.
-_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+def configure_hip_runtime(warn: bool = True) -> bool:
+  """Opt-in process-wide ROCm runtime setting for the captured denoise loop; entry points (bench.py, tools/, tests) call it before
+  the first CUDA call, importing the package no longer touches os.environ.
+
+  ROCm 7.2's hipGraph "packet capture" costs the captured loop 1.2 % (469.0 vs 463.4 ms per 4-prompt loop: profiles/
+  r04_weight_prefetch.md) and was the mechanism behind round 1's mis-replayed memset nodes (profiles/r02_soak_bisect.md).  The runtime
+  reads DEBUG_CLR_GRAPH_PACKET_CAPTURE once, when HIP initialises.  Returns True if the setting can still take effect; if HIP is
+  already up in this process it cannot, and (unless the variable was already 0) a warning says so."""
+  already = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")
+  _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+  import sys
+  torch = sys.modules.get("torch")
+  late = torch is not None and torch.cuda.is_initialized()
+  if late and already is None and warn:
+    import warnings
+    warnings.warn("gill_amd.configure_hip_runtime(): HIP is already initialised in this process; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 "
+                  "cannot take effect (the captured denoise loop replays ~1.2 % slower)", RuntimeWarning, stacklevel=2)
+  return not late
 
 
 def install_as_gill() -> None:

@@ -1412,6 +1412,19 @@ int gemm_pick_splitk(int M, int N, int K, int act, bool plain, bool generic) {
       return s < 1 ? 1 : s;
     }
   }
+  // skinny weight-streaming GEMMs (OPT-6.7b at 4-8 prompts: M = 128 / 256 rows, 33-134 MB of weights per matrix).  Measured with
+  // tools/r05_probe.py (profiles/r05_opt_splitk.md): with >= 64 tiles of 160 columns (QKV N = 12288, fc1 N = 16384) the UNSPLIT launch streams
+  // at 3.3-4.3 TB/s and every split loses 20-45 % to its fp32 partials (7 x 128 x 12288 floats = 44 MB written and read back beside 100 MB of
+  // weights); the narrow ones (N = 4096: 26 tiles) want ~320 workgroups but no more partial bytes than a quarter of the weights
+  if (M <= 256 && !generic && act != ACT_GEGLU) {
+    if (tiles >= 64) return 1;
+    int s = (320 + tiles / 2) / tiles;
+    const int cap = K / (4 * M);
+    if (s > cap) s = cap;
+    if (s > ksteps / 4) s = ksteps / 4;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : s;
+  }
   // plain GEMMs with 150..383 128-row tiles run on 64-row tiles instead (gemm_launch: >= 300 workgroups, no partials):
   // measured 8192 x 640 x 3200 unsplit 49.1 us, two-way split + reducer 54.6 us
   if (plain && !generic && tiles >= 150 && tiles < 300 && M > 64) return 1;

@@ -428,7 +428,8 @@ struct Loader {
     *temb_off += cout;
     return 0;
   }
-  int xf(const std::string& p, int C, int H, int ctx_dim, int layer_id, XfW* x) {
+  // hw: tokens per sample at this layer (the softmax GEMM of the two-GEMM cross-attention runs on 64-row tiles of ONE sample)
+  int xf(const std::string& p, int C, int H, int ctx_dim, int layer_id, int hw, XfW* x) {
     x->C = C; x->heads = H; x->d = C / H; x->dp = attn_padded_dim(x->d); x->dpv = round_up(x->dp, 32); x->layer_id = layer_id;
     GILL_REQUIRE(x->dp > 0, "unsupported attention head dim");
     const int hdp = H * x->dp;
@@ -495,7 +496,9 @@ struct Loader {
     GILL_TRY(ln_fold_rows_launch(x->wq2, hdp, C, x->ln2.g, x->ln2.b, x->s_q2, x->c_q2, s));
     GILL_TRY(ln_fold_rows_launch(x->wff1, 8 * C, C, x->ln3.g, x->ln3.b, x->s_ff1, x->bff1, s));
     // cross-attention as two GEMMs: where the 80 key slots per head are no wider than the head itself (d >= 80: SD-1.5 levels 1-3)
-    if (xalg_on() && H % 2 == 0 && ctx_len <= 80 && 80 * H <= hdp && x->dp <= 160 && C % 64 == 0 && ctx_dim % 64 == 0) {
+    // ... and a sample is whole 64-row tiles (per-sample weights: a tile must not straddle samples — sample_size 32 / 96 have 16- / 144-token
+    // mid blocks); otherwise the layer keeps its K / V caches and the attention-kernel form
+    if (xalg_on() && H % 2 == 0 && ctx_len <= 80 && 80 * H <= hdp && x->dp <= 160 && C % 64 == 0 && ctx_dim % 64 == 0 && hw % 64 == 0) {
       GILL_TRY(pool.alloc(&x->xg, (size_t)2 * H * C * ctx_dim, false));
       GILL_TRY(pool.alloc(&x->xgb, (size_t)H * ctx_dim));
       const float qs = 1.4426950408889634f / sqrtf((float)x->d);
@@ -604,14 +607,14 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
     if (i < 3) {
       m->down_xf[i].resize(2);
       for (int j = 0; j < 2; ++j)
-        if ((rc = L.xf(p + ".attentions." + std::to_string(j), ch[i], Hl[i], ctxd, layer_id++, &m->down_xf[i][j]))) return fail(rc);
+        if ((rc = L.xf(p + ".attentions." + std::to_string(j), ch[i], Hl[i], ctxd, layer_id++, hw_of(i), &m->down_xf[i][j]))) return fail(rc);
       if ((rc = L.conv3(p + ".downsamplers.0.conv", ch[i], ch[i], hw_of(i), &m->down_ds[i]))) return fail(rc);
     }
   }
   // mid
   if ((rc = L.resnet("mid_block.resnets.0", ch[3], ch[3], hw_of(3), temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[0], f8)))
     return fail(rc);
-  if ((rc = L.xf("mid_block.attentions.0", ch[3], Hl[3], ctxd, layer_id++, &m->mid_xf))) return fail(rc);
+  if ((rc = L.xf("mid_block.attentions.0", ch[3], Hl[3], ctxd, layer_id++, hw_of(3), &m->mid_xf))) return fail(rc);
   if ((rc = L.resnet("mid_block.resnets.1", ch[3], ch[3], hw_of(3), temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[1], f8)))
     return fail(rc);
   // up blocks: UpBlock2D, CrossAttnUpBlock2D x3
@@ -631,7 +634,7 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
     if (i > 0) {
       m->up_xf[i].resize(3);
       for (int j = 0; j < 3; ++j)
-        if ((rc = L.xf(p + ".attentions." + std::to_string(j), outc, Hl[3 - i], ctxd, layer_id++, &m->up_xf[i][j]))) return fail(rc);
+        if ((rc = L.xf(p + ".attentions." + std::to_string(j), outc, Hl[3 - i], ctxd, layer_id++, hw_of(3 - i), &m->up_xf[i][j]))) return fail(rc);
     }
     if (i < 3)
       if ((rc = L.conv3(p + ".upsamplers.0.conv", outc, outc, hw_of(3 - i), &m->up_us[i], false, true))) return fail(rc);

@@ -12,8 +12,10 @@ def pytest_configure(config):
   config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
   # the CPU oracle runs on torch's CPU thread pool: size it to the cores this process may use (cgroup quota)
   import torch
+  import gill_amd
   from gill_amd.synth import host_cores
   torch.set_num_threads(host_cores())
+  gill_amd.configure_hip_runtime()   # the GPU tests replay captured graphs the way bench.py does (explicit opt-in since round 5)
 
 
 @pytest.fixture(scope="session")

@@ -157,6 +157,34 @@ def test_unet_reduced_width_many_groupnorm_partials_vs_oracle(cuda, sample_size)
   assert rell < 5e-2 and cosl > 0.995
 
 
+@SLOW
+@pytest.mark.parametrize("sample_size", [32])
+def test_sd15_full_width_small_latents_vs_oracle(cuda, sample_size):
+  """the two-GEMM cross-attention (XALG) was enabled from the head geometry alone, and its softmax GEMM runs on
+  64-row tiles of ONE sample (per-sample weights).  A full-width SD-1.5 UNet at sample_size 32 has a 4x4 = 16-token mid block (and
+  sample_size 96 a 144-token one): those layers must keep their K / V caches and the attention-kernel form.  One forward of batch 2 and
+  a 2-step CFG loop against the oracle."""
+  import dataclasses
+  from gill_amd.sd import GillSDPipeline
+  from oracle import pipeline_ref, unet_ref
+  cfg = dataclasses.replace(synth.UNetConfig.sd15(), sample_size=sample_size)
+  sd = _bfw(synth.unet_state_dict(cfg, seed=81))
+  uncond = synth.uncond_context(cfg.ctx_len, cfg.cross_attention_dim, seed=81).bfloat16().float()
+  pipe = GillSDPipeline(sd, cfg, uncond, cuda, max_batch=2)
+  x = synth.initial_latents(2, 4, sample_size, seed=8181)
+  ctx = torch.cat([uncond, synth.normal("sd15s_ctx", (1, 77, 768), 82)], 0).bfloat16().float()
+  t = torch.tensor([801.0, 801.0])
+  ref = unet_ref.unet_forward(sd, x, t, ctx, cfg.block_out_channels, cfg.num_heads, cfg.norm_num_groups)
+  got = pipe.unet(x, t, ctx)
+  _, rel, cos = _stats(f"SD-1.5 full-width forward at {sample_size}x{sample_size} latents", got, ref)
+  assert got.shape == ref.shape and rel < 5e-2 and cos > 0.998
+  lat0 = synth.initial_latents(1, 4, sample_size, seed=8282)
+  a = pipe(prompt_embeds=ctx[1:], latents=lat0, guidance_scale=7.5, num_inference_steps=2, output_type="latent").images
+  refl = pipeline_ref.denoise(sd, ctx[1:], uncond, lat0, 2, 7.5, cfg.block_out_channels, cfg.num_heads, cfg.norm_num_groups)
+  _, rell, cosl = _stats(f"SD-1.5 full-width 2-step CFG loop at {sample_size}x{sample_size} latents", a, refl)
+  assert rell < 5e-2 and cosl > 0.998
+
+
 def test_guidance_scale_is_not_baked_into_the_captured_step(cuda):
   """the guidance scale used to be part of the graph key (one captured hipGraphExec per value, never evicted).  It is
   a device-side scalar now: a sweep re-uses ONE captured step and every value still gives its own (oracle-checked) answer."""

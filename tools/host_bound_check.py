@@ -3,6 +3,8 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
+import gill_amd
+gill_amd.configure_hip_runtime()
 from gill_amd import synth
 from gill_amd.sd import GillSDPipeline
 

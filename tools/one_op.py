@@ -12,6 +12,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gill_amd
+gill_amd.configure_hip_runtime()
 from gill_amd import ops  # noqa: E402
 
 

@@ -2,6 +2,8 @@ import sys, time, torch
 sys.path.insert(0, "/root/repo")
 sys.argv = ["x"]
 import bench
+import gill_amd
+gill_amd.configure_hip_runtime()
 from gill_amd import synth
 from gill_amd.sd import GillSDPipeline
 dev = torch.device("cuda:0")
