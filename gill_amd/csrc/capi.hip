@@ -132,6 +132,38 @@ extern "C" int gill_op_conv3x3_gn(const void* x, const float* w_oihw, const floa
   return 0;
 }
 
+// The same convolution in Winograd F(2x2, 3x3) form (wino.hip): weight transform U = G g G^T, input transform V = B^T d B, the 16
+// position GEMMs as one 16-way split-K plain GEMM, A^T M A + epilogue in the split-K reducer — with the consuming GroupNorm (+ SiLU) when
+// gamma != NULL (then H * W in {64, 256} as for gill_op_conv3x3_gn; y_raw optional), else y_raw = conv(x) + bias + rowvec + resid.
+extern "C" int gill_op_conv3x3_wino(const void* x, const float* w_oihw, const float* bias, const float* rowvec, const void* resid,
+                                    const float* gamma, const float* beta, int groups, float eps, int silu, void* y_raw, void* y_norm, int B,
+                                    int H, int W, int Cin, int Cout, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GILL_REQUIRE(x && w_oihw && (y_raw || y_norm) && (gamma == nullptr || (beta && y_norm && groups > 0 && Cout % groups == 0)), "bad argument");
+  GILL_REQUIRE(gemm_wino_ok(B * H * W, Cout, Cin, H * W, W), "conv3x3_wino: unsupported geometry (odd map side, tiles % 128, Cout % 160, Cin % 64)");
+  DevBuf wu, v, ws;
+  GILL_TRY(wu.alloc(sizeof(bf16_t) * (size_t)Cout * 16 * Cin));
+  GILL_TRY(v.alloc(sizeof(bf16_t) * (size_t)4 * B * H * W * Cin));
+  GILL_TRY(ws.alloc(sizeof(float) * (size_t)4 * B * H * W * Cout));
+  GILL_TRY(wino_weight_transform_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wu.p, s));
+  GemmArgs g;
+  g.M = B * H * W; g.N = Cout; g.K = 16 * Cin; g.K1 = g.K; g.A = (const bf16_t*)v.p; g.lda = g.K;
+  g.W = (const bf16_t*)wu.p; g.bias = bias;
+  g.rowvec = rowvec; g.rows_per_batch = H * W; g.rowvec_bstride = Cout;
+  g.resid = resid; g.ldr = Cout; g.C = y_raw; g.ldc = Cout;
+  g.wino = 1; g.wino_W = W; g.splitk = 16; g.ws = (float*)ws.p;
+  if (gamma) {
+    g.fn_Y = (bf16_t*)y_norm; g.fn_gamma = gamma; g.fn_beta = beta; g.fn_eps = eps; g.fn_silu = silu; g.fn_cg = Cout / groups;
+    GILL_REQUIRE(gemm_fused_norm_ok(g), "conv3x3_wino: unsupported fused GroupNorm geometry (H * W in {64, 256}, Cout % 80 == 0, group width | 80)");
+  }
+  for (int r = 0; r < op_repeat(); ++r) {
+    GILL_TRY(wino_input_transform_launch((const bf16_t*)x, B, H, W, Cin, (bf16_t*)v.p, s));
+    GILL_TRY(gemm_launch(g, s));
+  }
+  GILL_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 // ResnetBlock2D's conv2 with the 1x1 conv_shortcut of the raw block input fused as extra K channels (the engine's c2f weights):
 // y = conv3x3(x1 ++ x2) + bias + conv1x1(xs1 ++ xs2), one implicit GEMM with K = 9 (C1 + C2) + CS1 + CS2.  For the operator tests.
 extern "C" int gill_op_conv3x3_shortcut(const void* x1, int C1, const void* x2, int C2, const float* w_oihw, const float* bias,

@@ -1091,8 +1091,33 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
 // Fused statistics are fixed-order like the in-kernel epilogue's: per-row / per-column cells in LDS written once each, then
 // one thread per output sum adds them in index order (row sums -> plane blockIdx.x of row_stats, bins -> this slab's
 // GroupNorm partial).
-template <int W, int R>
+// WINO (GemmArgs::wino): the 16 slices are the Winograd positions' planes [16][M / 4 tiles][N]; a thread row lane owns ONE tile (R = 4: its
+// four output pixels), sums A^T M A instead of the slices, and the rest of the epilogue runs on the pixels' rows.
+// A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]: Y[a][b] = sum_ij A^T[a][i] M[i][j] A^T[b][j]
+__device__ __forceinline__ void wino_out4(const float4 (&mp)[16], float4 (&y)[4]) {
+  float4 z0[4], z1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 a = mp[j], b = mp[4 + j], c = mp[8 + j], d = mp[12 + j];
+    z0[j] = make_float4(a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z, a.w + b.w + c.w);
+    z1[j] = make_float4(b.x - c.x - d.x, b.y - c.y - d.y, b.z - c.z - d.z, b.w - c.w - d.w);
+  }
+  y[0] = make_float4(z0[0].x + z0[1].x + z0[2].x, z0[0].y + z0[1].y + z0[2].y, z0[0].z + z0[1].z + z0[2].z, z0[0].w + z0[1].w + z0[2].w);
+  y[1] = make_float4(z0[1].x - z0[2].x - z0[3].x, z0[1].y - z0[2].y - z0[3].y, z0[1].z - z0[2].z - z0[3].z, z0[1].w - z0[2].w - z0[3].w);
+  y[2] = make_float4(z1[0].x + z1[1].x + z1[2].x, z1[0].y + z1[1].y + z1[2].y, z1[0].z + z1[1].z + z1[2].z, z1[0].w + z1[1].w + z1[2].w);
+  y[3] = make_float4(z1[1].x - z1[2].x - z1[3].x, z1[1].y - z1[2].y - z1[3].y, z1[1].z - z1[2].z - z1[3].z, z1[1].w - z1[2].w - z1[3].w);
+}
+// output row of pixel e = a * 2 + b of tile `tile` (tiles in (sample, ty, tx) order; rows_per_batch = H * W, wino_W = W)
+__device__ __forceinline__ int wino_row(const GemmArgs& p, int tile, int e) {
+  const int TW = p.wino_W >> 1;
+  const int tps = p.rows_per_batch >> 2;                 // tiles per sample
+  const int b = tile / tps, r = tile - b * tps;
+  const int ty = r / TW, tx = r - ty * TW;
+  return b * p.rows_per_batch + (2 * ty + (e >> 1)) * p.wino_W + 2 * tx + (e & 1);
+}
+template <int W, int R, bool WINO = false>
 __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArgs p) {
+  static_assert(!WINO || R == 4, "Winograd reducer: one tile (four pixels) per row lane");
   constexpr int QW = W / 4;                     // column quads per row
   constexpr int ROWS = 16 * R;                  // rows per block: 64 for large outputs, 16 when blocks would be too few
   __shared__ float2 rowp[ROWS][QW];               // per (row, quad) {sum, sum of squares} of the bf16-rounded outputs
@@ -1104,6 +1129,11 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
   float rsum[R], rsq[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) { rsum[r] = 0.f; rsq[r] = 0.f; }
+  // row of the thread's r-th value
+  auto row_of = [&](int r) -> int {
+    if constexpr (WINO) return wino_row(p, blockIdx.y * 16 + ty, r);
+    else return mbase + ty + 16 * r;
+  };
   if (n < p.N) {
     // all partial loads of the thread's 4 rows are issued before any epilogue store (a store in between would fence the
     // next row's loads): 4 rows x 4 splits = 16 independent 16-B loads in flight per pass
@@ -1116,9 +1146,21 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
       s[r] = make_float4(0, 0, 0, 0);
       src[r] = p.ws + (size_t)m * p.N + n;
     }
+    if constexpr (WINO) {
+      // the tile's 16 position planes (16 independent 16-B loads), A^T M A -> its four pixels
+      const size_t pstride = (size_t)(p.M >> 2) * p.N;
+      const float* tsrc = p.ws + (size_t)(blockIdx.y * 16 + ty) * p.N + n;
+      float4 mp[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) mp[q] = *reinterpret_cast<const float4*>(tsrc + (size_t)q * pstride);
+      float4 y4[4];
+      wino_out4(mp, y4);
+#pragma unroll
+      for (int r = 0; r < R; ++r) s[r] = y4[r & 3];
+    }
     const size_t zstride = (size_t)p.M * p.N;
     constexpr int U = 16 / R;        // slices per pass: 16 independent 16-B loads in flight per thread either way
-    int z = 0;
+    int z = WINO ? p.splitk : 0;
     for (; z + U <= p.splitk; z += U) {
       float4 v[R][U];
 #pragma unroll
@@ -1140,7 +1182,7 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
     const float4 cs = p.ln_stats ? *reinterpret_cast<const float4*>(p.ln_colsum + n) : make_float4(0, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int m = mbase + ty + 16 * r;
+      const int m = row_of(r);
       if (m >= p.M) continue;
       if (p.ln_stats) {
         float rr, rm;
@@ -1207,7 +1249,9 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
 // (+ SiLU) tensor: the GroupNorm-apply launch of that norm (5.5-7.5 us each, 24 per forward) and its read of the raw tensor disappear.
 // Also files the fused-statistics partials of the raw output (gn_stats: one slab = the whole sample) for a later two-source consumer.
 // RPT rows per thread: rows_per_batch = 16 * RPT (256 -> 16, 64 -> 4).  Block = W columns (80 | 40): W / 4 column quads x 16 row lanes.
-template <int RPT, int W>
+// WINO (GemmArgs::wino): the slices are the 16 Winograd position planes; the thread's RPT values are the 4 pixels of RPT / 4 tiles
+// (tile ty + 16 q of the sample, q = r / 4; pixel e = r % 4), everything after the reduction unchanged.
+template <int RPT, int W, bool WINO = false>
 __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_gn_kernel(const GemmArgs p) {
   constexpr int QW = W / 4, ROWS = 16 * RPT;
   __shared__ float2 part[16][QW];        // per (row lane, column quad) {sum, sum of squares} over the thread's rows
@@ -1220,6 +1264,34 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_gn_kernel(const Gemm
   // every global load of the block goes out before the first use: the partials of the first slices, the epilogue's vectors, the
   // residual rows, the norm's parameters — one memory round trip in front of the reduction, not four
   float4 v[RPT];
+  // row of the thread's r-th value
+  auto row_of = [&](int r) -> int {
+    if constexpr (WINO) return wino_row(p, b * (ROWS / 4) + ty + 16 * (r >> 2), r & 3);
+    else return mbase + ty + 16 * r;
+  };
+  float4 add = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
+  const float4 rv = p.rowvec ? *reinterpret_cast<const float4*>(p.rowvec + (size_t)b * p.rowvec_bstride + n) : make_float4(0, 0, 0, 0);
+  const float4 gam = *reinterpret_cast<const float4*>(p.fn_gamma + n), bet = *reinterpret_cast<const float4*>(p.fn_beta + n);
+  uint2 rr[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r)
+    rr[r] = p.resid ? *reinterpret_cast<const uint2*>((const bf16_t*)p.resid + (size_t)row_of(r) * p.ldr + n) : make_uint2(0u, 0u);
+  if constexpr (WINO) {
+    static_assert(!WINO || RPT % 4 == 0, "Winograd reducer: whole tiles per row lane");
+    // tile by tile: the 16 position planes of a tile (16 independent 16-B loads in flight), A^T M A -> its four pixels
+    const size_t pstride = (size_t)(p.M >> 2) * p.N;
+#pragma unroll
+    for (int q = 0; q < RPT / 4; ++q) {
+      const float* tsrc = p.ws + (size_t)(b * (ROWS / 4) + ty + 16 * q) * p.N + n;
+      float4 mp[16];
+#pragma unroll
+      for (int z = 0; z < 16; ++z) mp[z] = *reinterpret_cast<const float4*>(tsrc + (size_t)z * pstride);
+      float4 y4[4];
+      wino_out4(mp, y4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[q * 4 + e] = y4[e];
+    }
+  } else {
   const float* src = p.ws + (size_t)(mbase + ty) * p.N + n;
   const size_t zstride = (size_t)p.M * p.N, rstride = (size_t)16 * p.N;
 #pragma unroll
@@ -1227,13 +1299,6 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_gn_kernel(const Gemm
   float4 t1[RPT];
 #pragma unroll
   for (int r = 0; r < RPT; ++r) t1[r] = *reinterpret_cast<const float4*>(src + zstride + (size_t)r * rstride);      // (splitk >= 2)
-  float4 add = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
-  const float4 rv = p.rowvec ? *reinterpret_cast<const float4*>(p.rowvec + (size_t)b * p.rowvec_bstride + n) : make_float4(0, 0, 0, 0);
-  const float4 gam = *reinterpret_cast<const float4*>(p.fn_gamma + n), bet = *reinterpret_cast<const float4*>(p.fn_beta + n);
-  uint2 rr[RPT];
-#pragma unroll
-  for (int r = 0; r < RPT; ++r)
-    rr[r] = p.resid ? *reinterpret_cast<const uint2*>((const bf16_t*)p.resid + (size_t)(mbase + ty + 16 * r) * p.ldr + n) : make_uint2(0u, 0u);
 #pragma unroll
   for (int r = 0; r < RPT; ++r) { v[r].x += t1[r].x; v[r].y += t1[r].y; v[r].z += t1[r].z; v[r].w += t1[r].w; }
   for (int z = 2; z < p.splitk; ++z) {
@@ -1243,12 +1308,13 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_gn_kernel(const Gemm
 #pragma unroll
     for (int r = 0; r < RPT; ++r) { v[r].x += t[r].x; v[r].y += t[r].y; v[r].z += t[r].z; v[r].w += t[r].w; }
   }
+  }
   add.x += rv.x; add.y += rv.y; add.z += rv.z; add.w += rv.w;
   float ps = 0.f, pq = 0.f;
   uint2 raw[RPT];
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
-    const int m = mbase + ty + 16 * r;
+    const int m = row_of(r);
     v[r].x += add.x; v[r].y += add.y; v[r].z += add.z; v[r].w += add.w;
     v[r].x += bf2f((bf16_t)(rr[r].x & 0xffff)); v[r].y += bf2f((bf16_t)(rr[r].x >> 16));        // (zeros without a residual)
     v[r].z += bf2f((bf16_t)(rr[r].y & 0xffff)); v[r].w += bf2f((bf16_t)(rr[r].y >> 16));
@@ -1292,7 +1358,7 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_gn_kernel(const Gemm
   const float h0 = bet.x - g.x * s0, h1 = bet.y - g.x * s1, h2 = bet.z - g.x * s2, h3 = bet.w - g.x * s3;
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
-    const int m = mbase + ty + 16 * r;
+    const int m = row_of(r);
     // (the consumer of the unfused path reads the bf16 tensor: normalise the rounded values)
     float o0 = fmaf(bf2f((bf16_t)(raw[r].x & 0xffff)), s0, h0), o1 = fmaf(bf2f((bf16_t)(raw[r].x >> 16)), s1, h1);
     float o2 = fmaf(bf2f((bf16_t)(raw[r].y & 0xffff)), s2, h2), o3 = fmaf(bf2f((bf16_t)(raw[r].y >> 16)), s3, h3);
@@ -1368,6 +1434,7 @@ int gemm_row_planes(const GemmArgs& a) {
 }
 int gemm_gn_slab_rows(const GemmArgs& a) {
   if (a.splitk > 1 && a.fn_Y) return a.rows_per_batch;      // the fused reducer files one partial per (sample, bin)
+  if (a.wino) return 64;                                    // the Winograd reducer's blocks: 16 tiles = 64 pixels
   return a.splitk > 1 ? reduce_rows(a) : GN_SLAB_ROWS;
 }
 bool gemm_fused_gn_ok(int N, int cg) {
@@ -1440,8 +1507,36 @@ int gemm_pick_splitk(int M, int N, int K, int act, bool plain, bool generic) {
   return s;
 }
 
+bool gemm_wino_ok(int M, int N, int Cin, int rows_per_batch, int W) {
+  if (W <= 0 || W % 2 != 0 || rows_per_batch % W != 0 || (rows_per_batch / W) % 2 != 0) return false;
+  // whole samples, 16-tile reducer blocks inside one sample, the 128-row tiles of the split-K GEMM on the tile rows, whole K steps per position
+  return M > 0 && M % rows_per_batch == 0 && rows_per_batch % 64 == 0 && (M / 4) % 128 == 0 && N % 160 == 0 && Cin % 64 == 0 && 16 * Cin >= 2560;
+}
+
 int gemm_splitk_reduce_launch(const GemmArgs& a, hipStream_t s) {
   GILL_REQUIRE(a.splitk > 1 && a.ws != nullptr, "split-K reducer: no partials");
+  if (a.wino) {
+    GILL_REQUIRE(a.splitk == 16 && gemm_wino_ok(a.M, a.N, a.K / 16, a.rows_per_batch, a.wino_W) && !a.row_stats && !a.ln_stats && a.out_mode == OUT_BF16,
+                 "Winograd reducer: 16 position planes of a supported geometry, bf16 row-major epilogue");
+    if (a.fn_Y) {
+      GILL_REQUIRE(gemm_fused_norm_ok(a) && a.fn_gamma && a.fn_beta, "split-K reducer: unsupported fused GroupNorm geometry");
+      const int w = reduce_gn_width(a);
+      const dim3 rg(a.N / w, a.M / a.rows_per_batch);
+      if (a.rows_per_batch == 256 && w == 80) hipLaunchKernelGGL((gemm_splitk_reduce_gn_kernel<16, 80, true>), rg, dim3(320), 0, s, a);
+      else if (a.rows_per_batch == 256) hipLaunchKernelGGL((gemm_splitk_reduce_gn_kernel<16, 40, true>), rg, dim3(160), 0, s, a);
+      else if (w == 80) hipLaunchKernelGGL((gemm_splitk_reduce_gn_kernel<4, 80, true>), rg, dim3(320), 0, s, a);
+      else hipLaunchKernelGGL((gemm_splitk_reduce_gn_kernel<4, 40, true>), rg, dim3(160), 0, s, a);
+      GILL_CHECK_HIP(hipGetLastError());
+      return 0;
+    }
+    const int rw = reduce_width(a);
+    const dim3 rg(cdiv(a.N, rw), a.M / 64);
+    if (rw == 160) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<160, 4, true>), rg, dim3(640), 0, s, a);
+    else if (rw == 80) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<80, 4, true>), rg, dim3(320), 0, s, a);
+    else hipLaunchKernelGGL((gemm_splitk_reduce_kernel<64, 4, true>), rg, dim3(256), 0, s, a);
+    GILL_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   if (a.fn_Y) {
     GILL_REQUIRE(gemm_fused_norm_ok(a) && a.fn_gamma && a.fn_beta, "split-K reducer: unsupported fused GroupNorm geometry");
     const int w = reduce_gn_width(a);
@@ -1529,10 +1624,11 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   d.a.splitk = sk;
   GemmArgs red = d.a;       // what the split-K reducer sees: the output tensor, whatever the conv kernel's row space is
   // UPS4 (a.ups == 2): the kernel's rows are the SOURCE pixels of one parity class, blockIdx.z the class
+  // Winograd (a.wino): the kernel's rows are the 2 x 2 tiles (M / 4), blockIdx.y the transform position
   const int ncls = (a.conv && a.ups == 2) ? 4 : 1;
-  const int Mk = a.M / ncls;
+  const int Mk = a.M / ncls / (a.wino ? 4 : 1);
   d.a.M = Mk;
-  d.a.rows_per_batch = a.rows_per_batch / ncls;
+  d.a.rows_per_batch = a.rows_per_batch / ncls / (a.wino ? 4 : 1);
   d.tiles_n = cdiv(a.N, BN);
   // 64-row tiles for plain GEMMs whose 128-row tiling leaves CUs without a tile (GILL_GEMM_BM = 64 | 128 forces it: tools/soak.py)
   static const int forced_bm = env_int("GILL_GEMM_BM");
@@ -1564,7 +1660,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     // (loop 561.1 -> 558.0 ms; GILL_GEMM_PP128 = 0 keeps the 256-row tile with twice the split)
     if (pp128_on() && (int64_t)cdiv(Mk, 256) * ncls * d.tiles_n * sk <= 128 && Mk % 128 == 0) d.mi = 2;
   }
-  if (BN == 160 && !a.conv && gemm_plain_pingpong(a.M, a.N, a.K) && a.act == ACT_NONE && a.out_mode == OUT_BF16 && !a.resid_f32 && !a.wb_rows &&
+  if (BN == 160 && !a.conv && gemm_plain_pingpong(Mk, a.N, a.K) && a.act == ACT_NONE && a.out_mode == OUT_BF16 && !a.resid_f32 && !a.wb_rows &&
       !a.ln_stats && forced_bm == 0) {
     d.nwv = 8; d.mi = 4;
     if (((int64_t)cdiv(Mk, 256) * d.tiles_n * sk <= 128 && pp128_on()) || Mk % 256 != 0) d.mi = 2;
@@ -1674,6 +1770,12 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   }
   GILL_REQUIRE(a.fn_Y == nullptr || (a.splitk > 1 && gemm_fused_norm_ok(a)), "fused GroupNorm output: split-K GEMMs of a supported geometry only");
   GILL_REQUIRE(a.C != nullptr || a.fn_Y != nullptr || a.out_mode == OUT_QKV, "no output tensor");
+  if (a.wino) {
+    GILL_REQUIRE(!a.conv && a.splitk == 16 && a.K % 16 == 0 && a.K1 == a.K && a.lda == a.K && gemm_wino_ok(a.M, a.N, a.K / 16, a.rows_per_batch, a.wino_W),
+                 "Winograd GEMM: 16-way split of K = 16 Cin over V [tiles][16][Cin] of a supported geometry");
+    GILL_REQUIRE(a.out_mode == OUT_BF16 && a.act == ACT_NONE && !a.resid_f32 && !a.row_stats && !a.ln_stats && !a.wb_rows && a.alpha == 1.f,
+                 "Winograd GEMM: bf16 row-major epilogue only");
+  }
   if (a.splitk > 1) {
     GILL_REQUIRE(a.ws != nullptr, "split-K workspace missing");
     GILL_REQUIRE(a.act != ACT_GEGLU, "split-K cannot be combined with GEGLU");

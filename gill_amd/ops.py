@@ -95,6 +95,26 @@ def conv3x3_gn(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tenso
   return y_raw, y_norm
 
 
+def conv3x3_wino(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None,
+                 resid: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
+                 groups: int = 32, eps: float = 1e-5, silu: bool = True, want_raw: bool = True):
+  """Stride-1 3x3 convolution in Winograd F(2x2, 3x3) form (csrc/wino.hip).  x (B,H,W,Cin) bf16 NHWC, rowvec (B,Cout) fp32.
+  gamma is None: returns y = conv + bias + rowvec + resid.  Else returns (y_raw or None, y_norm) like conv3x3_gn."""
+  x = _bf(x)
+  B, H, W, Cin = x.shape
+  Cout = w_oihw.shape[0]
+  nan = float("nan")
+  fused = gamma is not None
+  y_raw = torch.full((B, H, W, Cout), nan, device=x.device, dtype=torch.bfloat16) if (want_raw or not fused) else None
+  y_norm = torch.full((B, H, W, Cout), nan, device=x.device, dtype=torch.bfloat16) if fused else None
+  f = lambda t: None if t is None else t.float().contiguous()   # noqa: E731
+  w, bias, rowvec, gamma, beta = f(w_oihw), f(bias), f(rowvec), f(gamma), f(beta)
+  resid = None if resid is None else _bf(resid)
+  N.check(N.lib().gill_op_conv3x3_wino(N.ptr(x), N.ptr(w), N.ptr(bias), N.ptr(rowvec), N.ptr(resid), N.ptr(gamma), N.ptr(beta), groups,
+                                       float(eps), int(silu), N.ptr(y_raw), N.ptr(y_norm), B, H, W, Cin, Cout, N.current_stream()))
+  return (y_raw, y_norm) if fused else y_raw
+
+
 def conv3x3_shortcut(x1: torch.Tensor, w_oihw: torch.Tensor, xs1: torch.Tensor, w_sc: torch.Tensor, bias: Optional[torch.Tensor] = None,
                      x2: Optional[torch.Tensor] = None, xs2: Optional[torch.Tensor] = None, splitk: int = 0) -> torch.Tensor:
   """conv3x3(x1 ++ x2, w_oihw) + bias + conv1x1(xs1 ++ xs2, w_sc) as one implicit GEMM (ResnetBlock2D conv2 + conv_shortcut)."""

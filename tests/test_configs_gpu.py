@@ -247,7 +247,11 @@ def test_bench_eight_ranks_uneven_shards_gloo(cuda):
 _SWITCH_DEFAULT_OUT = {}
 
 
-@pytest.mark.parametrize("switch", ["GILL_UNET_FFN_FUSED", "GILL_UNET_LNPROJ", "GILL_UNET_FFN_PRE", "GILL_ATT_DMA", "GILL_GEMM_RED_GN", "GILL_UNET_XALG", "GILL_UNET_GNFOLD"])
+_SWITCH_OPT_IN = {"GILL_UNET_WINO"}      # default off (every other switch defaults to on)
+
+
+@pytest.mark.parametrize("switch", ["GILL_UNET_FFN_FUSED", "GILL_UNET_LNPROJ", "GILL_UNET_FFN_PRE", "GILL_ATT_DMA", "GILL_GEMM_RED_GN", "GILL_UNET_XALG", "GILL_UNET_GNFOLD",
+                                    "GILL_UNET_WINO"])
 def test_fused_block_switches_full_size_forward(cuda, switch):
   """GILL_UNET_FFN_FUSED / GILL_UNET_LNPROJ / GILL_ATT_DMA (the level-0 attention on the LDS-DMA kernel, default, or on the register-staged
   one) / GILL_GEMM_RED_GN (levels 2-3: GroupNorm-apply inside the split-K reducer of its producer, default, or as its own launch; all read
@@ -256,7 +260,8 @@ def test_fused_block_switches_full_size_forward(cuda, switch):
   kernel (default) and as GEGLU + the two-source GEMM — resp. with the projection pairs around norm1 / norm2 as one kernel each (lnproj.hip,
   default) and as separate GEMMs — in two subprocesses on the same seeded weights.  Both forms have their oracle
   tests (the default one in every full-size test of this file); here they must agree with each other to the distance either has from
-  the oracle."""
+  the oracle.  GILL_UNET_WINO (opt-in, default off): the six level-2 stride-1 convolutions without a fused shortcut in Winograd F(2x2, 3x3) form
+  (wino.hip; operator parity: test_conv3x3_winograd_vs_torch)."""
   import tempfile
   code = ("import torch, sys; sys.path.insert(0, %r); from gill_amd import synth; from gill_amd.sd import GillSDPipeline\n"
           "cfg = synth.UNetConfig.sd15()\n"
@@ -267,8 +272,9 @@ def test_fused_block_switches_full_size_forward(cuda, switch):
           "torch.save(y, sys.argv[1])\n") % ROOT
   outs = []
   with tempfile.TemporaryDirectory() as d:
+    dflt = "0" if switch in _SWITCH_OPT_IN else "1"
     for sw in ("0", "1"):
-      if sw == "1" and "default" in _SWITCH_DEFAULT_OUT:      # every switch defaults to on: the all-defaults forward is run once
+      if sw == dflt and "default" in _SWITCH_DEFAULT_OUT:      # the all-defaults forward is run once
         outs.append(_SWITCH_DEFAULT_OUT["default"])
         continue
       f = os.path.join(d, f"y{sw}.pt")
@@ -276,7 +282,7 @@ def test_fused_block_switches_full_size_forward(cuda, switch):
                          timeout=900)
       assert r.returncode == 0, r.stderr[-2000:]
       outs.append(torch.load(f))
-      if sw == "1": _SWITCH_DEFAULT_OUT["default"] = outs[-1]
+      if sw == dflt: _SWITCH_DEFAULT_OUT["default"] = outs[-1]
   if switch == "GILL_UNET_GNFOLD":
     # the level-0 transformer blocks' GroupNorm applied by the projection kernel to the rows it loads, from the same scale / shift table
     # and with the same rounding as the stand-alone pass: not close — IDENTICAL

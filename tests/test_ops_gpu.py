@@ -358,6 +358,47 @@ def test_conv3x3_split_k_reducer_with_fused_groupnorm(cuda, B, H, W, Cin, Cout, 
     assert _report("  raw", y_raw.permute(0, 3, 1, 2), ref_raw) < 1.5e-2
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,fused,silu,resid,raw,rowvec", [
+  (2, 16, 16, 1280, 1280, True, True, False, False, True),    # UNet level 2: conv1 + time-embedding row -> norm2 (raw tensor not written)
+  (2, 16, 16, 2560, 1280, True, True, False, False, True),    # up block: concat input 2560 -> 1280
+  (2, 16, 16, 1280, 1280, True, False, True, True, False),    # conv2 + residual -> the transformer block's GroupNorm (no SiLU, eps 1e-6)
+  (2, 16, 16, 640, 1280, False, False, True, False, True),    # plain reducer (no fused norm): bias + row vector + residual
+  (8, 8, 8, 640, 640, False, False, False, False, False),     # 8 x 8 maps, 16 tiles per sample, plain reducer
+  (2, 32, 32, 640, 640, False, False, True, False, True),     # 32 x 32 maps (level 1 geometry), plain reducer
+])
+def test_conv3x3_winograd_vs_torch(cuda, B, H, W, Cin, Cout, fused, silu, resid, raw, rowvec):
+  """wino.hip: the stride-1 3x3 convolution as Winograd F(2x2, 3x3) — input / weight transforms, 16 position GEMMs as one 16-way split-K GEMM,
+  A^T M A + epilogue (+ the consuming GroupNorm) in the split-K reducer — against F.conv2d (+ F.group_norm) in fp32 on the same bf16
+  operands.  Bar as for the direct convolution (1.5e-2); the direct kernel measures ~3e-3 on these shapes, Winograd ~4-6e-3 (bf16 V and U)."""
+  from gill_amd import ops
+  x = _bf(_rnd((B, H, W, Cin), 190))
+  w = _rnd((Cout, Cin, 3, 3), 191, (9 * Cin) ** -0.5)
+  b = 0.1 * _rnd((Cout,), 192)
+  r = _bf(_rnd((B, H, W, Cout), 193)) if resid else None
+  rv = 0.3 * _rnd((B, Cout), 196) if rowvec else None
+  ref_raw = F.conv2d(x.float().permute(0, 3, 1, 2), _bf(w).float(), b, padding=1)
+  if rowvec:
+    ref_raw = ref_raw + rv.view(B, Cout, 1, 1)
+  if resid:
+    ref_raw = ref_raw + r.float().permute(0, 3, 1, 2)
+  dev = lambda t: None if t is None else t.to(cuda)   # noqa: E731
+  if not fused:
+    y = ops.conv3x3_wino(dev(x), dev(w), dev(b), dev(rv), dev(r))
+    assert torch.isfinite(y.float()).all()
+    assert _report(f"winograd conv B{B} {H}x{W} {Cin}->{Cout}", y.permute(0, 3, 1, 2), ref_raw) < 1.5e-2
+    return
+  gamma, beta = 1.0 + 0.2 * _rnd((Cout,), 194), 0.1 * _rnd((Cout,), 195)
+  eps = 1e-5 if silu else 1e-6
+  ref = F.group_norm(_bf(ref_raw).float(), 32, gamma, beta, eps)
+  if silu:
+    ref = F.silu(ref)
+  y_raw, y_norm = ops.conv3x3_wino(dev(x), dev(w), dev(b), dev(rv), dev(r), dev(gamma), dev(beta), 32, eps, silu, raw)
+  assert torch.isfinite(y_norm.float()).all()
+  assert _report(f"winograd conv+GN B{B} {H}x{W} {Cin}->{Cout}", y_norm.permute(0, 3, 1, 2), ref) < 1.5e-2
+  if raw:
+    assert _report("  raw", y_raw.permute(0, 3, 1, 2), ref_raw) < 1.5e-2
+
+
 # ---------------------------------------------------------------- norms
 @pytest.mark.parametrize("rows,C,f32", [(37, 512, True), (64, 4096, True), (300, 320, False), (16, 1280, False),
                                         (5, 768, True)])
