@@ -30,6 +30,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch import Tensor
 
 from . import _native as N
@@ -659,6 +660,50 @@ class GILL(nn.Module):
           return_outputs.append(utils.truncate_caption(caption) + f' {gen_prefix}')
           return_outputs.append(image_outputs)
     return return_outputs
+
+  @torch.no_grad()
+  def get_log_likelihood_scores(self, prompts: List) -> float:
+    """Log likelihood of an interleaved image / text prompt: minus the LM's mean next-token cross-entropy over the TEXT positions
+    (image positions carry the label -100 and are skipped, the <bos> tag is added once) — models.py:764-807, whose
+    `self.model.lm(inputs_embeds=..., labels=...)` is the OPT forward plus the tied lm_head and HF's shifted CrossEntropyLoss.
+    Here: hidden_states[-1] from gill_opt_forward, the lm_head rows of the T - 1 predicting positions through
+    gill_opt_last_logits (8 positions per call), and the log-softmax / mean on the (T - 1, vocab) fp32 host tensor."""
+    dev = self.model.logit_scale.device
+    embs, ids, first_text = [], [], True
+    for p in prompts:
+      if type(p) == str:
+        t = self.model.tokenizer(p, add_special_tokens=True, return_tensors="pt").input_ids.to(dev)
+        if not first_text:
+          t = t[:, 1:]          # <bos> only once
+        first_text = False
+        embs.append(self.model.input_embeddings(t))
+        ids.append(t)
+      elif type(p).__module__.startswith('PIL'):
+        px = utils.get_pixel_values_for_model(self.model.feature_extractor, p)
+        px = px.to(device=dev, dtype=self.model.logit_scale.dtype)[None, ...]
+        v = self.model.get_visual_embs(px, mode='captioning')
+        embs.append(v)
+        ids.append(torch.full(v.shape[:2], -100, dtype=torch.int64, device=dev))
+      else:
+        raise ValueError(f'Input prompts should be either PIL.Image.Image or str types, got {type(p)} instead.')
+    dt = next(e.dtype for e in embs)
+    x = torch.cat([e.to(dt) for e in embs], dim=1)
+    labels = torch.cat(ids, dim=1)[0, 1:].cpu()                  # position t predicts token t + 1
+    hidden = self.model._lm_forward_hidden(x)                      # (1, T, D) fp32, post final LayerNorm
+    T, D = hidden.shape[1], hidden.shape[2]
+    if T < 2 or bool((labels == -100).all()):
+      return float('nan')                                          # HF's mean over zero targets
+    vocab = self.model.opt_cfg.vocab_size
+    rows = hidden[0, :T - 1].contiguous()
+    logits = torch.empty((T - 1, vocab), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+      for r0 in range(0, T - 1, 8):
+        nb = min(8, T - 1 - r0)
+        # (nb, 1, D): every row is the "last position" of its own one-token sequence
+        N.check(N.lib().gill_opt_last_logits(self.model._opt_handle, N.ptr(rows[r0:r0 + nb]), nb, 1, N.ptr(logits[r0:r0 + nb]),
+                                             N.current_stream()))
+    loss = F.cross_entropy(logits.cpu(), labels, ignore_index=-100)
+    return -loss.item()
 
   @staticmethod
   def _scores(matrix: Tensor, query: Tensor) -> Tensor:
