@@ -560,7 +560,7 @@ static int attention_dma_launch(const AttnArgs& a, hipStream_t s) {
     GILL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_dma_kernel<DP, NTHR>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  static const int xcd_on = [] { const char* e = getenv("GILL_ATT_XCD"); return e ? atoi(e) : 1; }();
+  constexpr int xcd_on = 1;
   AttnArgs b = a;
   b.xcd_map = xcd_on;
   dim3 grid((xcd_on ? 8 * cdiv(a.H * a.B, 8) : a.H * a.B) * (a.nq / (NTHR / 2)), 1, 1);
@@ -582,7 +582,7 @@ static int attention_launch_inst(const AttnArgs& a, hipStream_t s) {
     GILL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel<DP, NTHR>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  static const int xcd_on = [] { const char* e = getenv("GILL_ATT_XCD"); return e ? atoi(e) : 1; }();
+  constexpr int xcd_on = 1;
   AttnArgs b = a;
   b.xcd_map = xcd_on;
   dim3 grid((xcd_on ? 8 * cdiv(a.H * a.B, 8) : a.H * a.B) * cdiv(a.nq, NTHR / 2), 1, 1);   // (XCD, pair slot, query tile): see the kernel's map

@@ -33,14 +33,21 @@ extern "C" int gill_op_gemm(const void* A, const void* W, const float* bias, con
   g.act = act;
   g.out_mode = out_f32 ? OUT_F32 : OUT_BF16;
   g.C = C; g.ldc = N;
-  g.splitk = splitk > 0 ? splitk : gemm_pick_splitk(M, N, K, act);
+  // weight-streaming shapes at a few hundred rows run the way the OPT engine runs them: on a 64 x 64-blocked copy of W (STREAM64)
+  DevBuf wblk;
+  if (M <= 256 && act != ACT_GEGLU && gemm_stream64_weights(N, K)) {
+    GILL_TRY(wblk.alloc(sizeof(bf16_t) * (size_t)N * K));
+    GILL_TRY(convert_to_bf16_blk64_launch(W, 0, N, K, (bf16_t*)wblk.p, s));
+    g.W = (const bf16_t*)wblk.p; g.w_blk64 = 1;
+  }
+  g.splitk = splitk > 0 ? splitk : (g.w_blk64 ? gemm_pick_splitk_blk64(M, N, K) : gemm_pick_splitk(M, N, K, act));
   DevBuf ws;
   if (g.splitk > 1) {
     GILL_TRY(ws.alloc(sizeof(float) * (size_t)g.splitk * M * N));
     g.ws = (float*)ws.p;
   }
   for (int r = 0; r < op_repeat(); ++r) GILL_TRY(gemm_launch(g, s));
-  if (g.splitk > 1) GILL_CHECK_HIP(hipStreamSynchronize(s));  // ws is freed on return
+  if (g.splitk > 1 || g.w_blk64) GILL_CHECK_HIP(hipStreamSynchronize(s));  // ws / the blocked copy are freed on return
   return 0;
 }
 

@@ -409,23 +409,6 @@ int dup_pair_launch(void* a, const void* b, void* b2, size_t bytes, hipStream_t 
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }
-// tools (unet.hip, GILL_UNET_TOUCH_W): one 4-byte read per 128-byte line pulls a byte range from HBM into the Infinity Cache
-__device__ unsigned int g_touch_sink;
-__global__ __launch_bounds__(256) void touch_bytes_kernel(const uint32_t* __restrict__ src, int64_t nlines) {
-  uint32_t acc = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nlines; i += (int64_t)gridDim.x * blockDim.x)
-    acc ^= __builtin_nontemporal_load(src + i * 32);
-  if (acc == 0x9E3779B9u && nlines < 0) g_touch_sink = acc;     // (never true: keeps the loads)
-}
-int touch_bytes_launch(const void* src, size_t bytes, int blocks, hipStream_t s) {
-  const int64_t nlines = (int64_t)(bytes / 128);
-  if (nlines == 0) return 0;
-  int64_t g = (nlines + 255) / 256;
-  if (g > blocks) g = blocks;
-  hipLaunchKernelGGL(touch_bytes_kernel, dim3((unsigned)g), dim3(256), 0, s, (const uint32_t*)src, nlines);
-  GILL_CHECK_HIP(hipGetLastError());
-  return 0;
-}
 int zero_bytes_launch(void* dst, size_t bytes, hipStream_t s) {
   GILL_REQUIRE(((uintptr_t)dst & 15) == 0 && (bytes & 15) == 0, "zero_bytes: 16-byte alignment required");
   if (bytes == 0) return 0;
@@ -530,6 +513,32 @@ int convert_to_bf16_launch(const void* src, int dtype, int64_t n, bf16_t* dst, h
 int convert_to_f32_launch(const void* src, int dtype, int64_t n, float* dst, hipStream_t s) {
   GILL_REQUIRE(dtype >= 0 && dtype <= 2, "unsupported source dtype");
   hipLaunchKernelGGL(convert_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dtype, n, dst);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+// [N][K] (any source dtype) -> bf16 [N / 64][K / 64][64][64]: the STREAM64 weight layout (gemm.hip).  One thread per 8 consecutive k: reads
+// 16-32 B, writes 16 B; a wave covers 8 rows x 128 B of one block.
+__global__ __launch_bounds__(256) void convert_bf16_blk64_kernel(const void* w, int dtype, int N, int K, bf16_t* out) {
+  const int64_t n8 = (int64_t)N * K / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = i * 8;                       // destination element index
+    const int64_t blk = o >> 12;
+    const int r = (int)((o >> 6) & 63), c = (int)(o & 63);
+    const int kb = (int)(blk % (K / 64));
+    const int nb = (int)(blk / (K / 64));
+    const int64_t src = ((int64_t)nb * 64 + r) * K + (int64_t)kb * 64 + c;
+    uint4 v;
+    v.x = pack_bf2(load_as_f32(w, dtype, src + 0), load_as_f32(w, dtype, src + 1));
+    v.y = pack_bf2(load_as_f32(w, dtype, src + 2), load_as_f32(w, dtype, src + 3));
+    v.z = pack_bf2(load_as_f32(w, dtype, src + 4), load_as_f32(w, dtype, src + 5));
+    v.w = pack_bf2(load_as_f32(w, dtype, src + 6), load_as_f32(w, dtype, src + 7));
+    *reinterpret_cast<uint4*>(out + o) = v;
+  }
+}
+int convert_to_bf16_blk64_launch(const void* src, int dtype, int N, int K, bf16_t* dst, hipStream_t s) {
+  GILL_REQUIRE(dtype >= 0 && dtype <= 2, "unsupported source dtype");
+  GILL_REQUIRE(N % 64 == 0 && K % 64 == 0, "64 x 64-blocked weights: N and K must be multiples of 64");
+  hipLaunchKernelGGL(convert_bf16_blk64_kernel, dim3(grid_for((int64_t)N * K / 8)), dim3(256), 0, s, src, dtype, N, K, dst);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -59,6 +59,7 @@ struct GemmDev {
   int kt;            // K elements per ring stage: 64 (2-deep ring) or 32 (4-deep ring, 128-row tiles only)
   int n_major;       // 1: consecutive tile ids walk M first (an XCD's contiguous id range = a range of N tiles over every M tile)
   int tiles_m;
+  int krot_mul = 0;  // STREAM64: workgroup t starts its K walk (t * krot_mul) % steps into its slice
 };
 
 __device__ __noinline__ float gelu_erf_call(float v) { return gelu_erf(v); }  // keeps erff out of the unrolled epilogue
@@ -171,13 +172,8 @@ __device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& 
 // launcher keeps KT = 64 unless GILL_GEMM_KT = 32).
 // MI: 16-row M sub-tiles per wave (4 | 2).  MI = 2 with NWV = 4 is a 64-row tile on FOUR waves (2 x 2, wave tile 32 x BN/2) for the
 // small plain GEMMs: the same 48 KiB of LDS as the 2-wave 64 x 128 tile (three workgroups per CU), twice the waves per CU.
-#if defined(PP_ABL) && (PP_ABL & 32)
-#define PP_BAR() do {} while (0)
-#else
-#define PP_BAR() __builtin_amdgcn_s_barrier()
-#endif
-// PP_ABL (timing-only builds: tools/sessions/r04_x27.sh, profiles/r04_pingpong_ablations.md): bit 0 no fragment reads, 1 no LDS-DMA, 2 no MFMAs,
-// 3 no pointer bookkeeping in the ping-pong loop after its first K step
+// (The timing-only ablation guards of round 4 — PP_ABL: no fragment reads / no LDS-DMA / no MFMAs / no bookkeeping / no epilogue / no barriers —
+// are gone from this file; their table is profiles/r04_pingpong_ablations.md, the bare loops live on in tools/ubench/gemm_loop.hip and gemm_ws.hip.)
 template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT, int MI>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void gemm_kernel(const GemmDev d) {
   constexpr int BM = (NWV / 2) * MI * 16;
@@ -186,6 +182,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
                 "MI = 2: the 4-wave 64-row plain tile, or the 128 x 160 ping-pong tile (8 waves of 32 x 80)");
   constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
   constexpr bool PP = (NWV == 8 && BN == 160 && STAGES == 3 && KT == 64);   // ping-pong main loop (see there)
+  // STREAM64 (host side: gemm_stream64_weights()): W is stored as [N / 64][K / 64][64 rows][64 k] — a K step's 64 x 64 weight tile is ONE
+  // contiguous 8 KiB run (whole DRAM pages) instead of 64 rows of 128 B at a stride of K — and is streamed with the non-temporal policy
+  constexpr bool WBLK = (BN == 64 && STAGES == 6 && CONV == 0);
   static_assert(KT == 64 || KT == 32, "stage depth");
   constexpr int LPR = KT / 8;          // lanes (16-B chunks) per tile row
   constexpr int RPI = 64 / LPR;        // tile rows one 1-KiB LDS-DMA wave-instruction covers (8 | 16)
@@ -315,6 +314,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
     }
     return half * (BN / 2) + c;
   };
+  // STREAM64: workgroup t starts its K walk krot steps into its slice and wraps (a fixed order per workgroup: still bit-repeatable).  All
+  // workgroups of a launch stream 8 KiB per K step from bases that are multiples of K * 128 B apart; walking in lockstep from the same offset
+  // they would knock on the same HBM channels at the same time (GILL_GEMM_KROT=0: every walk starts at its slice's first step)
+  int krot = 0;
+  if constexpr (WBLK) { if (d.krot_mul && nsteps > 0) krot = (int)(((unsigned)(tile / d.tiles_m) * (unsigned)d.krot_mul) % (unsigned)nsteps); }   // (M tiles of one N tile walk together: they share its weights in L2)
   const bf16_t* Wb = p.W + (p.wb_rows ? (size_t)(m0 / p.wb_rows) * (size_t)p.wb_stride : (size_t)0);     // per-sample weights (GemmArgs::wb_rows)
   auto w_setup = [&]() {
 #pragma unroll
@@ -322,7 +326,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       int row = tile_col((i * NWV + w) * RPI + srow);
       int n = n_issue + row;
       if (n > p.N - 1) n = p.N - 1;
-      w_ptr[i] = Wb + ((size_t)cls * p.N + n) * p.K + schunk * 8 + kt_beg * KT;
+      if constexpr (WBLK) w_ptr[i] = Wb + ((size_t)(n_issue / 64) * d.ksteps + kt_beg + krot) * 4096 + row * 64 + schunk * 8;
+      else w_ptr[i] = Wb + ((size_t)cls * p.N + n) * p.K + schunk * 8 + kt_beg * KT;
     }
   };
   w_setup();
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       }
     }
   };
-  int k_issue = kt_beg * KT;     // K coordinate of the next step to stage
+  int k_issue = (kt_beg + krot) * KT;     // K coordinate of the next step to stage
   int steps_in_tile = 0;
   // One stage = prepare (pointer set-up when the K walk enters a new N tile / (tap, source) segment) + dma (the LDS-DMA
   // instructions) + post (advance the walk).  The ping-pong loop runs the three in different phases.
@@ -401,6 +406,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       seg_left = 0;
       n_issue += BN;
       w_setup();
+    }
+    if constexpr (WBLK) {
+      if (k_issue == kt_end * KT) {      // wrap to the slice's first step
+        k_issue = kt_beg * KT;
+        seg_left = 0;
+#pragma unroll
+        for (int i = 0; i < WI; ++i) w_ptr[i] -= (size_t)nsteps * 4096;
+      }
     }
     if (seg_left == 0) seg_setup(k_issue);
   };
@@ -418,7 +431,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       if (i == WI - 1 && !w_last_ok) break;
       bf16_t* l = Bs + (i * NWV + w) * RPI * KT;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
-                                       (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)l, 16, 0, WBLK ? 2 : 0);     // (aux 2 = nt)
     }
   };
   auto issue_post = [&]() {
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
 #pragma unroll
     for (int i = 0; i < AI; ++i) a_ptr[i] += KT;
 #pragma unroll
-    for (int i = 0; i < WI; ++i) w_ptr[i] += KT;
+    for (int i = 0; i < WI; ++i) w_ptr[i] += WBLK ? 4096 : KT;
     k_issue += KT;
   };
   auto issue = [&](int buf) {
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
   const int frow = lane & 15;       // fragment row within a 16-row sub-tile
   const int fkc = lane >> 4;        // 16-B k chunk within the 32-wide MFMA k step
 
-  static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+  static_assert(STAGES >= 2 && STAGES <= 6, "ring depth");
   // s_waitcnt vmcnt(n) with a run-time n (its operand is an immediate): n = (stages still allowed in flight) * lw <= 15
   auto wait_vm = [](int n) {
     switch (n) {
@@ -457,6 +470,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
       case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
       case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+      case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+      case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // (waiting for more than needed is always correct)
     }
   };
@@ -511,9 +526,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       const int sb = k % STAGES;
       const bf16_t* As = smem + sb * BUF_ELEMS;
       const bf16_t* Bs = As + A_ELEMS;
-#ifdef PP_ABL
-      if (!((PP_ABL & 1) && k > 0))
-#endif
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
@@ -530,9 +542,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       // (the pointers of this stage were prepared during the previous MMA phase: only the DMA instructions here)
       // (round 4: only the A rows' pieces here and the W rows' at the tail of the wave's MMA phase, behind its 40 MFMAs — to shorten the
       // memory phase, the longer of the two by the cycle model: loop 477.7 -> 492.6 ms, A/B of two builds.  Not kept.)
-#ifdef PP_ABL
-      if ((PP_ABL & 2) && k > 0) return;
-#endif
       // (the pieces BEFORE the fragment reads instead of behind them: loop 448.6 -> 449.7 ms.  Not kept.)
       if (k + STAGES - 1 < nsteps) { issue_dma((k + STAGES - 1) % STAGES); ++issued; }
     };
@@ -540,13 +549,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       // the K walk's pointer advance is straight-line code: it goes out BETWEEN the MFMAs (one scalar / vector instruction per MFMA: the
       // matrix pipe paces the MFMAs at 16 cycles each, an in-order wave that issues them back to back and the bookkeeping behind them
       // pays for the bookkeeping in full at the tail of the phase).  (Past the last issued stage the advanced pointers are never used.)
-#ifdef PP_ABL
-      if (!((PP_ABL & 8) && k > 0))
-#endif
       issue_post();
-#ifdef PP_ABL
-      if (!((PP_ABL & 4) && k > 0))
-#endif
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
@@ -560,9 +563,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
         __builtin_amdgcn_sched_group_barrier(0x006, 1, 0);
       }
       // ... the next segment's set-up (branches) behind them
-#ifdef PP_ABL
-      if (!((PP_ABL & 8) && k > 0))
-#endif
       if (k + STAGES < nsteps) issue_prepare();
     };
     if (STAGES - 1 < nsteps) issue_prepare();
@@ -572,11 +572,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       for (int k = 0; k < nsteps; ++k) {
         mem(k);
         __builtin_amdgcn_sched_barrier(0);
-        PP_BAR();
+        __builtin_amdgcn_s_barrier();
         mma(k);
         landed(k + 1);
         __builtin_amdgcn_sched_barrier(0);
-        PP_BAR();
+        __builtin_amdgcn_s_barrier();
       }
       __builtin_amdgcn_s_barrier();
     } else {
@@ -585,10 +585,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
         mem(k);
         landed(k + 1);
         __builtin_amdgcn_sched_barrier(0);
-        PP_BAR();
+        __builtin_amdgcn_s_barrier();
         mma(k);
         __builtin_amdgcn_sched_barrier(0);
-        PP_BAR();
+        __builtin_amdgcn_s_barrier();
       }
     }
   } else
@@ -658,9 +658,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
     }
   }
 
-#ifdef PP_ABL
-  if constexpr (PP) { if (PP_ABL & 16) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f; return; } }      // (bit 4: no epilogue)
-#endif
   // ---- epilogue.  acc[i][j][r]: m = m0 + wm*(MI*16) + i*16 + (lane&15); column: see tile_col() — sub-tiles (2g, 2g+1) of a lane
   // hold the 8 consecutive columns nbase + g*32 + fkc*8 .. +7 (registers r of sub-tile 2g, then of 2g+1); an unpaired last
   // sub-tile (NT odd) holds nbase + j*16 + fkc*4 .. +3
@@ -1405,10 +1402,17 @@ static inline int reduce_rows(const GemmArgs& a) {
 }
 // Long-K plain GEMMs whose width tiles by 160 (the feed-forward output GEMMs of UNet levels 1-3: K = 5 C) run on the convolutions'
 // ping-pong kernel too: their 64 x 160 / 128 x 160 four-wave tiles fetch 22 / 14 KiB per MFLOP through a 64 B/clk L2 port, the 8-wave
-// tiles 14 / 10 (GILL_GEMM_PLAIN_PP = 0: the four-wave tiles)
+// tiles 14 / 10 (round 4 A/B: 57 -> 43 us at level 1, loop -0.5 %)
 static bool gemm_plain_pingpong(int M, int N, int K) {
-  static const int on = [] { const char* v = getenv("GILL_GEMM_PLAIN_PP"); return v ? atoi(v) : 1; }();
-  return on != 0 && N % 160 == 0 && M % 128 == 0 && K >= 2560 && K % 64 == 0;
+  return N % 160 == 0 && M % 128 == 0 && K >= 2560 && K % 64 == 0;
+}
+
+// ... and the launch's other conditions (tile_width() and gemm_launch_bn() used to test different things): the 8-wave plain kernel has
+// the lean bf16 row-major epilogue only
+static bool gemm_plain_pingpong_args(const GemmArgs& a) {
+  static const int forced_bm = env_int("GILL_GEMM_BM");
+  return !a.conv && gemm_plain_pingpong(a.M, a.N, a.K) && a.act == ACT_NONE && a.out_mode == OUT_BF16 && !a.resid_f32 && !a.wb_rows && !a.ln_stats &&
+         forced_bm == 0;
 }
 
 // Tile width.  Tried and removed (numbers in profiles/r02_big_tile.md, profiles/r01_sweep_gemm_tiles.md): a 256 x 256 8-wave tile for
@@ -1425,7 +1429,7 @@ static inline int tile_width(const GemmArgs& a) {
   // ... except on the 64-row tile (plain GEMMs with few tiles, see gemm_launch_bn): 64 x 128 needs 48 KiB of LDS, i.e. three
   // workgroups (six waves) per CU instead of two (four) — loop 587.3 -> 584.7 ms
   if (!a.conv && a.splitk <= 1 && a.N % 128 == 0 && !a.gn_stats && (int64_t)cdiv(a.M, 128) * cdiv(a.N, 160) < 300 && a.M > 64 && a.out_mode != OUT_SOFTMAX80 &&
-      !gemm_plain_pingpong(a.M, a.N, a.K)) bn = 128;
+      !gemm_plain_pingpong_args(a)) bn = 128;
   return bn;
 }
 int gemm_row_planes(const GemmArgs& a) {
@@ -1462,6 +1466,27 @@ bool conv_k_chunked(int HW, int Cin, int Cout) {
   static const int korder = [] { const char* v = getenv("GILL_CONV_KORDER"); return v ? atoi(v) : -1; }();
   if (korder >= 0) return korder != 0;
   return HW >= 4096 && (int64_t)HW * Cin * 2 > (int64_t)4 << 20 && !gemm_conv_pingpong(HW, Cout);
+}
+
+// STREAM64.  Weight-streaming GEMMs (a few hundred rows against 33-134 MB matrices: OPT-6.7b at <= 8 prompts) ran at 2.2-3 TB/s of weights on
+// the general tiles, whatever the ring depth (profiles/r05_opt_stream64.md: 128 x 64 tiles with a 6-deep ring streamed no faster than 64 x 128
+// tiles with a 3-deep one): a K step fetched 64-128 weight ROWS of 128 B each at a stride of 2 K bytes, i.e. one DRAM page activation per 128 B.
+// STREAM64 changes the layout, not only the tile: the matrix is stored at load time as [N / 64][K / 64][64][64] (gemm_stream64_weights() says
+// which matrices; convert_to_bf16_blk64_launch() writes them), so the 128 x 64 tile's weight stage is one contiguous 8 KiB run, a workgroup's
+// whole K walk one contiguous K * 128 B stream, fetched with the non-temporal policy (MI355X_MICROARCH "nt-weights") into a 6-deep ring
+// (144 KiB, one workgroup per CU, 40 KiB of weights + 80 KiB of L2-resident activations in flight per CU).  All rows of a <= 128-row problem
+// sit in the one M tile (every weight is read once); more rows = more M tiles next to each other on one XCD (n_major), sharing the L2.
+// No split for >= 160 workgroups; narrower matrices split K to ~256 workgroups.  GILL_GEMM_STREAM64=0: row-major weights, general tiles.
+bool gemm_stream64_weights(int N, int K) {
+  static const int on = [] { const char* v = getenv("GILL_GEMM_STREAM64"); return v ? atoi(v) : 1; }();
+  return on != 0 && N % 64 == 0 && K % 64 == 0 && K >= 1024 && (int64_t)N * K >= ((int64_t)4 << 20);
+}
+int gemm_pick_splitk_blk64(int M, int N, int K) {
+  const int tiles = cdiv(M, 128) * (N / 64), ksteps = K / BK;
+  if (tiles >= 160) return 1;
+  int s = (256 + tiles / 2) / tiles;
+  while (s > 1 && ksteps / s < 8) --s;
+  return s > 16 ? 16 : s;
 }
 
 int gemm_pick_splitk(int M, int N, int K, int act, bool plain, bool generic) {
@@ -1577,6 +1602,11 @@ static int gemm_launch_inst(const GemmDev& d, dim3 grid, hipStream_t s) {
 // d.nwv = 2 selects the 64-row tile (plain GEMMs, 2-deep ring, no split-K)
 template <int BN, int CONV, int EPI>
 static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
+  if constexpr (BN == 64) {
+    // STREAM64 (see gemm_stream64()): 128 x 64 tile, 6-deep ring = 144 KiB, one workgroup per CU
+    static_assert(CONV == 0 && (EPI == 0 || EPI == 2 || EPI == 3), "the 64-wide streaming tile: plain GEMMs, row-major / partial / QKV epilogues");
+    return gemm_launch_inst<4, 64, 0, EPI, 6>(d, grid, s);
+  } else {
   if constexpr (CONV == 0 && EPI != 2) {
     if (d.nwv == 2) return gemm_launch_inst<2, BN, CONV, EPI, 2>(d, grid, s);
   }
@@ -1601,9 +1631,7 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
     if (d.nwv == 4 && d.mi == 2) {
       // 64-row tile on four waves, 3-deep ring (72 KB: two workgroups per CU).  These grids are 1-2 workgroups per CU, so the ring depth IS
       // the number of K stages in flight on a CU, and a K step of these short-K GEMMs is one L2 round trip: 2-deep 487.3 ms, 3-deep
-      // 483.4 ms, 4-deep (one workgroup per CU) 496.1 ms on the loop.  GILL_GEMM_DEEP=2 restores the 2-deep ring.
-      static const int deep = env_int("GILL_GEMM_DEEP");
-      if (deep == 2) return gemm_launch_inst<4, BN, CONV, EPI, 2, BK, 2>(d, grid, s);
+      // 483.4 ms, 4-deep (one workgroup per CU) 496.1 ms on the loop.
       return gemm_launch_inst<4, BN, CONV, EPI, 3, BK, 2>(d, grid, s);
     }
   }
@@ -1612,6 +1640,7 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
     if (d.nwv == 8) return gemm_launch_inst<8, BN, CONV, EPI, 3>(d, grid, s);     // ping-pong 256 x 160 tile
   }
   return gemm_launch_inst<4, BN, CONV, EPI, 2>(d, grid, s);
+  }
 }
 
 template <int BN>
@@ -1660,8 +1689,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     // (loop 561.1 -> 558.0 ms; GILL_GEMM_PP128 = 0 keeps the 256-row tile with twice the split)
     if (pp128_on() && (int64_t)cdiv(Mk, 256) * ncls * d.tiles_n * sk <= 128 && Mk % 128 == 0) d.mi = 2;
   }
-  if (BN == 160 && !a.conv && gemm_plain_pingpong(Mk, a.N, a.K) && a.act == ACT_NONE && a.out_mode == OUT_BF16 && !a.resid_f32 && !a.wb_rows &&
-      !a.ln_stats && forced_bm == 0) {
+  if (BN == 160 && gemm_plain_pingpong_args(a)) {
     d.nwv = 8; d.mi = 4;
     if (((int64_t)cdiv(Mk, 256) * d.tiles_n * sk <= 128 && pp128_on()) || Mk % 256 != 0) d.mi = 2;
   }
@@ -1717,7 +1745,28 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     else if (a.act == ACT_NONE && a.out_mode == OUT_BF16 && !a.resid_f32) GILL_TRY((gemm_launch_stages<BN, 0, 4>(d, grid, s)));
     else GILL_TRY((gemm_launch_stages<BN, 0, 0>(d, grid, s)));
   }
-  if (sk > 1) return gemm_splitk_reduce_launch(red, s);
+  if (sk > 1 && !a.partials_only) return gemm_splitk_reduce_launch(red, s);
+  return 0;
+}
+
+static int gemm_launch_stream64(const GemmArgs& a, hipStream_t s) {
+  GemmDev d;
+  d.a = a;
+  d.zero = gill_zero_page();
+  GILL_REQUIRE(d.zero != nullptr, "zero page unavailable");
+  const int sk = a.splitk > 1 ? a.splitk : 1;
+  d.a.splitk = sk;
+  d.tiles_n = a.N / 64; d.tiles_m = cdiv(a.M, 128); d.npw = 1; d.groups_n = d.tiles_n; d.n_major = 1;
+  d.nwv = 4; d.mi = 4; d.kt = 64;
+  d.ksteps = a.K / 64;
+  d.ksteps_per_split = cdiv(d.ksteps, sk);
+  static const int krot = [] { const char* v = getenv("GILL_GEMM_KROT"); return v ? atoi(v) : 5; }();
+  d.krot_mul = krot;
+  const dim3 grid(d.tiles_n * d.tiles_m, sk, 1);
+  if (sk > 1) GILL_TRY((gemm_launch_stages<64, 0, 2>(d, grid, s)));
+  else if (a.out_mode == OUT_QKV) GILL_TRY((gemm_launch_stages<64, 0, 3>(d, grid, s)));
+  else GILL_TRY((gemm_launch_stages<64, 0, 0>(d, grid, s)));
+  if (sk > 1 && !a.partials_only) return gemm_splitk_reduce_launch(d.a, s);
   return 0;
 }
 
@@ -1788,6 +1837,12 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
     GILL_REQUIRE(a.N % 160 == 0 && a.splitk <= 1 && a.ln_stats && a.ln_colsum && a.bias && !a.conv && !a.gn_stats && !a.row_stats && a.C,
                  "softmax epilogue: N % 160 == 0, no split-K, folded-LayerNorm operands and a bias vector required");
   if (a.out_mode == OUT_QKV) GILL_REQUIRE(a.dp % 8 == 0 && a.heads > 0 && a.ntok > 0, "bad QKV scatter geometry (padded head dim must be a multiple of 8)");
+  if (a.w_blk64) {
+    GILL_REQUIRE(!a.conv && a.N % 64 == 0 && a.K1 == a.K && !a.gn_stats && !a.row_stats && !a.ln_stats && !a.wb_rows && !a.wino && !a.fn_Y &&
+                     a.act != ACT_GEGLU && a.out_mode != OUT_SOFTMAX80,
+                 "64 x 64-blocked weights (STREAM64): plain GEMMs with the row-major, QKV or split-K epilogue only");
+    return gemm_launch_stream64(a, s);
+  }
   const int bn = tile_width(a);
   if (bn == 160) return gemm_launch_bn<160>(a, s);
   return gemm_launch_bn<128>(a, s);

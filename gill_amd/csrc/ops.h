@@ -43,6 +43,8 @@ struct GemmArgs {
   int kv_tok_offset = 0;  // K / Vt rows land at token t + kv_tok_offset (appending to a KV cache); Q rows stay at t
   // split-K (0/1 = off).  ws must hold splitk*M*N floats.
   int splitk = 1; float* ws = nullptr;
+  int w_blk64 = 0;         // W is stored as [N / 64][K / 64][64][64] (convert_to_bf16_blk64_launch): the STREAM64 kernel, any M
+  int partials_only = 0;   // split-K: write the fp32 partials and stop — the caller runs its own reducer (opt.hip: reduce + residual + LayerNorm)
   // Both kinds of fused statistics are FIXED-ORDER: a producer writes each partial sum exactly once (no atomics, nothing to
   // zero), the consumer adds the partials in index order, so two runs of the same launch sequence are bit-identical.
   // fused GroupNorm statistics of the output: gn_stats[(b * nslab + slab) * gn_groups + g][2] = {sum, sum of squares} of the
@@ -92,7 +94,10 @@ int gemm_row_planes(const GemmArgs& a);
 // can a GEMM with N output columns produce fused GroupNorm statistics for bins of cg channels?
 bool gemm_fused_gn_ok(int N, int cg);
 // heuristic split-K factor for under-filled grids
-int gemm_pick_splitk(int M, int N, int K, int act, bool plain = false, bool generic = false);   // plain: not a conv (64-row tiles available);
+int gemm_pick_splitk(int M, int N, int K, int act, bool plain = false, bool generic = false);
+// STREAM64 (gemm.hip): which weight matrices are stored 64 x 64-blocked, and the split-K factor of a GEMM on one
+bool gemm_stream64_weights(int N, int K);
+int gemm_pick_splitk_blk64(int M, int N, int K);   // plain: not a conv (64-row tiles available);
                                                                                                // generic: 128-row 4-wave tiles only (the fp8 conv kernel): neither the 64-row nor the ping-pong rules
 
 // split-K reducer of gemm_launch on its own (partials a.ws [splitk][M][N] fp32 written by another kernel: conv_fp8.hip)
@@ -129,7 +134,7 @@ struct AttnArgs {
   int d = 0;            // the real head dim when known (0: not stated).  dp = 48 with d = 40: the kernel uses padding dim 40 (see QF)
   int causal = 0;
   int kv_bstride_zero = 0;  // 1: K/Vt have a single batch entry shared by every b (learned queries etc.)
-  int xcd_map = 1;          // 1: all query tiles of a (sample, head) on one XCD (set by the launcher; GILL_ATT_XCD=0 turns it off)
+  int xcd_map = 1;          // 1: all query tiles of a (sample, head) on one XCD (set by the launcher)
 };
 int attention_launch(const AttnArgs& a, hipStream_t s);
 
@@ -262,7 +267,6 @@ struct SdLoopArgs {
 // plain device-side fill / copy kernels for use INSIDE a captured forward: hipMemsetAsync / hipMemcpyAsync become memset /
 // memcpy graph nodes, whose replay was not reliable (profiles/r02_soak_bisect.md).  16-byte aligned pointers and sizes.
 int zero_bytes_launch(void* dst, size_t bytes, hipStream_t s);
-int touch_bytes_launch(const void* src, size_t bytes, int blocks, hipStream_t s);
 int copy_bytes_launch(void* dst, const void* src, size_t bytes, hipStream_t s);
 int dup_pair_launch(void* a, const void* b, void* b2, size_t bytes, hipStream_t s);   // a[bytes..] := a[0..bytes); b2[0..bytes) = b2[bytes..] := b[0..bytes)
 // first kernel of a step: latents -> UNet input (both CFG halves), time-embedding row of the current step -> temb_cur
@@ -281,6 +285,7 @@ bool conv_k_chunked(int HW, int Cin, int Cout);   // (GILL_CONV_KORDER = 0 | 1 f
 int conv_weight_relayout_ups4_launch(const void* w, int dtype, int Cout, int Cin, bf16_t* out /*[4][Cout][4][Cin]*/, hipStream_t s);   // GemmArgs::ups == 2
 int conv_weight_relayout_chunked_launch(const void* w, int dtype, int Cout, int Cin, bf16_t* out /*[Cout][Cin/64][9][64]*/, hipStream_t s);   // GemmArgs::conv
 int convert_to_bf16_launch(const void* src, int dtype, int64_t n, bf16_t* dst, hipStream_t s);
+int convert_to_bf16_blk64_launch(const void* src, int dtype, int N, int K, bf16_t* dst, hipStream_t s);   // -> [N / 64][K / 64][64][64] (STREAM64)
 int convert_to_f32_launch(const void* src, int dtype, int64_t n, float* dst, hipStream_t s);
 // copy rows of a [rows][cols] matrix into a (possibly wider/padded/permuted) destination:
 //   dst[dst_row_of(r)][0..cols) = src[r][0..cols)   with dst_row index list on device

@@ -15,6 +15,7 @@ struct OptLayer {
   bf16_t* w1 = nullptr; float* b1 = nullptr;
   bf16_t* w2 = nullptr; float* b2 = nullptr;
   float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+  int blk_qkv = 0, blk_o = 0, blk_1 = 0, blk_2 = 0;   // matrix stored 64 x 64-blocked (gemm_stream64_weights: the STREAM64 layout)
 };
 }  // namespace
 
@@ -58,6 +59,80 @@ __global__ __launch_bounds__(256) void opt_add_pos_kernel(const bf16_t* __restri
   }
 }
 
+// REDUCE + RESIDUAL + LAYERNORM.  The narrow GEMMs of a layer (out_proj, fc2: N = D) run split-K; their reducer is also the natural place
+// for the LayerNorm that follows them (the next sub-block's pre-LN): one workgroup per row adds the row's fp32 partials in split order, the
+// bias and the fp32 residual stream (the order of gemm.hip's reducer epilogue), stores the new stream row, and — the row being complete in its
+// registers — normalises it (two-pass variance like layernorm_kernel) into the bf16 operand of the next GEMM.  Two launches per layer gone
+// (the LayerNorm passes) and the stream row is not re-read.  Fixed summation order: bit-repeatable.
+template <int VPT>      // float4 vectors per thread: D <= 1024 * VPT
+__global__ __launch_bounds__(256) void opt_reduce_ln_kernel(const float* __restrict__ ws, int sk, int M, int D, const float* __restrict__ bias,
+                                                            float* __restrict__ h, const float* __restrict__ g, const float* __restrict__ b,
+                                                            bf16_t* __restrict__ nb, float eps) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, tid = threadIdx.x, nv = D >> 2;
+  const size_t slice = (size_t)M * D;
+  float4 v[VPT];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = (tid + i * 256) * 4;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid + i * 256 < nv) {
+      const float* p = ws + (size_t)row * D + c;
+      float4 a = *reinterpret_cast<const float4*>(p);
+      for (int z = 1; z < sk; ++z) {
+        const float4 q = *reinterpret_cast<const float4*>(p + (size_t)z * slice);
+        a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+      }
+      const float4 bb = *reinterpret_cast<const float4*>(bias + c);
+      const float4 r = *reinterpret_cast<const float4*>(h + (size_t)row * D + c);
+      a.x = a.x + bb.x + r.x; a.y = a.y + bb.y + r.y; a.z = a.z + bb.z + r.z; a.w = a.w + bb.w + r.w;
+      *reinterpret_cast<float4*>(h + (size_t)row * D + c) = a;
+      v[i] = a;
+    }
+  }
+  auto block_sum = [&](float x) -> float {      // fixed order: lanes (xor tree), then the four waves in index order
+    x = wave_sum(x);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = x;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = block_sum(s) / (float)D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    if (tid + i * 256 < nv) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      ss += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float rstd = rsqrtf(block_sum(ss) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = (tid + i * 256) * 4;
+    if (tid + i * 256 < nv) {
+      const float4 gg = *reinterpret_cast<const float4*>(g + c);
+      const float4 be = *reinterpret_cast<const float4*>(b + c);
+      uint2 o;
+      o.x = pack_bf2((v[i].x - mean) * rstd * gg.x + be.x, (v[i].y - mean) * rstd * gg.y + be.y);
+      o.y = pack_bf2((v[i].z - mean) * rstd * gg.z + be.z, (v[i].w - mean) * rstd * gg.w + be.w);
+      *reinterpret_cast<uint2*>(nb + (size_t)row * D + c) = o;
+    }
+  }
+}
+static int opt_reduce_ln_launch(const float* ws, int sk, int M, int D, const float* bias, float* h, const float* g, const float* b, bf16_t* nb,
+                                float eps, hipStream_t s) {
+  GILL_REQUIRE(D % 4 == 0 && D <= 8192 && sk >= 1, "reduce + LayerNorm: D must be a multiple of 4, at most 8192");
+  if (D <= 1024) hipLaunchKernelGGL((opt_reduce_ln_kernel<1>), dim3(M), dim3(256), 0, s, ws, sk, M, D, bias, h, g, b, nb, eps);
+  else if (D <= 4096) hipLaunchKernelGGL((opt_reduce_ln_kernel<4>), dim3(M), dim3(256), 0, s, ws, sk, M, D, bias, h, g, b, nb, eps);
+  else hipLaunchKernelGGL((opt_reduce_ln_kernel<8>), dim3(M), dim3(256), 0, s, ws, sk, M, D, bias, h, g, b, nb, eps);
+  GILL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int gill_opt_create(gill_opt** out, const gill_opt_config* cfg, const gill_tensor* weights, int n_weights) {
   GILL_REQUIRE(out && cfg && weights, "null argument");
   const int D = cfg->hidden_size, F = cfg->ffn_dim, H = cfg->num_heads;
@@ -90,18 +165,29 @@ extern "C" int gill_opt_create(gill_opt** out, const gill_opt_config* cfg, const
     if ((rc = m->pool.alloc(&L.wqkv, (size_t)3 * D * D, false))) return fail(rc);
     if ((rc = m->pool.alloc(&L.bqkv, (size_t)3 * D, false))) return fail(rc);
     const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+    L.blk_qkv = gemm_stream64_weights(3 * D, D); L.blk_o = gemm_stream64_weights(D, D);
+    L.blk_1 = gemm_stream64_weights(F, D); L.blk_2 = gemm_stream64_weights(D, F);
+    // (blocked or row-major, a [D][D] third of the stacked q | k | v matrix is a contiguous range of whole 64-row blocks)
+    auto load_w = [&](const std::string& name, int N, int K, int blk, bf16_t* dst) -> int {
+      const gill_tensor* t;
+      int r = wt.get(name, (int64_t)N * K, &t);
+      if (r) return r;
+      return blk ? convert_to_bf16_blk64_launch(t->data, t->dtype, N, K, dst, s) : convert_to_bf16_launch(t->data, t->dtype, (int64_t)N * K, dst, s);
+    };
     for (int j = 0; j < 3; ++j) {
       const gill_tensor* t;
-      if ((rc = wt.get(p + "self_attn." + names[j] + ".weight", (int64_t)D * D, &t))) return fail(rc);
-      if ((rc = convert_to_bf16_launch(t->data, t->dtype, (int64_t)D * D, L.wqkv + (size_t)j * D * D, s))) return fail(rc);
+      if ((rc = load_w(p + "self_attn." + names[j] + ".weight", D, D, L.blk_qkv, L.wqkv + (size_t)j * D * D))) return fail(rc);
       if ((rc = wt.get(p + "self_attn." + names[j] + ".bias", D, &t))) return fail(rc);
       if ((rc = convert_to_f32_launch(t->data, t->dtype, D, L.bqkv + (size_t)j * D, s))) return fail(rc);
     }
-    if ((rc = load_bf16(wt, m->pool, p + "self_attn.out_proj.weight", (int64_t)D * D, &L.wo, s))) return fail(rc);
+    if ((rc = m->pool.alloc(&L.wo, (size_t)D * D, false))) return fail(rc);
+    if ((rc = m->pool.alloc(&L.w1, (size_t)F * D, false))) return fail(rc);
+    if ((rc = m->pool.alloc(&L.w2, (size_t)D * F, false))) return fail(rc);
+    if ((rc = load_w(p + "self_attn.out_proj.weight", D, D, L.blk_o, L.wo))) return fail(rc);
+    if ((rc = load_w(p + "fc1.weight", F, D, L.blk_1, L.w1))) return fail(rc);
+    if ((rc = load_w(p + "fc2.weight", D, F, L.blk_2, L.w2))) return fail(rc);
     if ((rc = load_f32(wt, m->pool, p + "self_attn.out_proj.bias", D, &L.bo, s))) return fail(rc);
-    if ((rc = load_bf16(wt, m->pool, p + "fc1.weight", (int64_t)F * D, &L.w1, s))) return fail(rc);
     if ((rc = load_f32(wt, m->pool, p + "fc1.bias", F, &L.b1, s))) return fail(rc);
-    if ((rc = load_bf16(wt, m->pool, p + "fc2.weight", (int64_t)D * F, &L.w2, s))) return fail(rc);
     if ((rc = load_f32(wt, m->pool, p + "fc2.bias", D, &L.b2, s))) return fail(rc);
     if ((rc = load_f32(wt, m->pool, p + "self_attn_layer_norm.weight", D, &L.ln1g, s))) return fail(rc);
     if ((rc = load_f32(wt, m->pool, p + "self_attn_layer_norm.bias", D, &L.ln1b, s))) return fail(rc);
@@ -143,16 +229,27 @@ namespace {
 struct OptRun {
   gill_opt* m;
   hipStream_t s;
-  int linear(const bf16_t* A, int M, const bf16_t* W, const float* b, int N, int K, const float* resid, int act, void* out,
-             bool out_f32) {
+  // ln_g / ln_b / ln_out: the LayerNorm that consumes the result (in-place residual GEMMs into the fp32 stream only: out == resid, N == D).
+  // Split-K launches hand it to the reducer (opt_reduce_ln_kernel); unsplit ones run the stand-alone pass.
+  int linear(const bf16_t* A, int M, const bf16_t* W, int blk, const float* b, int N, int K, const float* resid, int act, void* out,
+             bool out_f32, const float* ln_g = nullptr, const float* ln_b = nullptr, bf16_t* ln_out = nullptr) {
+    static const int fuse = [] { const char* v = getenv("GILL_OPT_REDUCE_LN"); return v ? atoi(v) : 1; }();
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.K1 = K; g.A = A; g.lda = K; g.W = W; g.bias = b;
     g.resid = resid; g.ldr = N; g.resid_f32 = 1;
     g.act = act; g.out_mode = out_f32 ? OUT_F32 : OUT_BF16; g.C = out; g.ldc = N;
-    g.splitk = gemm_pick_splitk(M, N, K, act);
+    g.w_blk64 = blk;
+    g.splitk = blk ? gemm_pick_splitk_blk64(M, N, K) : gemm_pick_splitk(M, N, K, act);
     if ((size_t)g.splitk * M * N > m->splitk_ws_floats) g.splitk = 1;
     g.ws = m->splitk_ws;
-    return gemm_launch(g, s);
+    if (ln_out && fuse && g.splitk > 1 && out_f32 && resid == (const float*)out && act == ACT_NONE && b && N % 4 == 0 && N <= 8192) {
+      g.partials_only = 1;
+      GILL_TRY(gemm_launch(g, s));
+      return opt_reduce_ln_launch(m->splitk_ws, g.splitk, M, N, b, (float*)out, ln_g, ln_b, ln_out, 1e-5f, s);
+    }
+    GILL_TRY(gemm_launch(g, s));
+    if (ln_out) GILL_TRY(layernorm_launch(out, 1, ln_g, ln_b, ln_out, M, N, 1e-5f, s));
+    return 0;
   }
   // layers over the fp32 stream m->h (B*T rows).  past < 0: plain causal forward over T tokens.  past >= 0: the T rows are
   // the tokens past .. past+T-1 of each sequence; their K/V are appended to the handle's cache and they attend to it.
@@ -163,11 +260,14 @@ struct OptRun {
     const bool cached = past >= 0;
     const int kvpad = cached ? m->cache_tcap : Tpad;
     int li = 0;
+    const int nl = (int)m->layers.size();
     for (const OptLayer& L : m->layers) {
       bf16_t* kbuf = cached ? m->kcache[li] : m->k;
       bf16_t* vbuf = cached ? m->vcache[li] : m->vt;
+      const OptLayer* next = li + 1 < nl ? &m->layers[li + 1] : nullptr;
       ++li;
-      GILL_TRY(layernorm_launch(m->h, 1, L.ln1g, L.ln1b, m->nbuf, R, D, 1e-5f, s));
+      // (layers past the first: the previous layer's fc2 launch has normalised the stream into nbuf already)
+      if (li == 1) GILL_TRY(layernorm_launch(m->h, 1, L.ln1g, L.ln1b, m->nbuf, R, D, 1e-5f, s));
       {
         GemmArgs g;
         g.M = R; g.N = 3 * D; g.K = D; g.K1 = D; g.A = m->nbuf; g.lda = D; g.W = L.wqkv; g.bias = L.bqkv;
@@ -175,7 +275,8 @@ struct OptRun {
         g.heads = c.num_heads; g.dp = m->dp; g.dpv = m->dpv; g.ntok = T; g.ntok_pad_q = Tpad; g.ntok_pad_kv = kvpad;
         g.seg_base = 0; g.kv_tok_offset = cached ? past : 0;
         g.qscale = 1.4426950408889634f / sqrtf((float)m->dp);   // HF scales q by head_dim^-0.5
-        g.splitk = gemm_pick_splitk(R, 3 * D, D, 0);
+        g.w_blk64 = L.blk_qkv;
+        g.splitk = L.blk_qkv ? gemm_pick_splitk_blk64(R, 3 * D, D) : gemm_pick_splitk(R, 3 * D, D, 0);
         if ((size_t)g.splitk * R * 3 * D > m->splitk_ws_floats) g.splitk = 1;
         g.ws = m->splitk_ws;
         GILL_TRY(gemm_launch(g, s));
@@ -187,10 +288,10 @@ struct OptRun {
         a.dp = m->dp; a.dpv = m->dpv; a.ldo = D; a.scale = 1.0f / sqrtf((float)m->dp); a.causal = 1;
         GILL_TRY(attention_launch(a, s));
       }
-      GILL_TRY(linear(m->o, R, L.wo, L.bo, D, D, m->h, ACT_NONE, m->h, true));
-      GILL_TRY(layernorm_launch(m->h, 1, L.ln2g, L.ln2b, m->nbuf, R, D, 1e-5f, s));
-      GILL_TRY(linear(m->nbuf, R, L.w1, L.b1, F, D, nullptr, ACT_RELU, m->ff, false));
-      GILL_TRY(linear(m->ff, R, L.w2, L.b2, D, F, m->h, ACT_NONE, m->h, true));
+      GILL_TRY(linear(m->o, R, L.wo, L.blk_o, L.bo, D, D, m->h, ACT_NONE, m->h, true, L.ln2g, L.ln2b, m->nbuf));
+      GILL_TRY(linear(m->nbuf, R, L.w1, L.blk_1, L.b1, F, D, nullptr, ACT_RELU, m->ff, false));
+      if (next) GILL_TRY(linear(m->ff, R, L.w2, L.blk_2, L.b2, D, F, m->h, ACT_NONE, m->h, true, next->ln1g, next->ln1b, m->nbuf));
+      else GILL_TRY(linear(m->ff, R, L.w2, L.blk_2, L.b2, D, F, m->h, ACT_NONE, m->h, true));
     }
     return 0;
   }

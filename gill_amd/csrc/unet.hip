@@ -745,13 +745,8 @@ struct UNetRun {
     }
     if (rs) { g.row_stats = rs->p; rs->planes = gemm_row_planes(g); }
     if (ys && ys->stats) ys->nslab = ys->H * ys->W / gemm_gn_slab_rows(g);
-    {   // tools: GILL_UNET_TOUCH_W=1 pulls every GEMM's weights into the Infinity Cache right before it (on the same stream) — the
-        // kernel trace then shows what each GEMM costs with warm weights (-3.4 % of a forward), i.e. what an ideal weight prefetcher could
-        // buy.  A real one — a side stream touching the next ~48 MB of weights as a parallel branch of the captured graph — was built and
-        // measured: the loop got 4.5-15 % SLOWER, eager or captured, at any rate (profiles/r04_weight_prefetch.md); removed
-      static const bool touch = getenv("GILL_UNET_TOUCH_W") != nullptr;
-      if (touch) GILL_TRY(touch_bytes_launch(g.W, sizeof(bf16_t) * (size_t)g.N * g.K * ((g.conv && g.ups == 2) ? 4 : 1), 1024, s));
-    }
+    // (round 4: touching every GEMM's weights right before it is worth 3.4 % of a forward's kernel time, and a side-stream prefetcher costs 4.5-15 %:
+    // profiles/r04_weight_touch.md, r04_weight_prefetch.md; the probe switch is gone)
     GILL_TRY(gemm_launch(g, s));
     return dbg_sync(g.conv ? "conv" : (g.act == ACT_GEGLU ? "geglu" : (g.out_mode == OUT_QKV ? "qkv" : (g.out_mode == OUT_SOFTMAX80 ? "scores+softmax" : "gemm"))), g.M, g.N, g.K);
   }

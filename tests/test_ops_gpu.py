@@ -44,7 +44,7 @@ def test_gemm_plain(cuda, M, N, K):
 @pytest.mark.parametrize("M,N,K,sk", [(4096, 320, 1600, 1), (1024, 640, 3200, 1), (512, 1280, 6400, 2), (384, 320, 1600, 3)])
 def test_gemm_long_k_with_residual(cuda, M, N, K, sk):
   """The shapes of the UNet's fused feed-forward output GEMMs (N = 320 .. 1280, K = 5 N), with residual, unsplit and split-K.
-  N % 160 == 0, M % 128 == 0, K >= 2560 run on the convolutions' 8-wave ping-pong tiles (GILL_GEMM_PLAIN_PP, gemm.hip): cases 2 and 3."""
+  N % 160 == 0, M % 128 == 0, K >= 2560 run on the convolutions' 8-wave ping-pong tiles (gemm_plain_pingpong(), gemm.hip): cases 2 and 3."""
   from gill_amd import ops
   a, w = _bf(_rnd((M, K), 11)), _bf(_rnd((N, K), 12, 0.05))
   bias, resid = _rnd((N,), 13), _bf(_rnd((M, N), 14))
@@ -75,6 +75,24 @@ def test_gemm_splitk(cuda, M, N, K, sk):
   assert _report(f"gemm splitk{sk} {M}x{N}x{K}", out, ref) < 1e-4
   out_auto = ops.gemm(a.to(cuda), w.to(cuda), bias.to(cuda), act="relu", out_f32=True, splitk=0)
   assert _report(f"gemm splitk auto {M}x{N}x{K}", out_auto, ref) < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,sk", [(128, 4096, 4096, 0), (128, 2048, 2048, 1), (8, 4096, 1024, 0), (100, 1024, 4096, 3), (200, 2048, 2048, 0),
+                                      (256, 4096, 1024, 2), (1, 4096, 4096, 0)])
+def test_gemm_stream64_blocked_weights(cuda, M, N, K, sk):
+  """STREAM64 (gemm.hip): weight-streaming shapes (N K >= 4 Mi elements, K >= 1024) at <= 256 rows run on a 64 x 64-blocked copy of W —
+  gill_op_gemm makes the copy with the engine's own relayout kernel (convert_to_bf16_blk64_launch), so this checks the relayout, the
+  blocked K walk (whole, split: sk, heuristic: 0), one and two M tiles, ragged row counts, and the ReLU / fp32 epilogues, against torch."""
+  from gill_amd import ops
+  a, w = _bf(_rnd((M, K), 21)), _bf(_rnd((N, K), 22, 0.05))
+  bias = _rnd((N,), 23)
+  pre = a.float() @ w.float().T + bias
+  out = ops.gemm(a.to(cuda), w.to(cuda), bias.to(cuda), act="relu", out_f32=True, splitk=sk)
+  assert _report(f"gemm stream64 relu f32 {M}x{N}x{K} sk{sk}", out, F.relu(pre)) < 1e-4
+  out16 = ops.gemm(a.to(cuda), w.to(cuda), bias.to(cuda), splitk=sk)
+  assert _report(f"gemm stream64 bf16 {M}x{N}x{K} sk{sk}", out16, pre) < 1e-2
+  again = ops.gemm(a.to(cuda), w.to(cuda), bias.to(cuda), splitk=sk)
+  assert torch.equal(out16, again)
 
 
 def test_geglu(cuda):
