@@ -59,7 +59,6 @@ struct GemmDev {
   int kt;            // K elements per ring stage: 64 (2-deep ring) or 32 (4-deep ring, 128-row tiles only)
   int n_major;       // 1: consecutive tile ids walk M first (an XCD's contiguous id range = a range of N tiles over every M tile)
   int tiles_m;
-  int krot_mul = 0;  // STREAM64: workgroup t starts its K walk (t * krot_mul) % steps into its slice
 };
 
 __device__ __noinline__ float gelu_erf_call(float v) { return gelu_erf(v); }  // keeps erff out of the unrolled epilogue
@@ -178,8 +177,8 @@ template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT, int MI>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void gemm_kernel(const GemmDev d) {
   constexpr int BM = (NWV / 2) * MI * 16;
   static_assert(MI == 4 || (MI == 2 && NWV == 4 && CONV == 0 && (STAGES == 2 || STAGES == 3) && KT == 64) ||
-                    (MI == 2 && NWV == 8 && BN == 160 && STAGES == 3 && KT == 64),
-                "MI = 2: the 4-wave 64-row plain tile, or the 128 x 160 ping-pong tile (8 waves of 32 x 80)");
+                    (MI == 2 && NWV == 8 && BN == 160 && STAGES == 3 && KT == 64) || (MI == 2 && NWV == 8 && BN == 64 && STAGES == 6 && CONV == 0 && KT == 64),
+                "MI = 2: the 4-wave 64-row plain tile, the 128 x 160 ping-pong tile (8 waves of 32 x 80), or the 128 x 64 streaming tile on 8 waves of 32 x 32");
   constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
   constexpr bool PP = (NWV == 8 && BN == 160 && STAGES == 3 && KT == 64);   // ping-pong main loop (see there)
   // STREAM64 (host side: gemm_stream64_weights()): W is stored as [N / 64][K / 64][64 rows][64 k] — a K step's 64 x 64 weight tile is ONE
@@ -314,11 +313,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
     }
     return half * (BN / 2) + c;
   };
-  // STREAM64: workgroup t starts its K walk krot steps into its slice and wraps (a fixed order per workgroup: still bit-repeatable).  All
-  // workgroups of a launch stream 8 KiB per K step from bases that are multiples of K * 128 B apart; walking in lockstep from the same offset
-  // they would knock on the same HBM channels at the same time (GILL_GEMM_KROT=0: every walk starts at its slice's first step)
-  int krot = 0;
-  if constexpr (WBLK) { if (d.krot_mul && nsteps > 0) krot = (int)(((unsigned)(tile / d.tiles_m) * (unsigned)d.krot_mul) % (unsigned)nsteps); }   // (M tiles of one N tile walk together: they share its weights in L2)
   const bf16_t* Wb = p.W + (p.wb_rows ? (size_t)(m0 / p.wb_rows) * (size_t)p.wb_stride : (size_t)0);     // per-sample weights (GemmArgs::wb_rows)
   auto w_setup = [&]() {
 #pragma unroll
@@ -326,7 +320,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       int row = tile_col((i * NWV + w) * RPI + srow);
       int n = n_issue + row;
       if (n > p.N - 1) n = p.N - 1;
-      if constexpr (WBLK) w_ptr[i] = Wb + ((size_t)(n_issue / 64) * d.ksteps + kt_beg + krot) * 4096 + row * 64 + schunk * 8;
+      if constexpr (WBLK) w_ptr[i] = Wb + ((size_t)(n_issue / 64) * d.ksteps + kt_beg) * 4096 + row * 64 + schunk * 8;
       else w_ptr[i] = Wb + ((size_t)cls * p.N + n) * p.K + schunk * 8 + kt_beg * KT;
     }
   };
@@ -395,7 +389,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       }
     }
   };
-  int k_issue = (kt_beg + krot) * KT;     // K coordinate of the next step to stage
+  int k_issue = kt_beg * KT;     // K coordinate of the next step to stage
   int steps_in_tile = 0;
   // One stage = prepare (pointer set-up when the K walk enters a new N tile / (tap, source) segment) + dma (the LDS-DMA
   // instructions) + post (advance the walk).  The ping-pong loop runs the three in different phases.
@@ -406,14 +400,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       seg_left = 0;
       n_issue += BN;
       w_setup();
-    }
-    if constexpr (WBLK) {
-      if (k_issue == kt_end * KT) {      // wrap to the slice's first step
-        k_issue = kt_beg * KT;
-        seg_left = 0;
-#pragma unroll
-        for (int i = 0; i < WI; ++i) w_ptr[i] -= (size_t)nsteps * 4096;
-      }
     }
     if (seg_left == 0) seg_setup(k_issue);
   };
@@ -470,6 +456,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void ge
       case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
       case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
       case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+      case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
       case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
       case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // (waiting for more than needed is always correct)
@@ -1474,7 +1461,7 @@ bool conv_k_chunked(int HW, int Cin, int Cout) {
 // STREAM64 changes the layout, not only the tile: the matrix is stored at load time as [N / 64][K / 64][64][64] (gemm_stream64_weights() says
 // which matrices; convert_to_bf16_blk64_launch() writes them), so the 128 x 64 tile's weight stage is one contiguous 8 KiB run, a workgroup's
 // whole K walk one contiguous K * 128 B stream, fetched with the non-temporal policy (MI355X_MICROARCH "nt-weights") into a 6-deep ring
-// (144 KiB, one workgroup per CU, 40 KiB of weights + 80 KiB of L2-resident activations in flight per CU).  All rows of a <= 128-row problem
+// (144 KiB, one workgroup of eight waves per CU, 40 KiB of weights + 80 KiB of L2-resident activations in flight per CU).  All rows of a <= 128-row problem
 // sit in the one M tile (every weight is read once); more rows = more M tiles next to each other on one XCD (n_major), sharing the L2.
 // No split for >= 160 workgroups; narrower matrices split K to ~256 workgroups.  GILL_GEMM_STREAM64=0: row-major weights, general tiles.
 bool gemm_stream64_weights(int N, int K) {
@@ -1605,7 +1592,7 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
   if constexpr (BN == 64) {
     // STREAM64 (see gemm_stream64()): 128 x 64 tile, 6-deep ring = 144 KiB, one workgroup per CU
     static_assert(CONV == 0 && (EPI == 0 || EPI == 2 || EPI == 3), "the 64-wide streaming tile: plain GEMMs, row-major / partial / QKV epilogues");
-    return gemm_launch_inst<4, 64, 0, EPI, 6>(d, grid, s);
+    return gemm_launch_inst<8, 64, 0, EPI, 6, BK, 2>(d, grid, s);     // eight waves of 32 x 32: see gemm_launch_stream64()
   } else {
   if constexpr (CONV == 0 && EPI != 2) {
     if (d.nwv == 2) return gemm_launch_inst<2, BN, CONV, EPI, 2>(d, grid, s);
@@ -1757,11 +1744,14 @@ static int gemm_launch_stream64(const GemmArgs& a, hipStream_t s) {
   const int sk = a.splitk > 1 ? a.splitk : 1;
   d.a.splitk = sk;
   d.tiles_n = a.N / 64; d.tiles_m = cdiv(a.M, 128); d.npw = 1; d.groups_n = d.tiles_n; d.n_major = 1;
-  d.nwv = 4; d.mi = 4; d.kt = 64;
+  d.kt = 64;
   d.ksteps = a.K / 64;
   d.ksteps_per_split = cdiv(d.ksteps, sk);
-  static const int krot = [] { const char* v = getenv("GILL_GEMM_KROT"); return v ? atoi(v) : 5; }();
-  d.krot_mul = krot;
+  // (round 5: every workgroup starting its K walk (t * 5 | 13 | 29) % steps into its slice, against HBM-channel camping of 256 lockstep streams
+  // whose bases are K * 128 B apart: OPT stage 5.18 -> 5.24 ms, profiles/r05_opt_stream64.md.  Not that; removed.)
+  // eight waves of 32 x 32 (three LDS-DMA pieces per wave and stage) rather than four of 64 x 32 (six): OPT stage 5.03 -> 4.70 ms — a wave issues its
+  // pieces, fragment reads and MFMAs one after the other, and with one workgroup per CU only more waves overlap them
+  d.nwv = 8; d.mi = 2;
   const dim3 grid(d.tiles_n * d.tiles_m, sk, 1);
   if (sk > 1) GILL_TRY((gemm_launch_stages<64, 0, 2>(d, grid, s)));
   else if (a.out_mode == OUT_QKV) GILL_TRY((gemm_launch_stages<64, 0, 3>(d, grid, s)));
