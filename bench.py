@@ -225,7 +225,9 @@ def cpu_baseline(n_infer_steps, pipe, unet_cfg, fp8):
   per_image = (n_infer_steps + 1) * t_unet + t_map
   rec = {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
          "sample": f"UNet loop + GILLMapper only: 1 UNet forward of the CFG pair (batch 2, {L}x{L} latents): {t_unet:.2f} s; GILLMapper B=1: {t_map * 1e3:.0f} ms; "
-                   f"extrapolated x{n_infer_steps + 1} UNet calls per image (OPT forward excluded from the sample)"}
+                   f"extrapolated x{n_infer_steps + 1} UNet calls per image (OPT forward excluded from the sample).  Measured end to end once, not in this run: "
+                   f"BASELINE configs[0] (opt-125m + SD-1.5, 1 prompt, 10 steps, fp32) through the oracle on 16 host cores = 54.4 s per image "
+                   f"(profiles/r04_c1_cpu_end_to_end.log, tools/c1_cpu_end_to_end.py)"}
   return rec, check
 
 

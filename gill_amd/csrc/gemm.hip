@@ -174,10 +174,11 @@ __device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& 
 // (The timing-only ablation guards of round 4 — PP_ABL: no fragment reads / no LDS-DMA / no MFMAs / no bookkeeping / no epilogue / no barriers —
 // are gone from this file; their table is profiles/r04_pingpong_ablations.md, the bare loops live on in tools/ubench/gemm_loop.hip and gemm_ws.hip.)
 template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT, int MI>
-__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 1 : (MI == 2 ? 3 : 2)) void gemm_kernel(const GemmDev d) {
+__global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 2 : 1) : (MI == 2 ? 3 : 2)) void gemm_kernel(const GemmDev d) {
   constexpr int BM = (NWV / 2) * MI * 16;
   static_assert(MI == 4 || (MI == 2 && NWV == 4 && CONV == 0 && (STAGES == 2 || STAGES == 3) && KT == 64) ||
-                    (MI == 2 && NWV == 8 && BN == 160 && STAGES == 3 && KT == 64) || (MI == 2 && NWV == 8 && BN == 64 && STAGES == 6 && CONV == 0 && KT == 64),
+                    (MI == 2 && NWV == 8 && BN == 160 && STAGES == 3 && KT == 64) || (MI == 2 && NWV == 8 && BN == 64 && STAGES == 6 && CONV == 0 && KT == 64) ||
+                    (MI == 2 && NWV == 8 && BN == 128 && STAGES == 2 && CONV == 0 && KT == 64),
                 "MI = 2: the 4-wave 64-row plain tile, the 128 x 160 ping-pong tile (8 waves of 32 x 80), or the 128 x 64 streaming tile on 8 waves of 32 x 32");
   constexpr int NT = BN / 32;  // 16-wide N sub-tiles per wave (wave covers BN/2 columns)
   constexpr bool PP = (NWV == 8 && BN == 160 && STAGES == 3 && KT == 64);   // ping-pong main loop (see there)
@@ -1491,19 +1492,9 @@ int gemm_pick_splitk(int M, int N, int K, int act, bool plain, bool generic) {
       return s < 1 ? 1 : s;
     }
   }
-  // skinny weight-streaming GEMMs (OPT-6.7b at 4-8 prompts: M = 128 / 256 rows, 33-134 MB of weights per matrix).  Measured with
-  // tools/r05_probe.py (profiles/r05_opt_splitk.md): with >= 64 tiles of 160 columns (QKV N = 12288, fc1 N = 16384) the UNSPLIT launch streams
-  // at 3.3-4.3 TB/s and every split loses 20-45 % to its fp32 partials (7 x 128 x 12288 floats = 44 MB written and read back beside 100 MB of
-  // weights); the narrow ones (N = 4096: 26 tiles) want ~320 workgroups but no more partial bytes than a quarter of the weights
-  if (M <= 256 && !generic && act != ACT_GEGLU) {
-    if (tiles >= 64) return 1;
-    int s = (320 + tiles / 2) / tiles;
-    const int cap = K / (4 * M);
-    if (s > cap) s = cap;
-    if (s > ksteps / 4) s = ksteps / 4;
-    if (s > 16) s = 16;
-    return s < 1 ? 1 : s;
-  }
+  // (round 5, first session: an M-dependent rule for skinny weight-streaming GEMMs lived here.  The OPT matrices now take gemm_pick_splitk_blk64();
+  // for everything else it made the split factor — the fp32 summation order — depend on the batch, and the tiny UNet's batch-invariance check went
+  // from bit-identical to 2.4e-2 after 11 recurrent calls.  Removed.)
   // plain GEMMs with 150..383 128-row tiles run on 64-row tiles instead (gemm_launch: >= 300 workgroups, no partials):
   // measured 8192 x 640 x 3200 unsplit 49.1 us, two-way split + reducer 54.6 us
   if (plain && !generic && tiles >= 150 && tiles < 300 && M > 64) return 1;
@@ -1626,6 +1617,13 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
     if (d.nwv == 8 && d.mi == 2) return gemm_launch_inst<8, BN, CONV, EPI, 3, BK, 2>(d, grid, s);   // ping-pong 128 x 160 tile
     if (d.nwv == 8) return gemm_launch_inst<8, BN, CONV, EPI, 3>(d, grid, s);     // ping-pong 256 x 160 tile
   }
+  if constexpr (CONV == 0 && BN == 128 && (EPI == 1 || EPI == 3)) {
+    // round 5: the 128 x 128 tile of the GEGLU / QKV GEMMs on eight waves of 32 x 64 (two workgroups = 16 waves per CU, 116 registers) instead of four of
+    // 64 x 64: half the LDS-DMA pieces, fragment reads and MFMAs per wave and step, twice the waves to overlap them.  Loop 447.4 -> 445.8 ms (A/B x3,
+    // profiles/r05_linears.md); level-1 GEGLU 82.1 -> 79.7 us stand-alone
+    if (d.nwv == 4 && d.mi == 4) return gemm_launch_inst<8, BN, CONV, EPI, 2, BK, 2>(d, grid, s);
+  }
+  // (the same for the UNet's plain 128-row GEMMs — the lean row-major epilogue, EPI 4 — measured slower: loop 451.3 -> 456.0 ms, profiles/r05_linears.md)
   return gemm_launch_inst<4, BN, CONV, EPI, 2>(d, grid, s);
   }
 }
