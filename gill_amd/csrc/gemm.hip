@@ -443,26 +443,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
   const int fkc = lane >> 4;        // 16-B k chunk within the 32-wide MFMA k step
 
   static_assert(STAGES >= 2 && STAGES <= 6, "ring depth");
-  // s_waitcnt vmcnt(n) with a run-time n (its operand is an immediate): n = (stages still allowed in flight) * lw <= 15
-  auto wait_vm = [](int n) {
-    switch (n) {
-      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-      case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-      case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-      case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-      case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // (waiting for more than needed is always correct)
-    }
-  };
   const int total_steps = ntl * nsteps;
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
@@ -590,9 +570,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
       else if (w_last_ok) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + WI) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + WI - 1) : "memory");
     } else {
-      int ahead = total_steps - 1 - flat;
-      if (ahead > STAGES - 2) ahead = STAGES - 2;
-      wait_vm(ahead * lw);
+      // deeper rings (STREAM64: 6): in the steady state STAGES - 2 younger stages are in flight — this wave's pieces per stage times that, as an
+      // immediate behind a two-way test; the last STAGES - 2 steps of the walk just wait for everything (wait_vm()'s run-time switch compiles to a
+      // chain of ~15 compare-and-branch pairs per K step: an EMPTY step of this loop cost 0.34 us with it, profiles/r05_opt_stream64.md)
+      if (total_steps - 1 - flat < STAGES - 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (w_last_ok) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (AI + WI)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (AI + WI - 1)) : "memory");
     }
     __builtin_amdgcn_s_barrier();
     const bf16_t* As = smem + buf * BUF_ELEMS;

@@ -71,24 +71,35 @@ __global__ __launch_bounds__(256) void opt_reduce_ln_kernel(const float* __restr
   __shared__ float red[8];
   const int row = blockIdx.x, tid = threadIdx.x, nv = D >> 2;
   const size_t slice = (size_t)M * D;
-  float4 v[VPT];
+  // every load of the row goes out before the first addition (slices four at a time, clamped addresses: no branch between a load and its use,
+  // so the compiler does not fence them one by one): the kernel is one memory round trip deep, not sk + 2
+  float4 v[VPT], bb[VPT], rr[VPT];
+  float4 q[VPT][4];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int idx = (tid + i * 256 < nv) ? tid + i * 256 : 0;
+    const int c = idx * 4;
+    const float* p = ws + (size_t)row * D + c;
+#pragma unroll
+    for (int z = 0; z < 4; ++z) q[i][z] = *reinterpret_cast<const float4*>(p + (size_t)(z < sk ? z : 0) * slice);
+    bb[i] = *reinterpret_cast<const float4*>(bias + c);
+    rr[i] = *reinterpret_cast<const float4*>(h + (size_t)row * D + c);
+  }
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int c = (tid + i * 256) * 4;
-    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid + i * 256 < nv) {
-      const float* p = ws + (size_t)row * D + c;
-      float4 a = *reinterpret_cast<const float4*>(p);
-      for (int z = 1; z < sk; ++z) {
-        const float4 q = *reinterpret_cast<const float4*>(p + (size_t)z * slice);
-        a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
-      }
-      const float4 bb = *reinterpret_cast<const float4*>(bias + c);
-      const float4 r = *reinterpret_cast<const float4*>(h + (size_t)row * D + c);
-      a.x = a.x + bb.x + r.x; a.y = a.y + bb.y + r.y; a.z = a.z + bb.z + r.z; a.w = a.w + bb.w + r.w;
-      *reinterpret_cast<float4*>(h + (size_t)row * D + c) = a;
-      v[i] = a;
+    const bool ok = tid + i * 256 < nv;
+    float4 a = q[i][0];
+#pragma unroll
+    for (int z = 1; z < 4; ++z)
+      if (z < sk) { a.x += q[i][z].x; a.y += q[i][z].y; a.z += q[i][z].z; a.w += q[i][z].w; }
+    for (int z = 4; z < sk; ++z) {      // (more than four slices: not the OPT shapes)
+      const float4 e = *reinterpret_cast<const float4*>(ws + (size_t)row * D + (ok ? c : 0) + (size_t)z * slice);
+      a.x += e.x; a.y += e.y; a.z += e.z; a.w += e.w;
     }
+    a.x = a.x + bb[i].x + rr[i].x; a.y = a.y + bb[i].y + rr[i].y; a.z = a.z + bb[i].z + rr[i].z; a.w = a.w + bb[i].w + rr[i].w;
+    if (ok) *reinterpret_cast<float4*>(h + (size_t)row * D + c) = a;
+    v[i] = ok ? a : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   auto block_sum = [&](float x) -> float {      // fixed order: lanes (xor tree), then the four waves in index order
     x = wave_sum(x);
