@@ -84,3 +84,33 @@ def test_fp8_unet_mode_vs_bf16_mode(cuda, which):
   assert rel < 8e-2 and cos > 0.995      # the same bar the bf16 mode is held to against the fp32 oracle
   again = pipe8(**kw).images.float().cpu()
   assert torch.equal(again, got)
+
+
+@pytest.mark.parametrize("which", ["tiny", "sd15"])
+def test_fp8_unet_forward_vs_fp32_oracle(cuda, which):
+  """the fp8 mode was only ever compared with this build's own bf16 mode.  Here ONE UNet forward (CFG pair, t = 961) with
+  the 44 resnet convolutions in e4m3 goes against the fp32 CPU oracle (oracle/unet_ref.py, the same one the bf16 mode is held to), next to
+  the bf16 mode's own distance on the same inputs.  Measured: bf16 1.17e-2 (both sizes); fp8 5.4e-2 at full size, 5.8e-2 on the tiny UNet, cosine
+  0.9983-0.9986 — what e4m3 operands in the 44 resnet convolutions cost one forward.  Bars: bf16 5e-2 / 0.998 (its bar everywhere), fp8 8e-2 /
+  0.997 (the bar bench.py's forward_check applies to the C5 line)."""
+  import dataclasses
+  from gill_amd.sd import GillSDPipeline
+  from oracle import unet_ref
+  cfg = synth.UNetConfig.tiny(16) if which == "tiny" else synth.UNetConfig.sd15()
+  sd = _bfw(synth.unet_state_dict(cfg, seed=43))
+  uncond = synth.uncond_context(cfg.ctx_len, cfg.cross_attention_dim, seed=43).bfloat16().float()
+  L = cfg.sample_size
+  x = synth.initial_latents(2, 4, L, seed=4343)
+  ctx = torch.cat([uncond, synth.normal("f8o_ctx", (1, cfg.ctx_len, cfg.cross_attention_dim), 44)], 0).bfloat16().float()
+  t = torch.tensor([961.0, 961.0])
+  heads = cfg.heads_per_level if cfg.heads_per_level else cfg.num_heads
+  ref = unet_ref.unet_forward(sd, x, t, ctx, cfg.block_out_channels, heads, cfg.norm_num_groups)
+  out = {}
+  for name, c in (("bf16", cfg), ("fp8", dataclasses.replace(cfg, fp8_convs=True))):
+    got = GillSDPipeline(sd, c, uncond, cuda, max_batch=2).unet(x, t, ctx).float().cpu()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
+    print(f"[{name} UNet forward vs fp32 oracle, {which}] rel-L2 {rel:.3e} cos {cos:.5f}")
+    out[name] = (rel, cos)
+  assert out["bf16"][0] < 5e-2 and out["bf16"][1] > 0.998
+  assert out["fp8"][0] < 8e-2 and out["fp8"][1] > 0.997
