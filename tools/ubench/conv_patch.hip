@@ -222,16 +222,27 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const bool lo_edge = frow == 0, hi_edge = frow == 15;
   bf16x8 af[2][4], bfr[2][5];
   // step k -> chunk, tap
-  auto wait_next = [&](int k, bool had_patch) __attribute__((always_inline)) {
-    // W(k + 1) landed: younger = this step's patch piece (if any) + W(k + 2) (3 pieces in group 0, 2 in group 1)
+  int had_prev = 0;
+  auto wait_next = [&](int k, int had_patch) __attribute__((always_inline)) {
+    // W(k + 1) landed: younger = this step's patch pieces + W(k + 2) (3 pieces in group 0, 2 in group 1).
+    // ABL bit 1 (ORDER): the patch pieces go out BEHIND the step's weight pieces, so the previous step's pieces (first touches of the input: L2 misses)
+    // are younger than W(k + 1) too and may stay in flight one more step.  ABL bit 2 (BURST, with ORDER): the whole next patch at tap 0, 6-7 pieces per wave.
     if (k + 2 < nsteps) {
-      const int n = (grp == 0 ? 3 : 2) + (had_patch ? 1 : 0);
-      if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      const int n = (grp == 0 ? 3 : 2) + had_patch + ((ABL & 2) ? had_prev : 0);
+      switch (n) {
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;     // (over-waiting is always correct)
+      }
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    had_prev = had_patch;
   };
-  auto mem = [&](int k, int chunk, int tap) __attribute__((always_inline)) -> bool {
+  auto mem = [&](int k, int chunk, int tap) __attribute__((always_inline)) -> int {
     const unsigned char* P = patch0 + (chunk & 1) * PATCH_B;
     const unsigned char* Bs = wring + (k % 3) * WST_B;
     const int ty = tap / 3;
@@ -253,12 +264,18 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         bfr[kk][j] = *reinterpret_cast<const bf16x8*>(Bs + row * 128 + (((kk * 4 + fkc) ^ (row & 7)) * 16));
       }
     }
-    bool had = false;
-    if (tap <= 6 && chunk + 1 < nsteps / 9) {
+    int had = 0;
+    if ((ABL & 2) && k + 2 < nsteps) issue_w((k + 2) % 3);
+    if (ABL & 4) {
+      if (tap == 0 && chunk + 1 < nsteps / 9) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) { const int g = t * 8 + w; if (g <= 48) { issue_patch(g, chunk + 1); ++had; } }
+      }
+    } else if (tap <= 6 && chunk + 1 < nsteps / 9) {
       const int g = tap * 8 + w;
-      if (g <= 48) { issue_patch(g, chunk + 1); had = !(ABL & 1); }
+      if (g <= 48) { issue_patch(g, chunk + 1); had = (ABL & 1) ? 0 : 1; }
     }
-    if (k + 2 < nsteps) issue_w((k + 2) % 3);
+    if (!(ABL & 2) && k + 2 < nsteps) issue_w((k + 2) % 3);
     return had;
   };
   auto mma = [&]() __attribute__((always_inline)) {
@@ -279,7 +296,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   int chunk = 0, tap = 0;
   if (grp == 0) {
     for (int k = 0; k < nsteps; ++k) {
-      const bool had = mem(k, chunk, tap);
+      const int had = mem(k, chunk, tap);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       mma();
@@ -292,9 +309,182 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   } else {
     __builtin_amdgcn_s_barrier();
     for (int k = 0; k < nsteps; ++k) {
-      const bool had = mem(k, chunk, tap);
+      const int had = mem(k, chunk, tap);
       wait_next(k, had);
       if (++tap == 9) { tap = 0; ++chunk; }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      mma();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  if (write_c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          C[(size_t)(m0 + wm * 64 + i * 16 + frow) * N + n0 + wn * 80 + j * 16 + fkc * 4 + r] = acc[i][j][r];
+  } else {
+    float result = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) result += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    C[(size_t)blockIdx.x * 512 + tid] = result;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------- 9-tap patch, version 2
+// The same loop with NOTHING but reads and LDS-DMA issues in the memory phase: the next K step's fragment addresses (three registers + their ^ 64
+// twins), the next patch piece's source pointer and the (chunk, dy, dx) walk are computed in the MMA phase, one scalar / vector instruction behind
+// each MFMA (sched_group_barrier), where the shipped kernel keeps its pointer bookkeeping.
+template <int ABL>
+__global__ __launch_bounds__(512, 1) void k_patch2(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, float* __restrict__ C,
+                                                   int M, int N, int K, int write_c) {
+  extern __shared__ __attribute__((aligned(128))) unsigned char smem_raw[];
+  constexpr int PATCH_ROWS = 392;
+  constexpr int PATCH_B = PATCH_ROWS * 128;
+  constexpr int WST_B = BN * 128;
+  unsigned char* patch0 = smem_raw;
+  unsigned char* wring = smem_raw + 2 * PATCH_B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = N / BN;
+  const int tile = xcd_tile();
+  const int tn = tile % tiles_n, tm = tile / tiles_n;
+  const int m0 = tm * 256, n0 = tn * BN;
+  const int b = m0 / 4096, y0 = (m0 % 4096) / 64;
+  const int srow = lane >> 3;
+  const int nsteps = K / BK, nchunks = nsteps / 9;
+  const int grp = w >> 2;
+  const bf16_t* zero_lane = (const bf16_t*)g_zero + (lane & 7) * 8;
+  const bf16_t* w_ptr[3];
+  for (int i = 0; i < 3; ++i) {
+    int g = i * 8 + w; if (g > 19) g = 19;
+    int row = g * 8 + srow;
+    w_ptr[i] = W + (size_t)(n0 + row) * K + ((lane & 7) ^ (row & 7)) * 8;
+  }
+  auto patch_src = [&](int g, int chunk) __attribute__((always_inline)) -> const bf16_t* {
+    const int yy = g >> 3;
+    const int iy = y0 - 1 + yy;
+    const bool ok = (g < 48) && iy >= 0 && iy < 64;
+    const bf16_t* p = A + ((size_t)b * 4096 + (size_t)iy * 64 + (g & 7) * 8 + srow) * KW + chunk * 64 + ((lane & 7) ^ srow) * 8;
+    return ok ? p : zero_lane;
+  };
+  auto issue_w = [&](int stage) __attribute__((always_inline)) {
+    unsigned char* Bs = wring + stage * WST_B;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i < 2 || grp == 0) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
+                                         (__attribute__((address_space(3))) void*)(Bs + (i * 8 + w) * 1024), 16, 0, 0);
+        w_ptr[i] += BK;
+      }
+    }
+  };
+  const int wm = w >> 1, wn = w & 1;
+  f32x4 acc[4][5];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+  const int frow = lane & 15, fkc = lane >> 4;
+  const int a_lane = ((wm + 1) * 64 + frow) * 128;
+  const int zrow = 384 * 128 + fkc * 16;
+  const bool lo_edge = frow == 0, hi_edge = frow == 15;
+  bf16x8 af[2][4], bfr[2][5];
+  // state of the NEXT memory phase, prepared during the MMA phase before it
+  int chunk = 0, dy = -1, dx = -1, tapi = 0;          // (chunk, tap) of the step whose addresses are in c_*
+  int c_b0, c_e0, c_e3;                               // fragment addresses (bytes from smem_raw) of i = 1..2 (+ immediates), i = 0, i = 3
+  const bf16_t* c_psrc; int c_pdst; bool c_has;       // patch piece of this step (for chunk + 1)
+  auto prep = [&](int ch, int ty, int tx, int tp) __attribute__((always_inline)) {
+    const int pb = (ch & 1) * PATCH_B;
+    const int base = pb + a_lane + (ty * 64 + tx) * 128 + ((fkc ^ ((frow + tx) & 7)) << 4);
+    c_b0 = base;
+    c_e0 = (tx < 0 && lo_edge) ? pb + zrow : base;
+    c_e3 = (tx > 0 && hi_edge) ? pb + zrow : base + 3 * 2048;
+    const int g = tp * 8 + w;
+    c_has = !(ABL & 1) && tp <= 6 && ch + 1 < nchunks && g <= 48;
+    c_psrc = patch_src(g, ch + 1);
+    c_pdst = ((ch + 1) & 1) * PATCH_B + g * 1024;
+  };
+  auto wait_next = [&](int k, bool had_patch) __attribute__((always_inline)) {
+    if (k + 2 < nsteps) {
+      const int n = (grp == 0 ? 3 : 2) + (had_patch ? 1 : 0);
+      if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto mem = [&](int k) __attribute__((always_inline)) -> bool {
+    const unsigned char* Bs = wring + (k % 3) * WST_B;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int x = kk ? 64 : 0;
+      af[kk][0] = *reinterpret_cast<const bf16x8*>(smem_raw + (c_e0 ^ x));
+      af[kk][1] = *reinterpret_cast<const bf16x8*>(smem_raw + (c_b0 ^ x) + 2048);
+      af[kk][2] = *reinterpret_cast<const bf16x8*>(smem_raw + (c_b0 ^ x) + 4096);
+      af[kk][3] = *reinterpret_cast<const bf16x8*>(smem_raw + (c_e3 ^ x));
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int row = wn * 80 + j * 16 + frow;
+        bfr[kk][j] = *reinterpret_cast<const bf16x8*>(Bs + row * 128 + (((kk * 4 + fkc) ^ (row & 7)) * 16));
+      }
+    }
+    const bool had = c_has;
+    if (had)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)c_psrc,
+                                       (__attribute__((address_space(3))) void*)(smem_raw + c_pdst), 16, 0, 0);
+    if (k + 2 < nsteps) issue_w((k + 2) % 3);
+    return had;
+  };
+  auto mma = [&]() __attribute__((always_inline)) {
+    // advance the (chunk, dy, dx) walk and prepare the next step's addresses between the MFMAs
+    int ndx = dx + 1, ndy = dy, nch = chunk, ntap = tapi + 1;
+    if (ndx == 2) { ndx = -1; ndy = dy + 1; }
+    if (ndy == 2) { ndy = -1; nch = chunk + 1; ntap = 0; }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+    dx = ndx; dy = ndy; chunk = nch; tapi = ntap;
+    prep(chunk, dy, dx, tapi);
+#pragma unroll
+    for (int q = 0; q < 40; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x006, 1, 0);
+    }
+  };
+  // prologue: the whole patch of chunk 0 (7 groups per wave), two weight stages
+  if (!(ABL & 1))
+    for (int t = 0; t < 7; ++t) {
+      const int g = t * 8 + w;
+      if (g <= 48)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)patch_src(g, 0),
+                                         (__attribute__((address_space(3))) void*)(patch0 + g * 1024), 16, 0, 0);
+    }
+  issue_w(0);
+  if (nsteps > 1) issue_w(1);
+  prep(0, -1, -1, 0);
+  if (nsteps > 1) { if (grp == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 0) {
+    for (int k = 0; k < nsteps; ++k) {
+      const bool had = mem(k);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      mma();
+      wait_next(k, had);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __builtin_amdgcn_s_barrier();
+    for (int k = 0; k < nsteps; ++k) {
+      const bool had = mem(k);
+      wait_next(k, had);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       mma();
@@ -392,7 +582,11 @@ int main(int argc, char** argv) {
     const bool chk = rep == 0;
     run(k_pp, SM3, 512, A, W, C, M, N, K, "ping-pong, per-tap A tiles (shipped structure; GEMM stand-in)", hA, hW, chk, 0);
     run(k_patch<0>, SMP, 512, A, W, C, M, N, K, "ping-pong, 9-tap input patch in LDS (real convolution)", hA, hW, chk, 1);
+    run(k_patch2<0>, SMP, 512, A, W, C, M, N, K, "  version 2: addresses prepared in the MMA phase", hA, hW, chk, 1);
+    run(k_patch<2>, SMP, 512, A, W, C, M, N, K, "  version 1, patch piece behind the weight pieces (one more step in flight)", hA, hW, chk, 1);
+    run(k_patch<6>, SMP, 512, A, W, C, M, N, K, "  version 1, the whole next patch at tap 0, behind the weight pieces", hA, hW, chk, 1);
     if (rep == 2) run(k_patch<1>, SMP, 512, A, W, C, M, N, K, "  ablation: no patch pieces (timing only)", hA, hW, false, 1);
+    if (rep == 2) run(k_patch2<1>, SMP, 512, A, W, C, M, N, K, "  ablation, version 2: no patch pieces (timing only)", hA, hW, false, 1);
   }
   return 0;
 }
