@@ -1453,10 +1453,10 @@ bool conv_k_chunked(int HW, int Cin, int Cout) {
 // whole K walk one contiguous K * 128 B stream, fetched with the non-temporal policy (MI355X_MICROARCH "nt-weights") into a 6-deep ring
 // (144 KiB, one workgroup of eight waves per CU, 40 KiB of weights + 80 KiB of L2-resident activations in flight per CU).  All rows of a <= 128-row problem
 // sit in the one M tile (every weight is read once); more rows = more M tiles next to each other on one XCD (n_major), sharing the L2.
-// No split for >= 160 workgroups; narrower matrices split K to ~256 workgroups.  GILL_GEMM_STREAM64=0: row-major weights, general tiles.
+// No split for >= 160 workgroups; narrower matrices split K to ~256 workgroups.  (The A/B switch of round 5 is gone: row-major weights on the general
+// tiles measured 5.95-6.08 ms for the OPT stage against 4.31 ms, profiles/r05_opt_stream64.md.)
 bool gemm_stream64_weights(int N, int K) {
-  static const int on = [] { const char* v = getenv("GILL_GEMM_STREAM64"); return v ? atoi(v) : 1; }();
-  return on != 0 && N % 64 == 0 && K % 64 == 0 && K >= 1024 && (int64_t)N * K >= ((int64_t)4 << 20);
+  return N % 64 == 0 && K % 64 == 0 && K >= 1024 && (int64_t)N * K >= ((int64_t)4 << 20);
 }
 int gemm_pick_splitk_blk64(int M, int N, int K) {
   const int tiles = cdiv(M, 128) * (N / 64), ksteps = K / BK;

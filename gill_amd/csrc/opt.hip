@@ -244,7 +244,6 @@ struct OptRun {
   // Split-K launches hand it to the reducer (opt_reduce_ln_kernel); unsplit ones run the stand-alone pass.
   int linear(const bf16_t* A, int M, const bf16_t* W, int blk, const float* b, int N, int K, const float* resid, int act, void* out,
              bool out_f32, const float* ln_g = nullptr, const float* ln_b = nullptr, bf16_t* ln_out = nullptr) {
-    static const int fuse = [] { const char* v = getenv("GILL_OPT_REDUCE_LN"); return v ? atoi(v) : 1; }();
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.K1 = K; g.A = A; g.lda = K; g.W = W; g.bias = b;
     g.resid = resid; g.ldr = N; g.resid_f32 = 1;
@@ -253,7 +252,7 @@ struct OptRun {
     g.splitk = blk ? gemm_pick_splitk_blk64(M, N, K) : gemm_pick_splitk(M, N, K, act);
     if ((size_t)g.splitk * M * N > m->splitk_ws_floats) g.splitk = 1;
     g.ws = m->splitk_ws;
-    if (ln_out && fuse && g.splitk > 1 && out_f32 && resid == (const float*)out && act == ACT_NONE && b && N % 4 == 0 && N <= 8192) {
+    if (ln_out && g.splitk > 1 && out_f32 && resid == (const float*)out && act == ACT_NONE && b && N % 4 == 0 && N <= 8192) {
       g.partials_only = 1;
       GILL_TRY(gemm_launch(g, s));
       return opt_reduce_ln_launch(m->splitk_ws, g.splitk, M, N, b, (float*)out, ln_g, ln_b, ln_out, 1e-5f, s);
