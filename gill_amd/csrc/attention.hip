@@ -598,8 +598,7 @@ static int attention_launch_inst(const AttnArgs& a, hipStream_t s) {
 template <int DP>
 static int attention_launch_dp(const AttnArgs& a, hipStream_t s) {
   const int64_t bh = (int64_t)a.H * a.B;
-  static const int forced = [] { const char* e = getenv("GILL_ATT_THREADS"); return e ? atoi(e) : 0; }();   // tests / tools
-  const bool big = forced == 512 || (forced != 256 && cdiv(a.nq, 256) * bh >= 256);
+  const bool big = cdiv(a.nq, 256) * bh >= 256;
   if constexpr (DP == 48) {
     if (attention_dma_ok(a, big ? 512 : 256)) return big ? attention_dma_launch<DP, 512>(a, s) : attention_dma_launch<DP, 256>(a, s);
   }

@@ -21,6 +21,25 @@ static int op_repeat() {
   return r;
 }
 
+// One grow-only split-K workspace for the operator entry points (they synchronise before they return and the reference's threading model is one
+// request at a time — SURVEY 8b — so one buffer serves them all): a per-call hipMalloc / hipFree of up to 100 MB sat inside every timed call
+// (profiles/r05_opt_stream64.md: it poisoned a probe).  Freed at process exit with the context.
+static float* op_splitk_ws(size_t floats) {
+  static float* ws = nullptr;
+  static size_t cap = 0;
+  if (floats > cap) {
+    if (ws) (void)hipFree(ws);
+    ws = nullptr; cap = 0;
+    const size_t want = floats + (floats >> 2);
+    if (hipMalloc((void**)&ws, sizeof(float) * want) != hipSuccess) { ws = nullptr; return nullptr; }
+    cap = want;
+  }
+  return ws;
+}
+
+// splitk: 0 = the launcher's heuristic, n > 1 = forced.  splitk < 0: FORCE THE GENERAL ROW-MAJOR TILES — never the 64 x 64-blocked
+// STREAM64 copy that weight-streaming shapes (M <= 256, N * K >= 4 Mi) otherwise take — with the heuristic split (-1) or -splitk ways (< -1), so that
+// the operator tests can pin both paths on the same shape (the UNet and CLIP engines run such shapes on the general tiles).
 extern "C" int gill_op_gemm(const void* A, const void* W, const float* bias, const void* resid_bf16, void* C, int M, int N,
                             int K, float alpha, int act, int out_f32, int splitk, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -33,21 +52,22 @@ extern "C" int gill_op_gemm(const void* A, const void* W, const float* bias, con
   g.act = act;
   g.out_mode = out_f32 ? OUT_F32 : OUT_BF16;
   g.C = C; g.ldc = N;
+  const bool row_major = splitk < 0;
+  if (row_major) splitk = (splitk == -1) ? 0 : -splitk;
   // weight-streaming shapes at a few hundred rows run the way the OPT engine runs them: on a 64 x 64-blocked copy of W (STREAM64)
   DevBuf wblk;
-  if (M <= 256 && act != ACT_GEGLU && gemm_stream64_weights(N, K)) {
+  if (!row_major && M <= 256 && act != ACT_GEGLU && gemm_stream64_weights(N, K)) {
     GILL_TRY(wblk.alloc(sizeof(bf16_t) * (size_t)N * K));
     GILL_TRY(convert_to_bf16_blk64_launch(W, 0, N, K, (bf16_t*)wblk.p, s));
     g.W = (const bf16_t*)wblk.p; g.w_blk64 = 1;
   }
   g.splitk = splitk > 0 ? splitk : (g.w_blk64 ? gemm_pick_splitk_blk64(M, N, K) : gemm_pick_splitk(M, N, K, act));
-  DevBuf ws;
   if (g.splitk > 1) {
-    GILL_TRY(ws.alloc(sizeof(float) * (size_t)g.splitk * M * N));
-    g.ws = (float*)ws.p;
+    g.ws = op_splitk_ws((size_t)g.splitk * M * N);
+    GILL_REQUIRE(g.ws != nullptr, "split-K workspace allocation failed");
   }
   for (int r = 0; r < op_repeat(); ++r) GILL_TRY(gemm_launch(g, s));
-  if (g.splitk > 1 || g.w_blk64) GILL_CHECK_HIP(hipStreamSynchronize(s));  // ws / the blocked copy are freed on return
+  if (g.w_blk64) GILL_CHECK_HIP(hipStreamSynchronize(s));  // the blocked copy is freed on return
   return 0;
 }
 
@@ -82,7 +102,7 @@ extern "C" int gill_op_conv3x3(const void* x1, int C1, const void* x2, int C2, c
   const int Cin = C1 + C2;
   DevBuf wr, ws;
   GILL_TRY(wr.alloc(sizeof(bf16_t) * (size_t)Cout * 16 * Cin));     // 9 taps, or 4 classes x 4 taps
-  // K order as the engines choose it (GILL_CONV_KORDER = 0 | 1 forces tap-major / chunk-major for tests and tools)
+  // K order as the engines choose it
   int chunked = conv_k_chunked(IH * IW, Cin, Cout) ? 1 : 0;
   // ups = 1: the engines' form — four pre-summed 2x2-tap kernels on the source grid (GILL_CONV_UPS4 = 0, or a residual / row
   // vector, which that form does not take: the 9-tap gather over the upsampled grid)
@@ -135,38 +155,6 @@ extern "C" int gill_op_conv3x3_gn(const void* x, const float* w_oihw, const floa
   g.fn_Y = (bf16_t*)y_norm; g.fn_gamma = gamma; g.fn_beta = beta; g.fn_eps = eps; g.fn_silu = silu; g.fn_cg = Cout / groups;
   GILL_REQUIRE(gemm_fused_norm_ok(g), "conv3x3_gn: unsupported geometry (H * W in {64, 256}, Cout % 80 == 0, group width | 80)");
   for (int r = 0; r < op_repeat(); ++r) GILL_TRY(gemm_launch(g, s));
-  GILL_CHECK_HIP(hipStreamSynchronize(s));
-  return 0;
-}
-
-// The same convolution in Winograd F(2x2, 3x3) form (wino.hip): weight transform U = G g G^T, input transform V = B^T d B, the 16
-// position GEMMs as one 16-way split-K plain GEMM, A^T M A + epilogue in the split-K reducer — with the consuming GroupNorm (+ SiLU) when
-// gamma != NULL (then H * W in {64, 256} as for gill_op_conv3x3_gn; y_raw optional), else y_raw = conv(x) + bias + rowvec + resid.
-extern "C" int gill_op_conv3x3_wino(const void* x, const float* w_oihw, const float* bias, const float* rowvec, const void* resid,
-                                    const float* gamma, const float* beta, int groups, float eps, int silu, void* y_raw, void* y_norm, int B,
-                                    int H, int W, int Cin, int Cout, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
-  GILL_REQUIRE(x && w_oihw && (y_raw || y_norm) && (gamma == nullptr || (beta && y_norm && groups > 0 && Cout % groups == 0)), "bad argument");
-  GILL_REQUIRE(gemm_wino_ok(B * H * W, Cout, Cin, H * W, W), "conv3x3_wino: unsupported geometry (odd map side, tiles % 128, Cout % 160, Cin % 64)");
-  DevBuf wu, v, ws;
-  GILL_TRY(wu.alloc(sizeof(bf16_t) * (size_t)Cout * 16 * Cin));
-  GILL_TRY(v.alloc(sizeof(bf16_t) * (size_t)4 * B * H * W * Cin));
-  GILL_TRY(ws.alloc(sizeof(float) * (size_t)4 * B * H * W * Cout));
-  GILL_TRY(wino_weight_transform_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wu.p, s));
-  GemmArgs g;
-  g.M = B * H * W; g.N = Cout; g.K = 16 * Cin; g.K1 = g.K; g.A = (const bf16_t*)v.p; g.lda = g.K;
-  g.W = (const bf16_t*)wu.p; g.bias = bias;
-  g.rowvec = rowvec; g.rows_per_batch = H * W; g.rowvec_bstride = Cout;
-  g.resid = resid; g.ldr = Cout; g.C = y_raw; g.ldc = Cout;
-  g.wino = 1; g.wino_W = W; g.splitk = 16; g.ws = (float*)ws.p;
-  if (gamma) {
-    g.fn_Y = (bf16_t*)y_norm; g.fn_gamma = gamma; g.fn_beta = beta; g.fn_eps = eps; g.fn_silu = silu; g.fn_cg = Cout / groups;
-    GILL_REQUIRE(gemm_fused_norm_ok(g), "conv3x3_wino: unsupported fused GroupNorm geometry (H * W in {64, 256}, Cout % 80 == 0, group width | 80)");
-  }
-  for (int r = 0; r < op_repeat(); ++r) {
-    GILL_TRY(wino_input_transform_launch((const bf16_t*)x, B, H, W, Cin, (bf16_t*)v.p, s));
-    GILL_TRY(gemm_launch(g, s));
-  }
   GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
 }

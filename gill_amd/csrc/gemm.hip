@@ -1059,33 +1059,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
 // Fused statistics are fixed-order like the in-kernel epilogue's: per-row / per-column cells in LDS written once each, then
 // one thread per output sum adds them in index order (row sums -> plane blockIdx.x of row_stats, bins -> this slab's
 // GroupNorm partial).
-// WINO (GemmArgs::wino): the 16 slices are the Winograd positions' planes [16][M / 4 tiles][N]; a thread row lane owns ONE tile (R = 4: its
-// four output pixels), sums A^T M A instead of the slices, and the rest of the epilogue runs on the pixels' rows.
-// A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]: Y[a][b] = sum_ij A^T[a][i] M[i][j] A^T[b][j]
-__device__ __forceinline__ void wino_out4(const float4 (&mp)[16], float4 (&y)[4]) {
-  float4 z0[4], z1[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float4 a = mp[j], b = mp[4 + j], c = mp[8 + j], d = mp[12 + j];
-    z0[j] = make_float4(a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z, a.w + b.w + c.w);
-    z1[j] = make_float4(b.x - c.x - d.x, b.y - c.y - d.y, b.z - c.z - d.z, b.w - c.w - d.w);
-  }
-  y[0] = make_float4(z0[0].x + z0[1].x + z0[2].x, z0[0].y + z0[1].y + z0[2].y, z0[0].z + z0[1].z + z0[2].z, z0[0].w + z0[1].w + z0[2].w);
-  y[1] = make_float4(z0[1].x - z0[2].x - z0[3].x, z0[1].y - z0[2].y - z0[3].y, z0[1].z - z0[2].z - z0[3].z, z0[1].w - z0[2].w - z0[3].w);
-  y[2] = make_float4(z1[0].x + z1[1].x + z1[2].x, z1[0].y + z1[1].y + z1[2].y, z1[0].z + z1[1].z + z1[2].z, z1[0].w + z1[1].w + z1[2].w);
-  y[3] = make_float4(z1[1].x - z1[2].x - z1[3].x, z1[1].y - z1[2].y - z1[3].y, z1[1].z - z1[2].z - z1[3].z, z1[1].w - z1[2].w - z1[3].w);
-}
-// output row of pixel e = a * 2 + b of tile `tile` (tiles in (sample, ty, tx) order; rows_per_batch = H * W, wino_W = W)
-__device__ __forceinline__ int wino_row(const GemmArgs& p, int tile, int e) {
-  const int TW = p.wino_W >> 1;
-  const int tps = p.rows_per_batch >> 2;                 // tiles per sample
-  const int b = tile / tps, r = tile - b * tps;
-  const int ty = r / TW, tx = r - ty * TW;
-  return b * p.rows_per_batch + (2 * ty + (e >> 1)) * p.wino_W + 2 * tx + (e & 1);
-}
-template <int W, int R, bool WINO = false>
+template <int W, int R>
 __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArgs p) {
-  static_assert(!WINO || R == 4, "Winograd reducer: one tile (four pixels) per row lane");
   constexpr int QW = W / 4;                     // column quads per row
   constexpr int ROWS = 16 * R;                  // rows per block: 64 for large outputs, 16 when blocks would be too few
   __shared__ float2 rowp[ROWS][QW];               // per (row, quad) {sum, sum of squares} of the bf16-rounded outputs
@@ -1098,10 +1073,7 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
 #pragma unroll
   for (int r = 0; r < R; ++r) { rsum[r] = 0.f; rsq[r] = 0.f; }
   // row of the thread's r-th value
-  auto row_of = [&](int r) -> int {
-    if constexpr (WINO) return wino_row(p, blockIdx.y * 16 + ty, r);
-    else return mbase + ty + 16 * r;
-  };
+  auto row_of = [&](int r) -> int { return mbase + ty + 16 * r; };
   if (n < p.N) {
     // all partial loads of the thread's 4 rows are issued before any epilogue store (a store in between would fence the
     // next row's loads): 4 rows x 4 splits = 16 independent 16-B loads in flight per pass
@@ -1114,21 +1086,9 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
       s[r] = make_float4(0, 0, 0, 0);
       src[r] = p.ws + (size_t)m * p.N + n;
     }
-    if constexpr (WINO) {
-      // the tile's 16 position planes (16 independent 16-B loads), A^T M A -> its four pixels
-      const size_t pstride = (size_t)(p.M >> 2) * p.N;
-      const float* tsrc = p.ws + (size_t)(blockIdx.y * 16 + ty) * p.N + n;
-      float4 mp[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) mp[q] = *reinterpret_cast<const float4*>(tsrc + (size_t)q * pstride);
-      float4 y4[4];
-      wino_out4(mp, y4);
-#pragma unroll
-      for (int r = 0; r < R; ++r) s[r] = y4[r & 3];
-    }
     const size_t zstride = (size_t)p.M * p.N;
     constexpr int U = 16 / R;        // slices per pass: 16 independent 16-B loads in flight per thread either way
-    int z = WINO ? p.splitk : 0;
+    int z = 0;
     for (; z + U <= p.splitk; z += U) {
       float4 v[R][U];
 #pragma unroll
@@ -1217,9 +1177,7 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
 // (+ SiLU) tensor: the GroupNorm-apply launch of that norm (5.5-7.5 us each, 24 per forward) and its read of the raw tensor disappear.
 // Also files the fused-statistics partials of the raw output (gn_stats: one slab = the whole sample) for a later two-source consumer.
 // RPT rows per thread: rows_per_batch = 16 * RPT (256 -> 16, 64 -> 4).  Block = W columns (80 | 40): W / 4 column quads x 16 row lanes.
-// WINO (GemmArgs::wino): the slices are the 16 Winograd position planes; the thread's RPT values are the 4 pixels of RPT / 4 tiles
-// (tile ty + 16 q of the sample, q = r / 4; pixel e = r % 4), everything after the reduction unchanged.
-template <int RPT, int W, bool WINO = false>
+template <int RPT, int W>
 __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_gn_kernel(const GemmArgs p) {
   constexpr int QW = W / 4, ROWS = 16 * RPT;
   __shared__ float2 part[16][QW];        // per (row lane, column quad) {sum, sum of squares} over the thread's rows
@@ -1233,10 +1191,7 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_gn_kernel(const Gemm
   // residual rows, the norm's parameters — one memory round trip in front of the reduction, not four
   float4 v[RPT];
   // row of the thread's r-th value
-  auto row_of = [&](int r) -> int {
-    if constexpr (WINO) return wino_row(p, b * (ROWS / 4) + ty + 16 * (r >> 2), r & 3);
-    else return mbase + ty + 16 * r;
-  };
+  auto row_of = [&](int r) -> int { return mbase + ty + 16 * r; };
   float4 add = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
   const float4 rv = p.rowvec ? *reinterpret_cast<const float4*>(p.rowvec + (size_t)b * p.rowvec_bstride + n) : make_float4(0, 0, 0, 0);
   const float4 gam = *reinterpret_cast<const float4*>(p.fn_gamma + n), bet = *reinterpret_cast<const float4*>(p.fn_beta + n);
@@ -1244,22 +1199,6 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_gn_kernel(const Gemm
 #pragma unroll
   for (int r = 0; r < RPT; ++r)
     rr[r] = p.resid ? *reinterpret_cast<const uint2*>((const bf16_t*)p.resid + (size_t)row_of(r) * p.ldr + n) : make_uint2(0u, 0u);
-  if constexpr (WINO) {
-    static_assert(!WINO || RPT % 4 == 0, "Winograd reducer: whole tiles per row lane");
-    // tile by tile: the 16 position planes of a tile (16 independent 16-B loads in flight), A^T M A -> its four pixels
-    const size_t pstride = (size_t)(p.M >> 2) * p.N;
-#pragma unroll
-    for (int q = 0; q < RPT / 4; ++q) {
-      const float* tsrc = p.ws + (size_t)(b * (ROWS / 4) + ty + 16 * q) * p.N + n;
-      float4 mp[16];
-#pragma unroll
-      for (int z = 0; z < 16; ++z) mp[z] = *reinterpret_cast<const float4*>(tsrc + (size_t)z * pstride);
-      float4 y4[4];
-      wino_out4(mp, y4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[q * 4 + e] = y4[e];
-    }
-  } else {
   const float* src = p.ws + (size_t)(mbase + ty) * p.N + n;
   const size_t zstride = (size_t)p.M * p.N, rstride = (size_t)16 * p.N;
 #pragma unroll
@@ -1275,7 +1214,6 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_gn_kernel(const Gemm
     for (int r = 0; r < RPT; ++r) t[r] = *reinterpret_cast<const float4*>(src + (size_t)z * zstride + (size_t)r * rstride);
 #pragma unroll
     for (int r = 0; r < RPT; ++r) { v[r].x += t[r].x; v[r].y += t[r].y; v[r].z += t[r].z; v[r].w += t[r].w; }
-  }
   }
   add.x += rv.x; add.y += rv.y; add.z += rv.z; add.w += rv.w;
   // STATISTICS SOURCE: every FUSED producer of GroupNorm statistics in this file — the in-kernel epilogue (gs / gq), the plain reducer
@@ -1343,10 +1281,8 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_gn_kernel(const Gemm
 }
 // blocks of 40 columns where 80-column blocks would leave half the CUs without one and the groups / bins allow it
 static inline int reduce_gn_width(const GemmArgs& a) {
-  static const int forced = [] { const char* e = getenv("GILL_RED_GN_W"); return e ? atoi(e) : 0; }();     // tools
   const bool ok40 = 40 % a.fn_cg == 0 && (a.gn_stats == nullptr || 40 % a.gn_cg == 0) && a.N % 40 == 0;
-  if (forced == 80 || !ok40) return 80;
-  if (forced == 40) return 40;
+  if (!ok40) return 80;
   return ((int64_t)(a.N / 80) * (a.M / a.rows_per_batch) < 256) ? 40 : 80;
 }
 // geometries the fused reducer takes: whole samples of 64 or 256 rows, 80-column blocks of whole groups, the plain bf16 epilogue
@@ -1358,11 +1294,6 @@ bool gemm_fused_norm_ok(const GemmArgs& a) {
   return (rows == 64 || rows == 256) && M > 0 && M % rows == 0 && a.N % 80 == 0 && a.fn_cg >= 4 && a.fn_cg % 4 == 0 && 80 % a.fn_cg == 0 &&
          a.out_mode == OUT_BF16 && a.act == ACT_NONE && !a.resid_f32 && !a.row_stats && !a.ln_stats && a.alpha == 1.f && a.ldc == a.N &&
          (a.gn_stats == nullptr || (a.gn_cg >= 4 && a.gn_cg % 4 == 0 && 80 % a.gn_cg == 0));
-}
-
-static int env_int(const char* name) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : 0;
 }
 
 // width of the split-K reducer's blocks: 80 when the fused GroupNorm bins do not divide 64 (UNet: 5 / 10 / 20 / 40 channels)
@@ -1387,9 +1318,7 @@ static bool gemm_plain_pingpong(int M, int N, int K) {
 // ... and the launch's other conditions (tile_width() and gemm_launch_bn() used to test different things): the 8-wave plain kernel has
 // the lean bf16 row-major epilogue only
 static bool gemm_plain_pingpong_args(const GemmArgs& a) {
-  static const int forced_bm = env_int("GILL_GEMM_BM");
-  return !a.conv && gemm_plain_pingpong(a.M, a.N, a.K) && a.act == ACT_NONE && a.out_mode == OUT_BF16 && !a.resid_f32 && !a.wb_rows && !a.ln_stats &&
-         forced_bm == 0;
+  return !a.conv && gemm_plain_pingpong(a.M, a.N, a.K) && a.act == ACT_NONE && a.out_mode == OUT_BF16 && !a.resid_f32 && !a.wb_rows && !a.ln_stats;
 }
 
 // Tile width.  Tried and removed (numbers in profiles/r02_big_tile.md, profiles/r01_sweep_gemm_tiles.md): a 256 x 256 8-wave tile for
@@ -1415,7 +1344,6 @@ int gemm_row_planes(const GemmArgs& a) {
 }
 int gemm_gn_slab_rows(const GemmArgs& a) {
   if (a.splitk > 1 && a.fn_Y) return a.rows_per_batch;      // the fused reducer files one partial per (sample, bin)
-  if (a.wino) return 64;                                    // the Winograd reducer's blocks: 16 tiles = 64 pixels
   return a.splitk > 1 ? reduce_rows(a) : GN_SLAB_ROWS;
 }
 bool gemm_fused_gn_ok(int N, int cg) {
@@ -1428,10 +1356,6 @@ bool gemm_fused_gn_ok(int N, int cg) {
 
 // 3x3 convolutions whose row count is a multiple of 256 and whose width tiles by 160 run on the 256 x 160 ping-pong kernel
 // (GILL_GEMM_PP = 0: two co-resident 128 x 160 workgroups instead, the round-1 structure)
-static bool pp128_on() {
-  static const int v = [] { const char* e = getenv("GILL_GEMM_PP128"); return e ? atoi(e) : 1; }();
-  return v != 0;
-}
 // (round 4: 256 x 128 ping-pong tiles for the widths 160 does not divide — the VAE decoder's 128 / 256 / 512-channel convolutions: 484.8 /
 // 403.2 / 303.9 us against 464.8 / 406.1 / 301.0 us on the four-wave 128 x 128 tiles, VAE decode 12.74 vs 12.69 ms.  Not kept.)
 bool gemm_conv_pingpong(int rows_multiple_of, int Cout) {
@@ -1440,8 +1364,6 @@ bool gemm_conv_pingpong(int rows_multiple_of, int Cout) {
 }
 
 bool conv_k_chunked(int HW, int Cin, int Cout) {
-  static const int korder = [] { const char* v = getenv("GILL_CONV_KORDER"); return v ? atoi(v) : -1; }();
-  if (korder >= 0) return korder != 0;
   return HW >= 4096 && (int64_t)HW * Cin * 2 > (int64_t)4 << 20 && !gemm_conv_pingpong(HW, Cout);
 }
 
@@ -1463,7 +1385,9 @@ int gemm_pick_splitk_blk64(int M, int N, int K) {
   if (tiles >= 160) return 1;
   int s = (256 + tiles / 2) / tiles;
   while (s > 1 && ksteps / s < 8) --s;
-  return s > 16 ? 16 : s;
+  if (s > 16) s = 16;
+  // no empty trailing split (ksteps = 129, s = 16 -> 9 steps per split, split 15 would start past the end and write a zero plane)
+  return cdiv(ksteps, cdiv(ksteps, s));
 }
 
 int gemm_pick_splitk(int M, int N, int K, int act, bool plain, bool generic) {
@@ -1473,7 +1397,7 @@ int gemm_pick_splitk(int M, int N, int K, int act, bool plain, bool generic) {
   const int ksteps = K / BK;
   if (tiles >= 384 || ksteps < 8) return 1;
   {   // convs that gemm_launch_bn puts on 128 x 160 ping-pong tiles: one workgroup per CU, 256 slots
-    if (pp128_on() && !generic && (plain ? gemm_plain_pingpong(M, N, K) : gemm_conv_pingpong(M, N)) && tiles <= 256 && M % 128 == 0) {
+    if (!generic && (plain ? gemm_plain_pingpong(M, N, K) : gemm_conv_pingpong(M, N)) && tiles <= 256 && M % 128 == 0) {
       int s = (256 + tiles / 2) / tiles;
       const int min_steps = (M <= 256 || tiles < 64) ? 4 : 24;
       if (s > ksteps / min_steps) s = ksteps / min_steps;
@@ -1491,44 +1415,15 @@ int gemm_pick_splitk(int M, int N, int K, int act, bool plain, bool generic) {
   // each split pays an fp32 partial write + a reduce pass: keep >= 24 K steps per split (measured: K = 1280 GEMMs lose
   // from any split, K >= 5120 convs win up to 4-8 ways), except for skinny weight-streaming GEMMs (OPT, M <= 256)
   // where filling every CU with HBM requests matters more than the tiny partials
-  static const int min_env = env_int("GILL_GEMM_MINSTEPS");
-  const int min_steps = (M <= 256 || tiles < 64) ? 4 : (min_env > 0 ? min_env : 24);
+  const int min_steps = (M <= 256 || tiles < 64) ? 4 : 24;
   if (s > ksteps / min_steps) s = ksteps / min_steps;
   if (s > 16) s = 16;
   if (s < 1) s = 1;
   return s;
 }
 
-bool gemm_wino_ok(int M, int N, int Cin, int rows_per_batch, int W) {
-  if (W <= 0 || W % 2 != 0 || rows_per_batch % W != 0 || (rows_per_batch / W) % 2 != 0) return false;
-  // whole samples, 16-tile reducer blocks inside one sample, the 128-row tiles of the split-K GEMM on the tile rows, whole K steps per position
-  return M > 0 && M % rows_per_batch == 0 && rows_per_batch % 64 == 0 && (M / 4) % 128 == 0 && N % 160 == 0 && Cin % 64 == 0 && 16 * Cin >= 2560;
-}
-
 int gemm_splitk_reduce_launch(const GemmArgs& a, hipStream_t s) {
   GILL_REQUIRE(a.splitk > 1 && a.ws != nullptr, "split-K reducer: no partials");
-  if (a.wino) {
-    GILL_REQUIRE(a.splitk == 16 && gemm_wino_ok(a.M, a.N, a.K / 16, a.rows_per_batch, a.wino_W) && !a.row_stats && !a.ln_stats && a.out_mode == OUT_BF16,
-                 "Winograd reducer: 16 position planes of a supported geometry, bf16 row-major epilogue");
-    if (a.fn_Y) {
-      GILL_REQUIRE(gemm_fused_norm_ok(a) && a.fn_gamma && a.fn_beta, "split-K reducer: unsupported fused GroupNorm geometry");
-      const int w = reduce_gn_width(a);
-      const dim3 rg(a.N / w, a.M / a.rows_per_batch);
-      if (a.rows_per_batch == 256 && w == 80) hipLaunchKernelGGL((gemm_splitk_reduce_gn_kernel<16, 80, true>), rg, dim3(320), 0, s, a);
-      else if (a.rows_per_batch == 256) hipLaunchKernelGGL((gemm_splitk_reduce_gn_kernel<16, 40, true>), rg, dim3(160), 0, s, a);
-      else if (w == 80) hipLaunchKernelGGL((gemm_splitk_reduce_gn_kernel<4, 80, true>), rg, dim3(320), 0, s, a);
-      else hipLaunchKernelGGL((gemm_splitk_reduce_gn_kernel<4, 40, true>), rg, dim3(160), 0, s, a);
-      GILL_CHECK_HIP(hipGetLastError());
-      return 0;
-    }
-    const int rw = reduce_width(a);
-    const dim3 rg(cdiv(a.N, rw), a.M / 64);
-    if (rw == 160) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<160, 4, true>), rg, dim3(640), 0, s, a);
-    else if (rw == 80) hipLaunchKernelGGL((gemm_splitk_reduce_kernel<80, 4, true>), rg, dim3(320), 0, s, a);
-    else hipLaunchKernelGGL((gemm_splitk_reduce_kernel<64, 4, true>), rg, dim3(256), 0, s, a);
-    GILL_CHECK_HIP(hipGetLastError());
-    return 0;
-  }
   if (a.fn_Y) {
     GILL_REQUIRE(gemm_fused_norm_ok(a) && a.fn_gamma && a.fn_beta, "split-K reducer: unsupported fused GroupNorm geometry");
     const int w = reduce_gn_width(a);
@@ -1627,14 +1522,12 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   d.a.splitk = sk;
   GemmArgs red = d.a;       // what the split-K reducer sees: the output tensor, whatever the conv kernel's row space is
   // UPS4 (a.ups == 2): the kernel's rows are the SOURCE pixels of one parity class, blockIdx.z the class
-  // Winograd (a.wino): the kernel's rows are the 2 x 2 tiles (M / 4), blockIdx.y the transform position
   const int ncls = (a.conv && a.ups == 2) ? 4 : 1;
-  const int Mk = a.M / ncls / (a.wino ? 4 : 1);
+  const int Mk = a.M / ncls;
   d.a.M = Mk;
-  d.a.rows_per_batch = a.rows_per_batch / ncls / (a.wino ? 4 : 1);
+  d.a.rows_per_batch = a.rows_per_batch / ncls;
   d.tiles_n = cdiv(a.N, BN);
-  // 64-row tiles for plain GEMMs whose 128-row tiling leaves CUs without a tile (GILL_GEMM_BM = 64 | 128 forces it: tools/soak.py)
-  static const int forced_bm = env_int("GILL_GEMM_BM");
+  // 64-row tiles for plain GEMMs whose 128-row tiling leaves CUs without a tile
   d.nwv = 4;
   // (tile_width() counts 128 x 160 tiles when it hands these GEMMs BN = 128, this rule counts 128 x 128 tiles: an 8192 x 640 GEMM
   // — 256 vs 320 — therefore lands on the 4-wave 128 x 128 tile, not the 64-row one; measured better that way: 567.8 vs 575.5 ms)
@@ -1651,21 +1544,19 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   if (a.out_mode == OUT_SOFTMAX80) { d.nwv = 4; d.mi = 2; }      // (see gemm_launch_stages)
   // (round 4: the 64-row four-wave tile with its 3-deep ring — 96 instead of 64 KB in flight per CU — on ALL GEGLU / QKV / 128-wide plain
   // GEMMs, not only the few-tile ones: loop 460.4 -> 469.4 / 464.8 / 460.7 ms.  Not kept.)
-  if (forced_bm == 128) { d.nwv = 4; d.mi = 4; }
-  if (forced_bm == 64 && !a.conv && sk == 1) { d.nwv = 2; d.mi = 4; }
   // 3x3 convolutions: 256 x 160 tile with the ping-pong main loop, one workgroup per CU (GILL_GEMM_PP = 0 keeps the two
   // co-resident 128 x 160 workgroups)
-  if (BN == 160 && a.conv && gemm_conv_pingpong(Mk, a.N) && forced_bm == 0) {
+  if (BN == 160 && a.conv && gemm_conv_pingpong(Mk, a.N)) {
     d.nwv = 8;
     // Where the 256-row tiling x split-K gives at most 128 workgroups (UNet levels 1-3 at the 8-sample batch), run
     // 128 x 160 ping-pong tiles (eight waves of 32 x 80); gemm_pick_splitk() then aims at 256 workgroups of those, i.e. half the
     // split factor: half the fp32 partials (none at level 1)
     // (loop 561.1 -> 558.0 ms; GILL_GEMM_PP128 = 0 keeps the 256-row tile with twice the split)
-    if (pp128_on() && (int64_t)cdiv(Mk, 256) * ncls * d.tiles_n * sk <= 128 && Mk % 128 == 0) d.mi = 2;
+    if ((int64_t)cdiv(Mk, 256) * ncls * d.tiles_n * sk <= 128 && Mk % 128 == 0) d.mi = 2;
   }
   if (BN == 160 && gemm_plain_pingpong_args(a)) {
     d.nwv = 8; d.mi = 4;
-    if (((int64_t)cdiv(Mk, 256) * d.tiles_n * sk <= 128 && pp128_on()) || Mk % 256 != 0) d.mi = 2;
+    if (((int64_t)cdiv(Mk, 256) * d.tiles_n * sk <= 128) || Mk % 256 != 0) d.mi = 2;
   }
   // (round 4: the short-K GEGLU / QKV GEMMs on 256 x 128 / 128 x 128 ping-pong tiles, one N tile per workgroup: loop 464.0 -> 478.0 / 480.4 ms
   // (GEGLU), 467.0 / 468.8 ms (QKV) — ten K steps do not amortise a prologue and an epilogue that no second workgroup covers.  Not kept.)
@@ -1677,8 +1568,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   // latency and the epilogue.  Let one workgroup walk `npw` N tiles back to back instead: the ring is staged across tile
   // boundaries, so the loads of tile t+1 fly during the epilogue of tile t.  Keep ~2 workgroups per CU.
   d.npw = 1;
-  static const int npw_off = env_int("GILL_GEMM_NPW_OFF");
-  if (!a.conv && sk == 1 && d.nwv != 8 && !a.gn_stats && d.tiles_n >= 2 && !npw_off) {
+  if (!a.conv && sk == 1 && d.nwv != 8 && !a.gn_stats && d.tiles_n >= 2) {
     int groups = cdiv(512, tiles_m);   // ~2 workgroups per CU
     if (groups < 1) groups = 1;
     if (groups > d.tiles_n) groups = d.tiles_n;
@@ -1796,12 +1686,6 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
   }
   GILL_REQUIRE(a.fn_Y == nullptr || (a.splitk > 1 && gemm_fused_norm_ok(a)), "fused GroupNorm output: split-K GEMMs of a supported geometry only");
   GILL_REQUIRE(a.C != nullptr || a.fn_Y != nullptr || a.out_mode == OUT_QKV, "no output tensor");
-  if (a.wino) {
-    GILL_REQUIRE(!a.conv && a.splitk == 16 && a.K % 16 == 0 && a.K1 == a.K && a.lda == a.K && gemm_wino_ok(a.M, a.N, a.K / 16, a.rows_per_batch, a.wino_W),
-                 "Winograd GEMM: 16-way split of K = 16 Cin over V [tiles][16][Cin] of a supported geometry");
-    GILL_REQUIRE(a.out_mode == OUT_BF16 && a.act == ACT_NONE && !a.resid_f32 && !a.row_stats && !a.ln_stats && !a.wb_rows && a.alpha == 1.f,
-                 "Winograd GEMM: bf16 row-major epilogue only");
-  }
   if (a.splitk > 1) {
     GILL_REQUIRE(a.ws != nullptr, "split-K workspace missing");
     GILL_REQUIRE(a.act != ACT_GEGLU, "split-K cannot be combined with GEGLU");
@@ -1815,7 +1699,7 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
                  "softmax epilogue: N % 160 == 0, no split-K, folded-LayerNorm operands and a bias vector required");
   if (a.out_mode == OUT_QKV) GILL_REQUIRE(a.dp % 8 == 0 && a.heads > 0 && a.ntok > 0, "bad QKV scatter geometry (padded head dim must be a multiple of 8)");
   if (a.w_blk64) {
-    GILL_REQUIRE(!a.conv && a.N % 64 == 0 && a.K1 == a.K && !a.gn_stats && !a.row_stats && !a.ln_stats && !a.wb_rows && !a.wino && !a.fn_Y &&
+    GILL_REQUIRE(!a.conv && a.N % 64 == 0 && a.K1 == a.K && !a.gn_stats && !a.row_stats && !a.ln_stats && !a.wb_rows && !a.fn_Y &&
                      a.act != ACT_GEGLU && a.out_mode != OUT_SOFTMAX80,
                  "64 x 64-blocked weights (STREAM64): plain GEMMs with the row-major, QKV or split-K epilogue only");
     return gemm_launch_stream64(a, s);

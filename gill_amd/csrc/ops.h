@@ -72,17 +72,7 @@ struct GemmArgs {
   // fn_Y [M][N] bf16 = [silu]((C - mean) * rstd * fn_gamma + fn_beta) with mean / rstd over (rows_per_batch rows, fn_cg channels).
   // C may then be null (the raw tensor has no other reader).  gemm_fused_norm_ok() says which geometries the reducer takes.
   bf16_t* fn_Y = nullptr; const float* fn_gamma = nullptr; const float* fn_beta = nullptr; float fn_eps = 1e-5f; int fn_silu = 0; int fn_cg = 0;
-  // Winograd F(2x2, 3x3) (wino.hip): a stride-1 3x3 convolution as a 16-way split-K plain GEMM whose split z multiplies the operands of
-  // transform position z.  M = OUTPUT pixels (rows_per_batch = H * W of one sample, wino_W = map width); A = V [M / 4 tiles][16][Cin]
-  // (wino_input_transform_launch), lda = K = 16 Cin; W = U [N][16][Cin] (wino_weight_transform_launch); splitk == 16; ws holds the 16
-  // fp32 planes [16][M / 4][N].  The split-K reducers apply A^T M A instead of the sum and then their usual epilogue.
-  int wino = 0; int wino_W = 0;
 };
-// U [Cout][16][Cin] = G g G^T from OIHW weights; V [B * H/2 * W/2][16][C] = B^T d B of an NHWC activation (tiles in (sample, ty, tx) order)
-int wino_weight_transform_launch(const void* w_oihw, int dtype, int Cout, int Cin, bf16_t* U, hipStream_t s);
-int wino_input_transform_launch(const bf16_t* x, int B, int H, int W, int C, bf16_t* V, hipStream_t s);
-// geometries the Winograd reducers take (whole 2 x 2 tiles, 16 tiles = 64 output rows per reducer block inside one sample)
-bool gemm_wino_ok(int M, int N, int Cin, int rows_per_batch, int W);
 bool gemm_fused_norm_ok(const GemmArgs& a);
 int gemm_launch(const GemmArgs& a, hipStream_t s);
 #define GN_SLAB_ROWS 64        // rows per fused GroupNorm-statistics partial of the in-kernel epilogue
@@ -93,12 +83,12 @@ int gemm_gn_slab_rows(const GemmArgs& a);
 int gemm_row_planes(const GemmArgs& a);
 // can a GEMM with N output columns produce fused GroupNorm statistics for bins of cg channels?
 bool gemm_fused_gn_ok(int N, int cg);
-// heuristic split-K factor for under-filled grids
+// heuristic split-K factor for under-filled grids.  plain: not a conv (64-row tiles available); generic: 128-row 4-wave tiles only (the fp8 conv
+// kernel): neither the 64-row nor the ping-pong rules
 int gemm_pick_splitk(int M, int N, int K, int act, bool plain = false, bool generic = false);
 // STREAM64 (gemm.hip): which weight matrices are stored 64 x 64-blocked, and the split-K factor of a GEMM on one
 bool gemm_stream64_weights(int N, int K);
-int gemm_pick_splitk_blk64(int M, int N, int K);   // plain: not a conv (64-row tiles available);
-                                                                                               // generic: 128-row 4-wave tiles only (the fp8 conv kernel): neither the 64-row nor the ping-pong rules
+int gemm_pick_splitk_blk64(int M, int N, int K);
 
 // split-K reducer of gemm_launch on its own (partials a.ws [splitk][M][N] fp32 written by another kernel: conv_fp8.hip)
 int gemm_splitk_reduce_launch(const GemmArgs& a, hipStream_t s);

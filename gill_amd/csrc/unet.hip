@@ -31,8 +31,6 @@ struct ConvW {
   bf16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; int chunked = 0; /* K order: GemmArgs::k_chunked */ int ups4 = 0; /* w = the 4-tap parity-class form (GemmArgs::ups == 2) */
   // gill_unet_config.fp8_convs: e4m3 weights [cout][kpad] in conv_fp8.hip's K order + per-output-channel de-quantisation scale
   unsigned char* w8 = nullptr; float* cs = nullptr; int kpad = 0;
-  // Winograd F(2x2, 3x3) form [cout][16][cin] (wino.hip) beside `w`, for the maps conv() runs that way (16 x 16: UNet level 2 at 64 x 64 latents)
-  bf16_t* wu = nullptr;
 };
 struct LinW { bf16_t* w = nullptr; float* b = nullptr; int out = 0, in = 0; };
 struct NormW { float* g = nullptr; float* b = nullptr; int c = 0; };
@@ -323,16 +321,6 @@ static bool lnproj_on() {
   static const bool on = [] { const char* e = getenv("GILL_UNET_LNPROJ"); return !(e && e[0] == '0'); }();
   return on;
 }
-// GILL_UNET_FFN_PRE=0: attn2.to_out + residual of the level-0 blocks as its own GEMM in front of the fused feed-forward kernel
-static bool ffn_pre_on() {
-  static const bool on = [] { const char* e = getenv("GILL_UNET_FFN_PRE"); return !(e && e[0] == '0'); }();
-  return on;
-}
-// GILL_UNET_GNFOLD=0: the level-0 transformer blocks' GroupNorm as its own pass in front of the fused projection kernel
-static bool gnfold_on() {
-  static const bool on = [] { const char* e = getenv("GILL_UNET_GNFOLD"); return !(e && e[0] == '0'); }();
-  return on;
-}
 // GILL_UNET_XALG=0: attn2 of levels 1-3 as to_q + attention kernel + to_out instead of the two per-sample GEMMs (xalg_fold_kernel)
 static bool xalg_on() {
   static const bool on = [] { const char* e = getenv("GILL_UNET_XALG"); return !(e && e[0] == '0'); }();
@@ -358,20 +346,10 @@ struct Loader {
   // hw: pixels per sample of the conv's INPUT (decides the K order, see GemmArgs::k_chunked)
   // ups4: the conv follows a nearest-2x upsample — store the four pre-summed 2x2-tap kernels instead (gemm.hip "UPS4";
   // GILL_CONV_UPS4 = 0 keeps the 9-tap gather over the upsampled grid)
-  // wino: a stride-1 convolution without a fused 1x1 segment — keep the Winograd form of its weights too where the map size qualifies
-  // (16 x 16 maps: 256 rows per sample, the geometry the split-K reducers' fused GroupNorm takes; decided per call in conv())
-  int conv3(const std::string& p, int cin, int cout, int hw, ConvW* c, bool f8 = false, bool ups4 = false, bool wino = false) {
+  int conv3(const std::string& p, int cin, int cout, int hw, ConvW* c, bool f8 = false, bool ups4 = false) {
     c->cin = cin; c->cout = cout; c->chunked = conv_k_chunked(hw, cin, cout) ? 1 : 0;
     const gill_tensor* t;
     GILL_TRY(wt.get(p + ".weight", (int64_t)cout * cin * 9, &t));
-    // OPT-IN (GILL_UNET_WINO=1).  Measured in round 5 (profiles/r05_winograd.md): parity-green, but at the 8-sample batch the four level-2
-    // shapes run 1.04 / 0.93 / 0.81 / 0.77 of the direct convolution stand-alone and the denoise loop does not move (456.5 vs 456.4 ms): the input
-    // transform launch, twice the fp32 partial planes and 20-K-step tiles eat what 16/36 of the multiply-adds save.  No-go as a default.
-    static const bool wino_on = [] { const char* e = getenv("GILL_UNET_WINO"); return e && e[0] == '1'; }();
-    if (wino && wino_on && !f8 && hw == 256 && gemm_wino_ok(2 * hw, cout, cin, hw, 16)) {
-      GILL_TRY(pool.alloc(&c->wu, (size_t)16 * cout * cin, false));
-      GILL_TRY(wino_weight_transform_launch(t->data, t->dtype, cout, cin, c->wu, s));
-    }
     static const int ups4_on = [] { const char* v = getenv("GILL_CONV_UPS4"); return v ? atoi(v) : 1; }();
     if (ups4 && ups4_on && !f8) {
       c->ups4 = 1; c->chunked = 0;
@@ -410,9 +388,9 @@ struct Loader {
     r->cin = cin; r->cout = cout;
     f8 = f8 && cin % 64 == 0 && cout % 64 == 0;
     GILL_TRY(norm(p + ".norm1", cin, &r->n1));
-    GILL_TRY(conv3(p + ".conv1", cin, cout, hw, &r->c1, f8, false, true));
+    GILL_TRY(conv3(p + ".conv1", cin, cout, hw, &r->c1, f8));
     GILL_TRY(norm(p + ".norm2", cout, &r->n2));
-    GILL_TRY(conv3(p + ".conv2", cout, cout, hw, &r->c2, f8, false, cin == cout));     // (cin != cout: conv2 runs with the fused 1x1 shortcut)
+    GILL_TRY(conv3(p + ".conv2", cout, cout, hw, &r->c2, f8));
     r->has_sc = (cin != cout);
     if (r->has_sc) GILL_TRY(lin(p + ".conv_shortcut", cout, cin, &r->sc));
     if (r->has_sc && !f8) {   // (fp8 mode: the 1x1 shortcut stays a bf16 GEMM of its own whose output is conv2's residual)
@@ -523,7 +501,7 @@ struct Loader {
       GILL_TRY(pool.alloc(&x->w1c, (size_t)8 * C * C, false));
       GILL_TRY(pool.alloc(&x->b1c, (size_t)8 * C, false));
       GILL_TRY(pool.alloc(&x->w2p, (size_t)4 * C * C, false));
-      if (ffn_pre_on() && hdp == 384) GILL_TRY(pool.alloc(&x->wpp, (size_t)C * C, false));
+      if (hdp == 384) GILL_TRY(pool.alloc(&x->wpp, (size_t)C * C, false));
       GILL_TRY(ffn_relayout_launch(x->wff1, x->bff1, x->wfo, x->w1c, x->b1c, x->w2p, x->wpp, s));
       x->w1c_kperm = x->wpp != nullptr;
     }
@@ -729,7 +707,6 @@ struct UNetRun {
   int gemm(GemmArgs& g, RowStats* rs = nullptr, Tensor* ys = nullptr, FusedNorm* fn = nullptr) {
     if (dry) return 0;
     pick_sk(g);
-    if (g.wino) g.splitk = 16;      // (the split IS the transform position)
     // (split-K partials come from 128-row tiles: not where a sample's rows are fewer — the 8 x 8 maps of the mid block)
     if (g.out_mode == OUT_SOFTMAX80 || (g.wb_rows && g.wb_rows % 128 != 0)) g.splitk = 1;
     if (fn && g.splitk > 1) {
@@ -805,25 +782,6 @@ struct UNetRun {
   // 3x3 conv (pad 1) over x1 (++ x2): stride 1|2, optional fused nearest-2x upsample
   int conv(const Tensor& x1, const Tensor* x2, const ConvW& w, int stride, int ups, const float* rowvec, int rv_bstride,
            const bf16_t* resid, Tensor& y, FusedNorm* fn = nullptr) {
-    if (w.wu && stride == 1 && !ups && !x2 && x1.C == w.cin && gemm_wino_ok(Bx * y.H * y.W, w.cout, w.cin, y.H * y.W, y.W) &&
-        (size_t)4 * Bx * y.H * y.W * w.cout <= m->splitk_ws_floats) {
-      // Winograd F(2x2, 3x3): V = B^T d B of the normalised input, the 16 position GEMMs as ONE 16-way split-K plain GEMM over
-      // K = 16 Cin (16/36 of the multiply-adds), A^T M A + the usual epilogue in the split-K reducer (wino.hip)
-      const size_t mk = m->arena.mark();
-      bf16_t* V = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)4 * Bx * y.H * y.W * w.cin);
-      if (!dry) GILL_TRY(wino_input_transform_launch(x1.p, Bx, x1.H, x1.W, w.cin, V, s));
-      GemmArgs g;
-      g.M = Bx * y.H * y.W; g.N = w.cout; g.K = 16 * w.cin; g.K1 = g.K; g.A = V; g.lda = g.K;
-      g.W = w.wu; g.bias = w.b;
-      g.rowvec = rowvec; g.rows_per_batch = y.H * y.W; g.rowvec_bstride = rv_bstride;
-      g.resid = resid; g.ldr = w.cout;
-      g.C = y.p; g.ldc = w.cout;
-      g.wino = 1; g.wino_W = y.W;
-      fuse_stats(g, y);
-      const int rc = gemm(g, nullptr, &y, fn);
-      m->arena.release(mk);
-      return rc;
-    }
     GemmArgs g;
     g.conv = 1; g.IH = x1.H; g.IW = x1.W; g.OH = y.H; g.OW = y.W; g.Cin = w.cin; g.stride = stride; g.ups = ups;
     g.M = Bx * y.H * y.W; g.N = w.cout; g.K = 9 * w.cin;
@@ -935,7 +893,7 @@ struct UNetRun {
     // statistics: the stand-alone pass (13 us, 21 MB read + 21 MB written per level-0 block) becomes a 640-float table per sample
     float* gn_ss = nullptr;
     bool gn_folded = false;
-    if (lnproj && gnfold_on() && HW % 128 == 0) gn_ss = (float*)m->arena.alloc(sizeof(float) * (size_t)Bx * 2 * C);
+    if (lnproj && HW % 128 == 0) gn_ss = (float*)m->arena.alloc(sizeof(float) * (size_t)Bx * 2 * C);
     if (pre && !shared) n = *pre;
     else GILL_TRY(gnorm(x, nullptr, w.gn, 1e-6f, 0, n, 0.f, gn_ss, &gn_folded));
     Bx = Bfull;

@@ -20,8 +20,11 @@ def _bf(t: torch.Tensor) -> torch.Tensor:
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
-         alpha: float = 1.0, act: str = "none", out_f32: bool = False, splitk: int = 0) -> torch.Tensor:
-  """act(alpha * a @ w.T + bias + resid); a (M,K) bf16, w (N,K) bf16, bias (N) fp32, resid (M,N) bf16."""
+         alpha: float = 1.0, act: str = "none", out_f32: bool = False, splitk: int = 0, row_major: bool = False) -> torch.Tensor:
+  """act(alpha * a @ w.T + bias + resid); a (M,K) bf16, w (N,K) bf16, bias (N) fp32, resid (M,N) bf16.
+  row_major: keep weight-streaming shapes (M <= 256, N * K >= 4 Mi) on the general tiles instead of the 64 x 64-blocked STREAM64 copy."""
+  if row_major:
+    splitk = -1 if splitk <= 1 else -splitk
   a, w = _bf(a), _bf(w)
   M, K = a.shape
   Nn = w.shape[0]
@@ -93,26 +96,6 @@ def conv3x3_gn(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tenso
   N.check(N.lib().gill_op_conv3x3_gn(N.ptr(x), N.ptr(w), N.ptr(bias), N.ptr(resid), N.ptr(gamma), N.ptr(beta), groups, float(eps),
                                      int(silu), N.ptr(y_raw), N.ptr(y_norm), B, H, W, Cin, Cout, splitk, N.current_stream()))
   return y_raw, y_norm
-
-
-def conv3x3_wino(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None,
-                 resid: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
-                 groups: int = 32, eps: float = 1e-5, silu: bool = True, want_raw: bool = True):
-  """Stride-1 3x3 convolution in Winograd F(2x2, 3x3) form (csrc/wino.hip).  x (B,H,W,Cin) bf16 NHWC, rowvec (B,Cout) fp32.
-  gamma is None: returns y = conv + bias + rowvec + resid.  Else returns (y_raw or None, y_norm) like conv3x3_gn."""
-  x = _bf(x)
-  B, H, W, Cin = x.shape
-  Cout = w_oihw.shape[0]
-  nan = float("nan")
-  fused = gamma is not None
-  y_raw = torch.full((B, H, W, Cout), nan, device=x.device, dtype=torch.bfloat16) if (want_raw or not fused) else None
-  y_norm = torch.full((B, H, W, Cout), nan, device=x.device, dtype=torch.bfloat16) if fused else None
-  f = lambda t: None if t is None else t.float().contiguous()   # noqa: E731
-  w, bias, rowvec, gamma, beta = f(w_oihw), f(bias), f(rowvec), f(gamma), f(beta)
-  resid = None if resid is None else _bf(resid)
-  N.check(N.lib().gill_op_conv3x3_wino(N.ptr(x), N.ptr(w), N.ptr(bias), N.ptr(rowvec), N.ptr(resid), N.ptr(gamma), N.ptr(beta), groups,
-                                       float(eps), int(silu), N.ptr(y_raw), N.ptr(y_norm), B, H, W, Cin, Cout, N.current_stream()))
-  return (y_raw, y_norm) if fused else y_raw
 
 
 def conv3x3_shortcut(x1: torch.Tensor, w_oihw: torch.Tensor, xs1: torch.Tensor, w_sc: torch.Tensor, bias: Optional[torch.Tensor] = None,

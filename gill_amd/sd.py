@@ -42,6 +42,10 @@ class GillSDPipeline:
     if self.device.type != "cuda":
       raise N.GillNativeError("GillSDPipeline runs only on an MI355X through libgill_amd")
     self.max_batch = max_batch
+    #  the captured denoise loop wants DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, which ROCm reads when HIP initialises: entry points call
+    # gill_amd.configure_hip_runtime() first; a caller that did not gets ONE RuntimeWarning here instead of a silent 1.2 % (README "Runtime setting")
+    from . import configure_hip_runtime
+    configure_hip_runtime(warn=True)
     self.uncond_embeds = uncond_embeds.to(self.device, torch.bfloat16).reshape(1, cfg.ctx_len, cfg.cross_attention_dim).contiguous()
     ccfg = N.gill_unet_config(in_channels=cfg.in_channels, out_channels=cfg.out_channels,
                               layers_per_block=cfg.layers_per_block, cross_attention_dim=cfg.cross_attention_dim,

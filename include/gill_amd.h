@@ -209,7 +209,9 @@ int gill_pndm_schedule(int num_steps, int32_t* timesteps_out, double* alphas_cum
  * parity tests can pin each against the CPU oracle.  All bf16 unless noted.
  * ------------------------------------------------------------------------------------------ */
 /* C[M,N] = act(alpha * A[M,K] . W[N,K]^T + bias[N] + resid[M,N]); act: 0 none 1 relu 2 gelu(erf) 3 silu.
- * out_f32: C is fp32 instead of bf16.  splitk: 0 = auto. */
+ * out_f32: C is fp32 instead of bf16.  splitk: 0 = auto, n > 1 = forced n-way split; < 0 = the general row-major tiles even for the
+ * weight-streaming shapes (M <= 256, N * K >= 4 Mi) that otherwise run on a 64 x 64-blocked copy of W (-1: auto split, -n: n ways).
+ * Split-K launches share one grow-only workspace owned by the library: one caller at a time (as everywhere on this path). */
 int gill_op_gemm(const void* A, const void* W, const float* bias, const void* resid_bf16, void* C, int M, int N, int K,
                  float alpha, int act, int out_f32, int splitk, void* stream);
 /* GEGLU projection: W (2*inner, K) in diffusers order [value rows | gate rows], bias (2*inner) ->
@@ -228,14 +230,6 @@ int gill_op_conv3x3(const void* x1, int C1, const void* x2, int C2, const float*
 int gill_op_conv3x3_gn(const void* x, const float* w_oihw, const float* bias, const void* resid, const float* gamma,
                        const float* beta, int groups, float eps, int silu, void* y_raw, void* y_norm, int B, int H, int W,
                        int Cin, int Cout, int splitk, void* stream);
-/* The same stride-1 convolution in Winograd F(2x2, 3x3) form (16/36 of the multiply-adds; csrc/wino.hip): G g G^T, B^T d B, the 16
- * position GEMMs as one 16-way split-K GEMM, A^T M A + epilogue in the split-K reducer.  gamma != NULL: the consuming GroupNorm (+ SiLU) runs
- * in the reducer as in gill_op_conv3x3_gn (H * W in {64, 256}; y_raw optional); gamma == NULL: y_raw = conv(x) + bias + rowvec[b] + resid.
- * x (B,H,W,Cin) bf16 NHWC, w (Cout,Cin,3,3) fp32, rowvec (B,Cout) fp32 optional; H, W even, B * H * W / 4 % 128 == 0, Cout % 160 == 0,
- * Cin % 64 == 0.  Replaces the same diffusers ResnetBlock2D convolutions (reference call site gill/custom_sd.py:633-638).  Synchronises. */
-int gill_op_conv3x3_wino(const void* x, const float* w_oihw, const float* bias, const float* rowvec, const void* resid,
-                         const float* gamma, const float* beta, int groups, float eps, int silu, void* y_raw, void* y_norm, int B,
-                         int H, int W, int Cin, int Cout, void* stream);
 /* conv3x3 (stride 1, pad 1) of x1 ++ x2 plus a fused 1x1 convolution of xs1 ++ xs2 (ResnetBlock2D.conv2 + conv_shortcut as one
  * implicit GEMM): y (B,IH,IW,Cout) bf16 NHWC; w_oihw (Cout, C1+C2, 3, 3) fp32, w_sc (Cout, CS1+CS2) fp32.  Synchronises. */
 int gill_op_conv3x3_shortcut(const void* x1, int C1, const void* x2, int C2, const float* w_oihw, const float* bias,

@@ -544,14 +544,12 @@ def test_safety_checker_vs_oracle(cuda):
 
 
 @SLOW
-def test_pingpong_conv_kernel_leaves_the_unet_bit_identical(cuda, tmp_path):
-  """gemm_kernel<8,160,CONV,EPI,3> (256 x 160 ping-pong tile) against the 128-row kernel it replaced, through the whole SD-1.5
-  UNet loop (fused GroupNorm statistics, time-embedding rows, residuals, fused shortcuts, split-K partials, stride-2 and
-  upsampling convs): same per-element summation order (the K order is pinned to tap-major for every run: the 128-row kernel
-  would otherwise pick chunk-major for the largest level-0 convs), so the latents of a 3-step CFG run must have the same digest
-  with GILL_GEMM_PP=1 and =0 as long as the split-K factors are the same (GILL_GEMM_PP128=0).  The default configuration also runs
-  the 128 x 160 ping-pong tile with half the split factor at levels 1-3: a different (still fixed) summation split, so it is held
-  to a distance instead (the switches are read once per process, hence subprocesses)."""
+def test_pingpong_conv_kernel_vs_128_row_kernel_through_the_unet_loop(cuda, tmp_path):
+  """gemm_kernel<8,160,CONV,EPI,3> (the 256 x 160 / 128 x 160 ping-pong tiles, default) against the four-wave 128-row kernel it replaced
+  (GILL_GEMM_PP=0, read once per process, hence subprocesses), through the whole SD-1.5 UNet loop (fused GroupNorm statistics, time-embedding
+  rows, residuals, fused shortcuts, split-K partials, stride-2 and upsampling convs).  The two use different (each fixed) split-K factors and
+  K orders, so the latents of a 3-step CFG run are held to a distance; the operator-level bit identity at equal split factors is
+  test_conv3x3_pingpong_short_k_and_bit_identity."""
   import subprocess, sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   code = ("import hashlib, os, sys, torch; sys.path.insert(0, %r)\n"
@@ -568,17 +566,16 @@ def test_pingpong_conv_kernel_leaves_the_unet_bit_identical(cuda, tmp_path):
           "torch.save(lat.float().cpu(), os.environ['GILL_TEST_OUT'])\n"
           "print('DIGEST', hashlib.sha256(lat.float().cpu().numpy().tobytes()).hexdigest())\n") % root
   digests, lats = [], []
-  for k, (pp, pp128) in enumerate((("0", "0"), ("1", "0"), ("1", "1"))):
+  for k, pp in enumerate(("0", "1")):
     out = str(tmp_path / f"lat{k}.pt")
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GILL_GEMM_PP=pp, GILL_GEMM_PP128=pp128, GILL_CONV_KORDER="0", GILL_TEST_OUT=out),
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GILL_GEMM_PP=pp, GILL_TEST_OUT=out),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0])
     lats.append(torch.load(out))
-  assert digests[0] == digests[1], digests
-  rel = ((lats[2] - lats[0]).norm() / lats[0].norm()).item()
-  print(f"[128-row ping-pong tile, half the split factors] rel-L2 vs the 128-row kernel {rel:.3e}")
-  # the same distance ANY change of the split-K factors causes on this random-weight UNet (tools/chaos_probe.py: the 128-row kernel
-  # with GILL_GEMM_MINSTEPS = 48 or 12 instead of 24 lands 2.9e-2 / 3.1e-2 away after the same 3 steps): rounding-order noise
+  rel = ((lats[1] - lats[0]).norm() / lats[0].norm()).item()
+  print(f"[ping-pong tiles, their split factors] rel-L2 vs the 128-row kernel {rel:.3e}")
+  # the same distance ANY change of the split-K factors causes on this random-weight UNet (round 4, tools/chaos_probe.py: the 128-row
+  # kernel with 48 or 12 instead of 24 minimum K steps per split landed 2.9e-2 / 3.1e-2 away after the same 3 steps): rounding-order noise
   # amplified by 4 recurrent UNet calls, well inside the 8e-2 the bf16 path is allowed against the fp32 oracle
   assert rel < 6e-2

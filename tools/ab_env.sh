@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of one engine switch (an environment variable read once per process), alternating runs of the default bench workload on one box:
-#   tools/ab_env.sh GILL_UNET_FFN_PRE [rounds]        -> VAR=0 vs VAR=1
+#   tools/ab_env.sh GILL_UNET_LNPROJ [rounds]        -> VAR=0 vs VAR=1
 VAR=$1; R=${2:-3}
 for r in $(seq 1 $R); do
   for v in 0 1; do

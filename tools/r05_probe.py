@@ -50,15 +50,7 @@ def gemm(M, N, K, sk=0, resid=False, out_f32=False):
 
 
 what = sys.argv[1:] or ["wino", "l3", "opt"]
-if "winoop" in what:
-  print("== level-2 convolutions at the 8-sample batch: direct (split-K 2 + reducer with the fused GroupNorm) vs Winograd (transform + 16-way split GEMM + reducer)")
-  for (Cin, Co) in ((640, 1280), (1280, 1280), (1920, 1280), (2560, 1280)):
-    x = torch.randn(8, 16, 16, Cin, device=dev).bfloat16()
-    w = torch.randn(Co, Cin, 3, 3, device=dev) * 0.02
-    b = torch.randn(Co, device=dev); g = torch.ones(Co, device=dev); be = torch.zeros(Co, device=dev)
-    td = timeit(lambda: ops.conv3x3_gn(x, w, b, g, be, 32, 1e-5, True, None, 2, False))
-    tw = timeit(lambda: ops.conv3x3_wino(x, w, b, None, None, g, be, 32, 1e-5, True, False))
-    print(f"  {Cin:4d}->{Co}: direct {td:6.1f} us   winograd {tw:6.1f} us   ({tw / td:.2f})")
+# ("winoop": the real Winograd operator against the direct convolution — profiles/r05_winograd_op_timing.log — went with csrc/wino.hip in round 6)
 if "wino" in what:
   print("== Winograd stand-in: direct conv vs ONE plain GEMM of the 16 per-position GEMMs' rows (optimistic: no transforms)")
   for (B, H, W, C1, C2, Co) in ((8, 64, 64, 640, 320, 320), (8, 32, 32, 1280, 640, 640), (8, 32, 32, 640, 0, 640), (8, 16, 16, 1280, 0, 1280), (8, 16, 16, 1280, 1280, 1280)):

@@ -5,7 +5,7 @@ for finiteness and compared with iteration 0.  Prints one line per iteration and
 any iteration is non-finite.
 
   python tools/soak.py --iters 30 [--infer-steps 50] [--prompts 4] [--no-decode] [--small] [--stage unet|all]
-Bisect switches (read by libgill_amd): GILL_NO_GRAPH=1, GILL_NO_CFG_SHARE=1, GILL_GEMM_BM=128, GILL_GEMM_NPW_OFF=1, ...
+Bisect switch (read by libgill_amd): GILL_NO_GRAPH=1 (the tile / N-walk bisect switches of round 2 are gone: profiles/r02_soak_bisect.md)
 """
 import argparse
 import os
