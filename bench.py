@@ -231,6 +231,89 @@ def cpu_baseline(n_infer_steps, pipe, unet_cfg, fp8):
   return rec, check
 
 
+class ClockSampler:
+  """sclk (MHz) and socket power (W) of this rank's GPU, sampled every 0.25 s INSIDE the timed region by a host thread (boxes of
+  the pool differ by up to 7 % at the same build; with these two keys in the line a slow box reads as a box, not as a regression).  Source: the amdgpu
+  hwmon files of the card whose PCI address matches the torch device (freq1_input in Hz, power1_average / power1_input in uW: two file reads per
+  sample, no subprocess); `rocm-smi --showclocks --showpower` once per second where sysfs has neither."""
+
+  def __init__(self, dev):
+    import glob
+    import threading
+    self.f_clk = self.f_pow = None
+    self.clk, self.pow = [], []
+    self._stop = threading.Event()
+    self._thr = None
+    self.source = None
+    try:
+      pr = torch.cuda.get_device_properties(dev)
+      want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+      want = None
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+    pick = [c for c in cards if want and want in os.path.realpath(c)] or [c for c in cards if glob.glob(c + "/hwmon/hwmon*/freq1_input")]
+    for c in pick[:1]:
+      for h in glob.glob(c + "/hwmon/hwmon*"):
+        if os.path.exists(h + "/freq1_input"):
+          self.f_clk = h + "/freq1_input"
+        for name in ("power1_average", "power1_input"):
+          if self.f_pow is None and os.path.exists(h + "/" + name):
+            self.f_pow = h + "/" + name
+    if self.f_clk or self.f_pow:
+      self.source = "sysfs hwmon"
+    else:
+      import shutil
+      self.smi = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+      self.dev_index = dev.index or 0
+      self.source = "rocm-smi" if self.smi else None
+
+  def _read(self, path, scale):
+    try:
+      with open(path) as fh:
+        return float(fh.read().split()[0]) * scale
+    except Exception:
+      return None
+
+  def _loop(self):
+    import re
+    while not self._stop.is_set():
+      if self.source == "sysfs hwmon":
+        c = self._read(self.f_clk, 1e-6) if self.f_clk else None
+        p = self._read(self.f_pow, 1e-6) if self.f_pow else None
+        period = 0.25
+      else:
+        c = p = None
+        period = 1.0
+        try:
+          out = subprocess.run([self.smi, "-d", str(self.dev_index), "--showclocks", "--showpower"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                               timeout=5).stdout.decode(errors="replace")
+          m = re.search(r"sclk clock level:\s*\d+:?\s*\((\d+)Mhz\)", out)
+          c = float(m.group(1)) if m else None
+          m = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+          p = float(m.group(1)) if m else None
+        except Exception:
+          pass
+      if c:
+        self.clk.append(c)
+      if p:
+        self.pow.append(p)
+      self._stop.wait(period)
+
+  def start(self):
+    if self.source:
+      import threading
+      self._thr = threading.Thread(target=self._loop, daemon=True)
+      self._thr.start()
+
+  def stop(self):
+    self._stop.set()
+    if self._thr:
+      self._thr.join(timeout=6)
+    mean = lambda v: (sum(v) / len(v)) if v else None   # noqa: E731
+    return {"sclk_mhz_mean": mean(self.clk), "sclk_mhz_min": min(self.clk) if self.clk else None, "power_w_mean": mean(self.pow),
+            "samples": max(len(self.clk), len(self.pow)), "source": self.source}
+
+
 def respawn_under_torchrun(a):
   """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
   with socket.socket() as sk:
@@ -366,9 +449,12 @@ def main():
   opt_ev.clear()
   map_ev.clear()
   kept = []
+  sampler = ClockSampler(dev) if (rank == 0 and not a.child_pmc) else None
   if world > 1:
     dist.barrier()
   torch.cuda.synchronize()
+  if sampler:
+    sampler.start()
   t0 = time.perf_counter()
   for _ in range(a.steps):
     kept.append(step())      # (latents of all ranks, uint8 images of this rank): 0.25 + 3 MiB per prompt, checked below
@@ -376,6 +462,7 @@ def main():
     dist.barrier()
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
+  clocks = sampler.stop() if sampler else None
   per_rank = None
   if world > 1:
     # every rank's own wall time and model-build time (a straggler or a slow loader shows up in the line), then the MAX as the job's time
@@ -512,6 +599,10 @@ def main():
       "vae": {"ms": vae_ms, "what": f"gill_vae_decode of {P_local} latents to uint8 {side}x{side}"},
       "host_and_gaps_ms": dt / a.steps * 1e3 - (opt_ms + map_ms + unet_ms * n_sd_calls + vae_ms),
     }
+    # the box under this very timed region (sampled by a host thread between t0 and dt): the two keys VERDICT r05 item 5 asks for, top level
+    rec["sclk_mhz_mean"] = clocks["sclk_mhz_mean"] if clocks else None
+    rec["power_w_mean"] = clocks["power_w_mean"] if clocks else None
+    rec["clocks"] = clocks
     if want_origin:
       rec["scale_origin"] = scale_origin
     if world == 1 and not a.small and a.config == "c2":

@@ -133,28 +133,65 @@ extern "C" int gill_op_conv3x3(const void* x1, int C1, const void* x2, int C2, c
   return 0;
 }
 
-// 3x3 convolution whose split-K reducer also runs the GroupNorm (+ SiLU) that consumes the output (gemm.hip "REDUCE + GROUPNORM"):
-// y_raw (optional) = conv(x) + bias + resid, y_norm = [silu](GroupNorm(y_raw; groups, gamma, beta, eps)).  H * W must be 64 or 256,
-// Cout / groups a multiple of 4 dividing 80, splitk >= 2.  For the operator tests.
-extern "C" int gill_op_conv3x3_gn(const void* x, const float* w_oihw, const float* bias, const void* resid, const float* gamma,
-                                  const float* beta, int groups, float eps, int silu, void* y_raw, void* y_norm, int B, int H, int W,
-                                  int Cin, int Cout, int splitk, void* stream) {
+// 3x3 convolution + the GroupNorm (+ SiLU) that consumes its output, without a GroupNorm launch of its own where the geometry allows:
+// y_raw (optional) = conv(x) + bias + rowvec[b] + resid, y_norm = [silu](GroupNorm(y_raw; groups, gamma, beta, eps)).
+//   splitk >= 2: the split-K reduction also normalises (H * W in {64, 256}, Cout / groups a multiple of 4 dividing 80) — coop = 0: in the reducer launch
+//                (gemm.hip "REDUCE + GROUPNORM"); coop = 1: inside the convolution's own launch (gemm.hip "COOP", EPI 7) when gemm_coop_ok() takes it
+//                (B * H * W / 128 x Cout / 160 x splitk workgroups <= the device's CUs, Cout % 160 == 0), else as coop = 0;
+//   splitk == 1: coop = 1: in the convolution's epilogue (COOP, EPI 6: H * W a multiple of the 128- / 256-row tile, <= 4096 pixels per sample,
+//                grid <= CUs) — an error where the geometry does not allow it; coop = 0: the reference dataflow, conv with fused statistics +
+//                groupnorm_apply_launch.
+// ss_out (optional, splitk == 1 && coop == 1 only): the per-(sample, channel) scale | shift table [B][2][Cout] instead of / next to y_norm.
+// For the operator tests.
+extern "C" int gill_op_conv3x3_gn(const void* x, const float* w_oihw, const float* bias, const float* rowvec, const void* resid, const float* gamma,
+                                  const float* beta, int groups, float eps, int silu, void* y_raw, void* y_norm, float* ss_out, int B, int H, int W,
+                                  int Cin, int Cout, int splitk, int coop, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  GILL_REQUIRE(x && w_oihw && gamma && beta && y_norm && groups > 0 && Cout % groups == 0 && splitk >= 2, "bad argument");
-  DevBuf wr, ws;
+  GILL_REQUIRE(x && w_oihw && gamma && beta && (y_norm || ss_out) && groups > 0 && Cout % groups == 0 && splitk >= 1, "bad argument");
+  GILL_REQUIRE(ss_out == nullptr || (splitk == 1 && coop), "conv3x3_gn: the scale | shift table comes from the in-kernel finish only");
+  DevBuf wr, ws, ctr, st, raw_tmp;
   GILL_TRY(wr.alloc(sizeof(bf16_t) * (size_t)Cout * 9 * Cin));
   GILL_TRY(conv_weight_relayout_launch(w_oihw, GILL_DTYPE_F32, Cout, Cin, (bf16_t*)wr.p, s));
   GemmArgs g;
   g.conv = 1; g.IH = H; g.IW = W; g.OH = H; g.OW = W; g.Cin = Cin; g.stride = 1;
   g.M = B * H * W; g.N = Cout; g.K = 9 * Cin;
   g.A = (const bf16_t*)x; g.K1 = Cin; g.W = (const bf16_t*)wr.p; g.bias = bias;
+  g.rowvec = rowvec; g.rowvec_bstride = Cout;
   g.rows_per_batch = H * W; g.resid = resid; g.ldr = Cout; g.C = y_raw; g.ldc = Cout;
   g.splitk = splitk;
-  GILL_TRY(ws.alloc(sizeof(float) * (size_t)splitk * g.M * g.N));
-  g.ws = (float*)ws.p;
-  g.fn_Y = (bf16_t*)y_norm; g.fn_gamma = gamma; g.fn_beta = beta; g.fn_eps = eps; g.fn_silu = silu; g.fn_cg = Cout / groups;
-  GILL_REQUIRE(gemm_fused_norm_ok(g), "conv3x3_gn: unsupported geometry (H * W in {64, 256}, Cout % 80 == 0, group width | 80)");
-  for (int r = 0; r < op_repeat(); ++r) GILL_TRY(gemm_launch(g, s));
+  if (splitk > 1) {
+    GILL_TRY(ws.alloc(sizeof(float) * (size_t)splitk * g.M * g.N));
+    g.ws = (float*)ws.p;
+  }
+  g.fn_Y = (bf16_t*)y_norm; g.fn_ss = ss_out; g.fn_gamma = gamma; g.fn_beta = beta; g.fn_eps = eps; g.fn_silu = silu; g.fn_cg = Cout / groups;
+  const int ncnt = gemm_coop_counters(g);
+  GILL_TRY(ctr.alloc(sizeof(unsigned) * (size_t)ncnt));
+  // statistics bins as the engine's talloc() picks them (C / 64 channels, else one group), one partial per 16 rows at most
+  const int sbin = (Cout % 64 == 0 && Cout / 64 >= 2) ? Cout / 64 : Cout / groups;
+  if (splitk == 1) {
+    GILL_REQUIRE(gemm_fused_gn_ok(Cout, sbin) && (H * W) % GN_SLAB_ROWS == 0, "conv3x3_gn: no fused statistics for this width / map size");
+    GILL_TRY(st.alloc(sizeof(float) * (size_t)B * (H * W / GN_SLAB_ROWS_MIN) * (Cout / sbin) * 2));
+    g.gn_stats = (float*)st.p; g.gn_groups = Cout / sbin; g.gn_cg = sbin;
+  }
+  if (coop) g.coop_ctr = (unsigned*)ctr.p;
+  if (splitk == 1 && !coop) {
+    // reference dataflow: the convolution files its statistics, a GroupNorm-apply launch normalises the rounded tensor
+    g.fn_Y = nullptr; g.fn_ss = nullptr;
+    if (!g.C) { GILL_TRY(raw_tmp.alloc(sizeof(bf16_t) * (size_t)g.M * g.N)); g.C = raw_tmp.p; }
+    for (int r = 0; r < op_repeat(); ++r) {
+      GILL_TRY(gemm_launch(g, s));
+      GILL_TRY(groupnorm_apply_launch((const bf16_t*)g.C, Cout, nullptr, 0, B, H * W, groups, gamma, beta, eps, silu, (bf16_t*)y_norm, g.gn_stats, sbin, Cout,
+                                      H * W / gemm_gn_slab_rows(g), nullptr, 0, 0, s, 0.f, nullptr, nullptr));
+    }
+    GILL_CHECK_HIP(hipStreamSynchronize(s));
+    return 0;
+  }
+  if (splitk == 1) GILL_REQUIRE(gemm_coop_ok(g), "conv3x3_gn: splitk == 1 with coop needs the in-kernel finish's geometry (gemm_coop_ok)");
+  else GILL_REQUIRE(gemm_coop_ok(g) || gemm_fused_norm_ok(g), "conv3x3_gn: unsupported geometry (H * W in {64, 256}, Cout % 80 == 0, group width | 80)");
+  for (int r = 0; r < op_repeat(); ++r) {
+    GILL_CHECK_HIP(hipMemsetAsync(ctr.p, 0, sizeof(unsigned) * (size_t)ncnt, s));
+    GILL_TRY(gemm_launch(g, s));
+  }
   GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
 }

@@ -125,11 +125,161 @@ __device__ __forceinline__ void store4(const GemmArgs& p, int m, int n, float v0
   }
 }
 
+// REDUCE + GROUPNORM.  Where a split-K GEMM's output feeds a single-source GroupNorm (every 3x3 convolution of UNet levels 2-3 at
+// the 8-sample batch: conv1 -> norm2 inside a ResnetBlock2D, and a block's last GEMM -> the next block's first norm), the reducer is
+// the first place that holds complete output values — and a unit that owns ALL rows of one sample for a run of whole groups holds
+// complete GroupNorm statistics too.  Unit = (sample b, W output columns from col0 = whole groups of fn_cg channels): sums the split slices
+// in slice order, applies the GEMM epilogue (bias, per-sample row vector, bf16 residual), optionally stores the raw tensor, totals
+// {sum, sum of squares} per group in a fixed order (thread -> 16 row lanes -> the group's column quads), and writes the normalised
+// (+ SiLU) tensor: the GroupNorm-apply launch of that norm (5.5-7.5 us each, 24 per forward) and its read of the raw tensor disappear.
+// Also files the fused-statistics partials of the raw output (gn_stats: one slab = the whole sample) for a later two-source consumer.
+// fn_Y == nullptr: the plain finish (raw tensor + partials only).
+// RPT rows per thread: rows_per_batch = 16 * RPT (256 -> 16, 64 -> 4).  W columns (80 | 40): W / 4 column quads x 16 row lanes = 4 W threads
+// do the work; a caller with more threads (the COOP finish inside gemm_kernel: 512) passes them all — they only take part in the barriers.
+// Two callers, one body: the stand-alone reducer kernel below (one unit per block) and gemm_kernel's EPI 7 (one unit per workgroup, after the
+// arrival counter of its group has filled) — so the in-kernel finish is bit-identical to the reducer launch it replaces.
+// poison: the caller gave up waiting for its group (COOP_SPIN_LIMIT): every output of the unit becomes NaN.
+template <int RPT, int W>
+__device__ __forceinline__ void splitk_finish_unit(const GemmArgs& p, const int b, const int col0, const int tidx, float2 (*part)[W / 4], float2* quad,
+                                                   float2* mr, const bool poison) {
+  constexpr int QW = W / 4, ROWS = 16 * RPT;
+  const bool act = tidx < 4 * W;
+  const int tx = tidx % QW, ty = act ? tidx / QW : 0;
+  const int n = col0 + tx * 4;
+  const int mbase = b * ROWS;
+  const bool norm = p.fn_Y != nullptr;
+  // every global load of the unit goes out before the first use: the partials of the first slices, the epilogue's vectors, the
+  // residual rows, the norm's parameters — one memory round trip in front of the reduction, not four
+  float4 v[RPT];
+  auto row_of = [&](int r) -> int { return mbase + ty + 16 * r; };     // row of the thread's r-th value
+  float ps = 0.f, pq = 0.f;
+  uint2 raw[RPT];
+  float4 gam = make_float4(0, 0, 0, 0), bet = make_float4(0, 0, 0, 0);
+  if (act) {
+  float4 add = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
+  const float4 rv = p.rowvec ? *reinterpret_cast<const float4*>(p.rowvec + (size_t)b * p.rowvec_bstride + n) : make_float4(0, 0, 0, 0);
+  if (norm) { gam = *reinterpret_cast<const float4*>(p.fn_gamma + n); bet = *reinterpret_cast<const float4*>(p.fn_beta + n); }
+  uint2 rr[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r)
+    rr[r] = p.resid ? *reinterpret_cast<const uint2*>((const bf16_t*)p.resid + (size_t)row_of(r) * p.ldr + n) : make_uint2(0u, 0u);
+  const float* src = p.ws + (size_t)(mbase + ty) * p.N + n;
+  const size_t zstride = (size_t)p.M * p.N, rstride = (size_t)16 * p.N;
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) v[r] = *reinterpret_cast<const float4*>(src + (size_t)r * rstride);
+  float4 t1[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) t1[r] = *reinterpret_cast<const float4*>(src + zstride + (size_t)r * rstride);      // (splitk >= 2)
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) { v[r].x += t1[r].x; v[r].y += t1[r].y; v[r].z += t1[r].z; v[r].w += t1[r].w; }
+  for (int z = 2; z < p.splitk; ++z) {
+    float4 t[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) t[r] = *reinterpret_cast<const float4*>(src + (size_t)z * zstride + (size_t)r * rstride);
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) { v[r].x += t[r].x; v[r].y += t[r].y; v[r].z += t[r].z; v[r].w += t[r].w; }
+  }
+  add.x += rv.x; add.y += rv.y; add.z += rv.z; add.w += rv.w;
+  if (poison) add.x = add.y = add.z = add.w = __builtin_nanf("");
+  // STATISTICS SOURCE (ADVICE r04): every FUSED producer of GroupNorm statistics in this file — the in-kernel epilogue (gs / gq), the plain reducer
+  // (store4()'s `fin`) and this unit — sums the fp32 values BEFORE their rounding to bf16, and every consumer normalises the ROUNDED tensor (below:
+  // raw[r], what a stand-alone apply pass would read).  The fused and unfused forms of one layer therefore see the same statistics source and differ
+  // only in the (fixed) order of the fp32 additions, which is why the fused and unfused forms are held to closeness, not equality.  Only the stand-alone
+  // statistics kernel of two-source (skip-concat) inputs reads rounded values — it has nothing else.  Variance: E[x^2] - E[x]^2 in fp32 over a
+  // (sample, group) slab of <= 256 x 80 values of O(1): cancellation costs ~1e-6 relative at |mean| ~ sigma, far below the bf16 output step.
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const int m = row_of(r);
+    v[r].x += add.x; v[r].y += add.y; v[r].z += add.z; v[r].w += add.w;
+    v[r].x += bf2f((bf16_t)(rr[r].x & 0xffff)); v[r].y += bf2f((bf16_t)(rr[r].x >> 16));        // (zeros without a residual)
+    v[r].z += bf2f((bf16_t)(rr[r].y & 0xffff)); v[r].w += bf2f((bf16_t)(rr[r].y >> 16));
+    ps += (v[r].x + v[r].y) + (v[r].z + v[r].w);
+    pq += (v[r].x * v[r].x + v[r].y * v[r].y) + (v[r].z * v[r].z + v[r].w * v[r].w);
+    raw[r].x = pack_bf2(v[r].x, v[r].y); raw[r].y = pack_bf2(v[r].z, v[r].w);
+    if (p.C) *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + n) = raw[r];
+  }
+  part[ty][tx] = make_float2(ps, pq);
+  }
+  __syncthreads();
+  if (tidx < QW) {
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float2 t = part[r][tidx]; a += t.x; q += t.y; }
+    quad[tidx] = make_float2(a, q);
+  }
+  __syncthreads();
+  if (norm) {
+    const int qpg = p.fn_cg / 4;             // column quads per group
+    const int ngrp = W / p.fn_cg;
+    if (tidx < ngrp) {
+      float a = 0.f, q = 0.f;
+      for (int t = 0; t < qpg; ++t) { const float2 u = quad[tidx * qpg + t]; a += u.x; q += u.y; }
+      const float inv_n = 1.f / ((float)p.fn_cg * (float)ROWS);
+      const float sm = a * inv_n, sq = q * inv_n;
+      const float var = fmaxf(sq - sm * sm, 0.f);
+      mr[tidx] = make_float2(sm, rsqrtf(var + p.fn_eps));
+    }
+  }
+  if (p.gn_stats) {      // partials of the raw output for a later (two-source) GroupNorm: bins of gn_cg channels, one slab per sample
+    const int qpb = p.gn_cg / 4, nbin = W / p.gn_cg;
+    const int t2 = tidx - 32;
+    if (t2 >= 0 && t2 < 2 * nbin) {
+      const int which = t2 & 1, lb = t2 >> 1;
+      float a = 0.f;
+      for (int t = 0; t < qpb; ++t) { const float2 u = quad[lb * qpb + t]; a += which ? u.y : u.x; }
+      p.gn_stats[((size_t)b * p.gn_groups + col0 / p.gn_cg + lb) * 2 + which] = a;
+    }
+  }
+  __syncthreads();
+  if (norm && act) {
+    const float2 g = mr[(tx * 4) / p.fn_cg];
+    const float s0 = g.y * gam.x, s1 = g.y * gam.y, s2 = g.y * gam.z, s3 = g.y * gam.w;
+    const float h0 = bet.x - g.x * s0, h1 = bet.y - g.x * s1, h2 = bet.z - g.x * s2, h3 = bet.w - g.x * s3;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const int m = row_of(r);
+      // (the consumer of the unfused path reads the bf16 tensor: normalise the rounded values)
+      float o0 = fmaf(bf2f((bf16_t)(raw[r].x & 0xffff)), s0, h0), o1 = fmaf(bf2f((bf16_t)(raw[r].x >> 16)), s1, h1);
+      float o2 = fmaf(bf2f((bf16_t)(raw[r].y & 0xffff)), s2, h2), o3 = fmaf(bf2f((bf16_t)(raw[r].y >> 16)), s3, h3);
+      if (p.fn_silu) { o0 = silu_f(o0); o1 = silu_f(o1); o2 = silu_f(o2); o3 = silu_f(o3); }
+      uint2 o; o.x = pack_bf2(o0, o1); o.y = pack_bf2(o2, o3);
+      *reinterpret_cast<uint2*>(p.fn_Y + (size_t)m * p.N + n) = o;
+    }
+  }
+}
+
+// ---- COOP: hand-offs between the co-resident workgroups of ONE launch (cdna_hip_programming.md Guideline 16, recipe R1; prices in
+// MI355X_MICROARCH.md "publish-large" / "splitk-seam").  Payload goes out WRITE-THROUGH (sc1: nothing left dirty, no release fence), every storing
+// wave drains its own stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane arrives on the group's counter (agent-scope atomic)
+// and polls it relaxed with s_sleep; readers then take ONE agent-scope acquire (split-K: bulk plain loads) or read the few words with sc1 loads
+// (GroupNorm partials).  Counters are zeroed once per forward (unet.hip), every slot is used by exactly one launch: the target is the group size.
+// The spin is bounded: a workgroup that gives up poisons its outputs with NaN (every test and bench.py check finiteness) instead of hanging the GPU.
+__device__ __forceinline__ void st_wt_f32x4(float* p, const f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_wt_f32(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_wt_f32(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+#define COOP_SPIN_LIMIT (1u << 18)
+__device__ __forceinline__ bool coop_arrive_wait(unsigned* ctr, unsigned target) {
+  __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (unsigned spins = 0;; ++spins) {
+    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    if (spins > COOP_SPIN_LIMIT) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
 // CONV: 0 plain GEMM, 1 conv3x3, 2 conv3x3 with fused nearest-2x upsample (9 taps gathered from the source grid),
 //       3 nearest-2x upsample + conv3x3 as FOUR 2x2-tap convolutions of the source grid, one per output parity (see "UPS4")
 // EPI : 0 row-major (bf16 / fp32) epilogue, 1 GEGLU, 2 raw fp32 split-K partials, 3 QKV head-major scatter,
 //       4 = 0 without activation / fp32 output / fp32 residual (the UNet's plain GEMMs: half the epilogue's code and branches)
 //       5 folded-LayerNorm scores + softmax over each wave's 80 columns (OUT_SOFTMAX80; BN = 160)
+//       6 = 0 on the ping-pong conv tiles + the consuming GroupNorm finished in-kernel (COOP, splitk == 1: see GemmArgs::coop_ctr)
+//       7 = 2 + the split-K finish in-kernel (COOP): partials published write-through, one (sample, 40-column) unit finished per workgroup
 // STAGES: depth of the LDS ring.  2: two workgroups per CU hide each other's DMA waits.  3: one workgroup per CU,
 //         the DMA of K steps i+1 AND i+2 is in flight while step i is multiplied (counted s_waitcnt vmcnt(N), raw
 //         s_barrier) — for grids of ~one workgroup per CU where co-residency cannot do the hiding.
@@ -219,7 +369,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
   const int tn_first = gn * d.npw;
   // (convolutions and split-K partials: one N tile per workgroup — gemm_launch_bn() — known at compile time, so that the K walk's
   // state is dead by the epilogue instead of being carried around it for a next tile that never comes)
-  const int ntl = (CONV != 0 || EPI == 2) ? 1 : ((d.tiles_n - tn_first < d.npw) ? d.tiles_n - tn_first : d.npw);   // N tiles of this workgroup
+  const int ntl = (CONV != 0 || EPI == 2 || EPI == 7) ? 1 : ((d.tiles_n - tn_first < d.npw) ? d.tiles_n - tn_first : d.npw);   // N tiles of this workgroup
   int n0 = tn_first * BN;
   const int z = blockIdx.y;
   const int kt_beg = z * d.ksteps_per_split;
@@ -647,7 +797,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
       return m;
     }
   };
-  if constexpr (EPI == 2) {
+  if constexpr (EPI == 2 || EPI == 7) {
     float* ws = p.ws + (size_t)z * (CONV == 3 ? 4 : 1) * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -660,9 +810,46 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
         const int n = nbase + (pair ? g * 32 + fkc * 8 : (2 * g) * 16 + fkc * 4);
         if (n >= p.N) continue;
         float* dst = ws + (size_t)m * p.N + n;
-        *reinterpret_cast<float4*>(dst) = make_float4(acc[i][2 * g][0], acc[i][2 * g][1], acc[i][2 * g][2], acc[i][2 * g][3]);
-        if (pair && n + 4 < p.N)
-          *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[i][j1][0], acc[i][j1][1], acc[i][j1][2], acc[i][j1][3]);
+        if constexpr (EPI == 7) {      // COOP: write-through, nothing left dirty in this XCD's L2 for a release to flush
+          st_wt_f32x4(dst, acc[i][2 * g]);
+          if (pair && n + 4 < p.N) st_wt_f32x4(dst + 4, acc[i][j1]);
+        } else {
+          *reinterpret_cast<float4*>(dst) = make_float4(acc[i][2 * g][0], acc[i][2 * g][1], acc[i][2 * g][2], acc[i][2 * g][3]);
+          if (pair && n + 4 < p.N)
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[i][j1][0], acc[i][j1][1], acc[i][j1][2], acc[i][j1][3]);
+        }
+      }
+    }
+    if constexpr (EPI == 7) {
+      // ---- COOP split-K finish (GemmArgs::coop_ctr).  Group = the workgroups whose tiles cover whole samples of one N tile, over all splits:
+      // M tiles per group mtg = rows_per_batch / BM (level 2: 2) or 1 with spg = BM / rows_per_batch samples in the tile (level 3: 2); G = mtg x splits
+      // workgroups arrive, then workgroup widx of the group finishes units widx, widx + G, ... of the group's spg x (BN / 40) (sample, 40-column) units.
+      static_assert(EPI != 7 || (PP && BN % 40 == 0), "COOP split-K finish: the ping-pong tiles");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its own write-through stores ...
+      __syncthreads();                                       // ... before the one arrival of the workgroup
+      const int rpb = p.rows_per_batch;
+      const int mtg = rpb > BM ? rpb / BM : 1, spg = rpb < BM ? BM / rpb : 1;
+      const int G = mtg * (int)gridDim.y;
+      const int tg = tm / mtg;
+      unsigned char* cs = smem_raw + 16384;                  // (the ring is dead; [0, 5 KiB) is the row-major epilogue's `red`, unused here)
+      float2 (*part)[10] = reinterpret_cast<float2 (*)[10]>(cs);
+      float2* quad = reinterpret_cast<float2*>(cs + 2048);
+      float2* mr = reinterpret_cast<float2*>(cs + 2304);
+      unsigned* okf = reinterpret_cast<unsigned*>(cs + 2560);
+      if (tid == 0) {
+        const bool ok = coop_arrive_wait(p.coop_ctr + (size_t)tg * d.tiles_n + n0 / BN, (unsigned)G);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // ONE acquire per workgroup: drops this CU's stale L1 lines; the slices are read with plain loads
+        *okf = ok ? 1u : 0u;
+      }
+      __syncthreads();
+      const bool poison = *okf == 0u;
+      constexpr int UPT = BN / 40;                           // units per sample in this N tile
+      const int widx = z * mtg + (tm - tg * mtg);
+      for (int u = widx; u < spg * UPT; u += G) {            // (workgroup-uniform trip count)
+        const int b = tg * spg + u / UPT, col0 = n0 + (u % UPT) * 40;
+        if (rpb == 256) splitk_finish_unit<16, 40>(p, b, col0, tid, part, quad, mr, poison);
+        else splitk_finish_unit<4, 40>(p, b, col0, tid, part, quad, mr, poison);
+        __syncthreads();                                     // (the scratch is reused by the next unit)
       }
     }
   } else if constexpr (EPI == 1) {
@@ -982,8 +1169,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
           if (st && hi) *reinterpret_cast<float4*>((float*)p.C + crow[i] + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
           uint4 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
-          if (st && hi) *reinterpret_cast<uint4*>((bf16_t*)p.C + crow[i] + n) = o;
-          else if (st) *reinterpret_cast<uint2*>((bf16_t*)p.C + crow[i] + n) = make_uint2(o.x, o.y);
+          const bool stc = st && (EPI != 6 || p.C != nullptr);     // (COOP: the raw tensor only where somebody else reads it)
+          if (stc && hi) *reinterpret_cast<uint4*>((bf16_t*)p.C + crow[i] + n) = o;
+          else if (stc) *reinterpret_cast<uint2*>((bf16_t*)p.C + crow[i] + n) = make_uint2(o.x, o.y);
+          if constexpr (EPI == 6) {      // the finished values stay in the accumulators until the group's statistics are complete
+            acc[i][2 * g] = (f32x4){v[0], v[1], v[2], v[3]};
+            if (pair) acc[i][j1] = (f32x4){v[4], v[5], v[6], v[7]};
+          }
           if (CONV == 0 && p.row_stats) {   // statistics of what the consumer will read: the rounded values (columns beyond N: none)
             const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
             const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
@@ -1044,7 +1236,93 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
           const int b = mfirst / p.rows_per_batch;
           const int slab = (mfirst - b * p.rows_per_batch) / GN_SLAB_ROWS + (CONV == 3 ? cls * (p.rows_per_batch / GN_SLAB_ROWS) : 0);
           const int nslab = (CONV == 3 ? 4 : 1) * (p.rows_per_batch / GN_SLAB_ROWS);
-          p.gn_stats[(((size_t)b * nslab + slab) * p.gn_groups + bin) * 2 + which] = a;
+          float* dst = p.gn_stats + (((size_t)b * nslab + slab) * p.gn_groups + bin) * 2 + which;
+          if constexpr (EPI == 6) st_wt_f32(dst, a);       // COOP: the other workgroups of the group read it inside this launch
+          else *dst = a;
+        }
+      }
+    }
+    if constexpr (EPI == 6) {
+      // ---- COOP GroupNorm finish (GemmArgs::coop_ctr, splitk == 1).  The rows_per_batch / BM workgroups that hold the M tiles of one (sample, N tile)
+      // have each published their per-slab partials above; once all have arrived every one of them totals the sample's partials for its BN columns
+      // EXACTLY as groupnorm_apply_kernel does (16-partial segments on a fixed tree, segments in order, bins in order: bit-identical statistics),
+      // folds gamma / beta into per-column scale | shift and normalises the ROUNDED values it still holds in its accumulators — what the
+      // stand-alone pass would have read back from HBM.
+      static_assert(EPI != 6 || (PP && CONV == 1), "COOP GroupNorm finish: the ping-pong convolution tiles");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      float* cs = reinterpret_cast<float*>(smem_raw + 16384);    // scratch behind `red`: seg [32 bins][2][4] | tot [32][2] | scale [BN] | shift [BN] | flag
+      float* c_seg = cs; float* c_tot = cs + 256; float* c_sc = cs + 320; float* c_sh = cs + 320 + BN; unsigned* okf = reinterpret_cast<unsigned*>(cs + 320 + 2 * BN);
+      const int bsmp = m0 / p.rows_per_batch;
+      if (tid == 0) {
+        const bool ok = coop_arrive_wait(p.coop_ctr + (size_t)bsmp * d.tiles_n + n0 / BN, (unsigned)(p.rows_per_batch / BM));
+        *okf = ok ? 1u : 0u;
+      }
+      __syncthreads();
+      const bool ok = *okf != 0u;
+      const int bins_tile = BN / p.gn_cg;                       // <= 32 (gemm_coop_ok)
+      const int ns = p.rows_per_batch / GN_SLAB_ROWS;           // <= 64 partials per (sample, bin)
+      if (tid < bins_tile * 8) {
+        const int seg = tid & 3, which = (tid >> 2) & 1, lb = tid >> 3;
+        const float* src = p.gn_stats + (((size_t)bsmp * ns + seg * 16) * p.gn_groups + n0 / p.gn_cg + lb) * 2 + which;
+        const size_t step = (size_t)p.gn_groups * 2;
+        float pv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pv[i] = (seg * 16 + i < ns) ? ld_wt_f32(src + (size_t)i * step) : 0.f;      // sc1 loads: the producers stored sc1
+        c_seg[(lb * 2 + which) * 4 + seg] = (((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]))) +
+                                            (((pv[8] + pv[9]) + (pv[10] + pv[11])) + ((pv[12] + pv[13]) + (pv[14] + pv[15])));
+      }
+      __syncthreads();
+      if (tid < bins_tile * 2) { const float* g4 = c_seg + tid * 4; c_tot[tid] = (g4[0] + g4[1]) + (g4[2] + g4[3]); }
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.N) {
+        const int gl = tid / p.fn_cg, r1 = p.fn_cg / p.gn_cg;
+        float a = 0.f, q = 0.f;
+        for (int bin = gl * r1; bin < (gl + 1) * r1; ++bin) { a += c_tot[bin * 2]; q += c_tot[bin * 2 + 1]; }
+        const float inv_n = 1.f / ((float)p.fn_cg * (float)p.rows_per_batch);
+        const float sm = a * inv_n;         // E[x]
+        const float sq = q * inv_n;         // E[x^2]
+        const float var = fmaxf(sq - sm * sm, 0.f);
+        const float rstd = rsqrtf(var + p.fn_eps);
+        float sc = rstd * p.fn_gamma[n0 + tid];
+        if (!ok) sc = __builtin_nanf("");
+        const float sh = p.fn_beta[n0 + tid] - sm * sc;
+        c_sc[tid] = sc; c_sh[tid] = sh;
+        if (p.fn_ss && m0 == bsmp * p.rows_per_batch) {        // the scale | shift table, once per (sample, N tile): [B][2][N]
+          p.fn_ss[((size_t)bsmp * 2 + 0) * p.N + n0 + tid] = sc;
+          p.fn_ss[((size_t)bsmp * 2 + 1) * p.N + n0 + tid] = sh;
+        }
+      }
+      __syncthreads();
+      if (p.fn_Y) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const bool pair = (2 * g + 1 < NT);
+          const int j1 = pair ? 2 * g + 1 : 2 * g;
+          const int cl = pair ? g * 32 + fkc * 8 : (2 * g) * 16 + fkc * 4;
+          const int n = nbase + cl;
+          const bool nok = n < p.N;
+          const bool hi = pair && (n + 4 < p.N);
+          const float* scp = c_sc + wn * (BN / 2) + cl; const float* shp = c_sh + wn * (BN / 2) + cl;
+          const float4 s0 = *reinterpret_cast<const float4*>(scp), h0 = *reinterpret_cast<const float4*>(shp);
+          const float4 s1 = pair ? *reinterpret_cast<const float4*>(scp + 4) : s0, h1 = pair ? *reinterpret_cast<const float4*>(shp + 4) : h0;
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const f32x4 a0 = acc[i][2 * g], a1 = acc[i][j1];
+            float o[8];
+            o[0] = fmaf(bf2f(f2bf(a0[0])), s0.x, h0.x); o[1] = fmaf(bf2f(f2bf(a0[1])), s0.y, h0.y);
+            o[2] = fmaf(bf2f(f2bf(a0[2])), s0.z, h0.z); o[3] = fmaf(bf2f(f2bf(a0[3])), s0.w, h0.w);
+            o[4] = fmaf(bf2f(f2bf(a1[0])), s1.x, h1.x); o[5] = fmaf(bf2f(f2bf(a1[1])), s1.y, h1.y);
+            o[6] = fmaf(bf2f(f2bf(a1[2])), s1.z, h1.z); o[7] = fmaf(bf2f(f2bf(a1[3])), s1.w, h1.w);
+            if (p.fn_silu) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = silu_f(o[e]);
+            }
+            uint4 ov; ov.x = pack_bf2(o[0], o[1]); ov.y = pack_bf2(o[2], o[3]); ov.z = pack_bf2(o[4], o[5]); ov.w = pack_bf2(o[6], o[7]);
+            bf16_t* yrow = p.fn_Y + (size_t)(mrow + i * 16) * p.N + n;
+            if (mok[i] && nok && hi) *reinterpret_cast<uint4*>(yrow) = ov;
+            else if (mok[i] && nok) *reinterpret_cast<uint2*>(yrow) = make_uint2(ov.x, ov.y);
+          }
         }
       }
     }
@@ -1168,116 +1446,12 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
   }
 }
 
-// REDUCE + GROUPNORM.  Where a split-K GEMM's output feeds a single-source GroupNorm (every 3x3 convolution of UNet levels 2-3 at
-// the 8-sample batch: conv1 -> norm2 inside a ResnetBlock2D, and a block's last GEMM -> the next block's first norm), the reducer is
-// the first kernel that holds complete output values — and a block that owns ALL rows of one sample for a run of whole groups holds
-// complete GroupNorm statistics too.  Block = (sample b, 80 output columns = whole groups of fn_cg channels): sums the split slices
-// in slice order, applies the GEMM epilogue (bias, per-sample row vector, bf16 residual), optionally stores the raw tensor, totals
-// {sum, sum of squares} per group in a fixed order (thread -> 16 row lanes -> the group's column quads), and writes the normalised
-// (+ SiLU) tensor: the GroupNorm-apply launch of that norm (5.5-7.5 us each, 24 per forward) and its read of the raw tensor disappear.
-// Also files the fused-statistics partials of the raw output (gn_stats: one slab = the whole sample) for a later two-source consumer.
-// RPT rows per thread: rows_per_batch = 16 * RPT (256 -> 16, 64 -> 4).  Block = W columns (80 | 40): W / 4 column quads x 16 row lanes.
 template <int RPT, int W>
 __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_gn_kernel(const GemmArgs p) {
-  constexpr int QW = W / 4, ROWS = 16 * RPT;
-  __shared__ float2 part[16][QW];        // per (row lane, column quad) {sum, sum of squares} over the thread's rows
-  __shared__ float2 quad[QW];            // per column quad, over the 16 row lanes
-  __shared__ float2 mr[QW];              // per group of the block: {mean, rstd}   (fn_cg >= 4)
-  const int tx = threadIdx.x % QW, ty = threadIdx.x / QW;
-  const int n = blockIdx.x * W + tx * 4;
-  const int b = blockIdx.y;
-  const int mbase = b * ROWS;
-  // every global load of the block goes out before the first use: the partials of the first slices, the epilogue's vectors, the
-  // residual rows, the norm's parameters — one memory round trip in front of the reduction, not four
-  float4 v[RPT];
-  // row of the thread's r-th value
-  auto row_of = [&](int r) -> int { return mbase + ty + 16 * r; };
-  float4 add = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
-  const float4 rv = p.rowvec ? *reinterpret_cast<const float4*>(p.rowvec + (size_t)b * p.rowvec_bstride + n) : make_float4(0, 0, 0, 0);
-  const float4 gam = *reinterpret_cast<const float4*>(p.fn_gamma + n), bet = *reinterpret_cast<const float4*>(p.fn_beta + n);
-  uint2 rr[RPT];
-#pragma unroll
-  for (int r = 0; r < RPT; ++r)
-    rr[r] = p.resid ? *reinterpret_cast<const uint2*>((const bf16_t*)p.resid + (size_t)row_of(r) * p.ldr + n) : make_uint2(0u, 0u);
-  const float* src = p.ws + (size_t)(mbase + ty) * p.N + n;
-  const size_t zstride = (size_t)p.M * p.N, rstride = (size_t)16 * p.N;
-#pragma unroll
-  for (int r = 0; r < RPT; ++r) v[r] = *reinterpret_cast<const float4*>(src + (size_t)r * rstride);
-  float4 t1[RPT];
-#pragma unroll
-  for (int r = 0; r < RPT; ++r) t1[r] = *reinterpret_cast<const float4*>(src + zstride + (size_t)r * rstride);      // (splitk >= 2)
-#pragma unroll
-  for (int r = 0; r < RPT; ++r) { v[r].x += t1[r].x; v[r].y += t1[r].y; v[r].z += t1[r].z; v[r].w += t1[r].w; }
-  for (int z = 2; z < p.splitk; ++z) {
-    float4 t[RPT];
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) t[r] = *reinterpret_cast<const float4*>(src + (size_t)z * zstride + (size_t)r * rstride);
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) { v[r].x += t[r].x; v[r].y += t[r].y; v[r].z += t[r].z; v[r].w += t[r].w; }
-  }
-  add.x += rv.x; add.y += rv.y; add.z += rv.z; add.w += rv.w;
-  // STATISTICS SOURCE (ADVICE r04): every FUSED producer of GroupNorm statistics in this file — the in-kernel epilogue (gs / gq), the plain reducer
-  // (store4()'s `fin`) and this kernel — sums the fp32 values BEFORE their rounding to bf16, and every consumer normalises the ROUNDED tensor (below:
-  // raw[r], what a stand-alone apply pass would read).  The fused and unfused forms of one layer therefore see the same statistics source and differ
-  // only in the (fixed) order of the fp32 additions, which is why GILL_GEMM_RED_GN on / off is held to closeness, not equality.  Only the stand-alone
-  // statistics kernel of two-source (skip-concat) inputs reads rounded values — it has nothing else.  Variance: E[x^2] - E[x]^2 in fp32 over a
-  // (sample, group) slab of <= 256 x 80 values of O(1): cancellation costs ~1e-6 relative at |mean| ~ sigma, far below the bf16 output step.
-  float ps = 0.f, pq = 0.f;
-  uint2 raw[RPT];
-#pragma unroll
-  for (int r = 0; r < RPT; ++r) {
-    const int m = row_of(r);
-    v[r].x += add.x; v[r].y += add.y; v[r].z += add.z; v[r].w += add.w;
-    v[r].x += bf2f((bf16_t)(rr[r].x & 0xffff)); v[r].y += bf2f((bf16_t)(rr[r].x >> 16));        // (zeros without a residual)
-    v[r].z += bf2f((bf16_t)(rr[r].y & 0xffff)); v[r].w += bf2f((bf16_t)(rr[r].y >> 16));
-    ps += (v[r].x + v[r].y) + (v[r].z + v[r].w);
-    pq += (v[r].x * v[r].x + v[r].y * v[r].y) + (v[r].z * v[r].z + v[r].w * v[r].w);
-    raw[r].x = pack_bf2(v[r].x, v[r].y); raw[r].y = pack_bf2(v[r].z, v[r].w);
-    if (p.C) *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + n) = raw[r];
-  }
-  part[ty][tx] = make_float2(ps, pq);
-  __syncthreads();
-  if ((int)threadIdx.x < QW) {
-    float a = 0.f, q = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { const float2 t = part[r][threadIdx.x]; a += t.x; q += t.y; }
-    quad[threadIdx.x] = make_float2(a, q);
-  }
-  __syncthreads();
-  const int qpg = p.fn_cg / 4;             // column quads per group
-  const int ngrp = W / p.fn_cg;
-  if ((int)threadIdx.x < ngrp) {
-    float a = 0.f, q = 0.f;
-    for (int t = 0; t < qpg; ++t) { const float2 u = quad[threadIdx.x * qpg + t]; a += u.x; q += u.y; }
-    const float inv_n = 1.f / ((float)p.fn_cg * (float)ROWS);
-    const float sm = a * inv_n, sq = q * inv_n;
-    const float var = fmaxf(sq - sm * sm, 0.f);
-    mr[threadIdx.x] = make_float2(sm, rsqrtf(var + p.fn_eps));
-  }
-  if (p.gn_stats) {      // partials of the raw output for a later (two-source) GroupNorm: bins of gn_cg channels, one slab per sample
-    const int qpb = p.gn_cg / 4, nbin = W / p.gn_cg;
-    const int t2 = (int)threadIdx.x - 32;
-    if (t2 >= 0 && t2 < 2 * nbin) {
-      const int which = t2 & 1, lb = t2 >> 1;
-      float a = 0.f;
-      for (int t = 0; t < qpb; ++t) { const float2 u = quad[lb * qpb + t]; a += which ? u.y : u.x; }
-      p.gn_stats[((size_t)b * p.gn_groups + blockIdx.x * nbin + lb) * 2 + which] = a;
-    }
-  }
-  __syncthreads();
-  const float2 g = mr[(tx * 4) / p.fn_cg];
-  const float s0 = g.y * gam.x, s1 = g.y * gam.y, s2 = g.y * gam.z, s3 = g.y * gam.w;
-  const float h0 = bet.x - g.x * s0, h1 = bet.y - g.x * s1, h2 = bet.z - g.x * s2, h3 = bet.w - g.x * s3;
-#pragma unroll
-  for (int r = 0; r < RPT; ++r) {
-    const int m = row_of(r);
-    // (the consumer of the unfused path reads the bf16 tensor: normalise the rounded values)
-    float o0 = fmaf(bf2f((bf16_t)(raw[r].x & 0xffff)), s0, h0), o1 = fmaf(bf2f((bf16_t)(raw[r].x >> 16)), s1, h1);
-    float o2 = fmaf(bf2f((bf16_t)(raw[r].y & 0xffff)), s2, h2), o3 = fmaf(bf2f((bf16_t)(raw[r].y >> 16)), s3, h3);
-    if (p.fn_silu) { o0 = silu_f(o0); o1 = silu_f(o1); o2 = silu_f(o2); o3 = silu_f(o3); }
-    uint2 o; o.x = pack_bf2(o0, o1); o.y = pack_bf2(o2, o3);
-    *reinterpret_cast<uint2*>(p.fn_Y + (size_t)m * p.N + n) = o;
-  }
+  __shared__ float2 part[16][W / 4];     // per (row lane, column quad) {sum, sum of squares} over the thread's rows
+  __shared__ float2 quad[W / 4];         // per column quad, over the 16 row lanes
+  __shared__ float2 mr[W / 4];           // per group of the block: {mean, rstd}   (fn_cg >= 4)
+  splitk_finish_unit<RPT, W>(p, blockIdx.y, blockIdx.x * W, threadIdx.x, part, quad, mr, false);
 }
 // blocks of 40 columns where 80-column blocks would leave half the CUs without one and the groups / bins allow it
 static inline int reduce_gn_width(const GemmArgs& a) {
@@ -1287,8 +1461,6 @@ static inline int reduce_gn_width(const GemmArgs& a) {
 }
 // geometries the fused reducer takes: whole samples of 64 or 256 rows, 80-column blocks of whole groups, the plain bf16 epilogue
 bool gemm_fused_norm_ok(const GemmArgs& a) {
-  static const bool on = [] { const char* e = getenv("GILL_GEMM_RED_GN"); return !(e && e[0] == '0'); }();     // A/B switch
-  if (!on) return false;
   const int rows = a.rows_per_batch;
   const int M = (a.conv && a.ups == 2) ? 0 : a.M;      // (not the 4-tap upsample form: its partials are filed per parity class)
   return (rows == 64 || rows == 256) && M > 0 && M % rows == 0 && a.N % 80 == 0 && a.fn_cg >= 4 && a.fn_cg % 4 == 0 && 80 % a.fn_cg == 0 &&
@@ -1343,7 +1515,7 @@ int gemm_row_planes(const GemmArgs& a) {
   return 2 * cdiv(a.N, tile_width(a));
 }
 int gemm_gn_slab_rows(const GemmArgs& a) {
-  if (a.splitk > 1 && a.fn_Y) return a.rows_per_batch;      // the fused reducer files one partial per (sample, bin)
+  if (a.splitk > 1 && (a.fn_Y || gemm_coop_ok(a))) return a.rows_per_batch;      // the fused reducer / the in-kernel finish files one partial per (sample, bin)
   return a.splitk > 1 ? reduce_rows(a) : GN_SLAB_ROWS;
 }
 bool gemm_fused_gn_ok(int N, int cg) {
@@ -1362,6 +1534,60 @@ bool gemm_conv_pingpong(int rows_multiple_of, int Cout) {
   static const int pp_env = [] { const char* v = getenv("GILL_GEMM_PP"); return v ? atoi(v) : 1; }();
   return pp_env != 0 && rows_multiple_of % 256 == 0 && Cout % 160 == 0;
 }
+
+// ---- COOP (GemmArgs::coop_ctr): which launches may finish in-kernel.
+static int device_cus() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return v;
+  }();
+  return n;
+}
+// rows of the ping-pong tile gemm_launch_bn() runs this launch on (0: it is not a ping-pong launch, or a form COOP does not take)
+static int coop_tile_rows(const GemmArgs& a, int sk) {
+  if (a.N % 160 != 0) return 0;
+  const int tiles_n = a.N / 160;
+  if (a.conv) {
+    if (a.ups || !gemm_conv_pingpong(a.M, a.N)) return 0;      // (upsample forms: parity classes in blockIdx.z / a 9-tap gather — their finish stays a launch)
+    return ((int64_t)cdiv(a.M, 256) * tiles_n * sk <= 128 && a.M % 128 == 0) ? 128 : 256;
+  }
+  if (!gemm_plain_pingpong_args(a)) return 0;
+  return ((int64_t)cdiv(a.M, 256) * tiles_n * sk <= 128 || a.M % 256 != 0) ? 128 : 256;
+}
+// GILL_GEMM_COOP = 0: every finish as its own launch (split-K reducers, GroupNorm-apply), the round-5 dataflow (A/B and the on / off parity test)
+static bool coop_on() {
+  static const bool on = [] { const char* e = getenv("GILL_GEMM_COOP"); return !(e && e[0] == '0'); }();
+  return on;
+}
+bool gemm_coop_ok(const GemmArgs& a) {
+  if (!a.coop_ctr || !coop_on()) return false;
+  const int sk = a.splitk > 1 ? a.splitk : 1;
+  const int bm = coop_tile_rows(a, sk);
+  const int rpb = a.rows_per_batch;
+  if (bm == 0 || rpb <= 0 || a.M % bm != 0 || a.M % rpb != 0) return false;
+  // co-residency: the waiting workgroups must all be on the chip — one per CU (the ping-pong tiles take a CU's whole LDS), so the grid may not
+  // exceed the CU count (MI355X: 256; a device with fewer falls back to the launches)
+  if ((int64_t)(a.M / bm) * (a.N / 160) * sk > device_cus()) return false;
+  if (a.out_mode != OUT_BF16 || a.act != ACT_NONE || a.resid_f32 || a.row_stats || a.ln_stats || a.alpha != 1.f || a.wb_rows || a.partials_only || a.w_blk64)
+    return false;
+  if (sk > 1) {
+    // split-K finish: (whole sample, 40 columns) units on the 128 x 160 tile, the reducer's geometries (64 / 256 rows per sample)
+    if (bm != 128 || !(rpb == 64 || rpb == 256) || a.fn_ss) return false;
+    if (a.fn_Y) { if (a.fn_cg < 4 || a.fn_cg % 4 != 0 || 40 % a.fn_cg != 0 || !a.fn_gamma || !a.fn_beta) return false; }
+    else if (!a.C) return false;
+    if (a.gn_stats && (a.gn_cg < 4 || a.gn_cg % 4 != 0 || 40 % a.gn_cg != 0)) return false;
+    return true;
+  }
+  // GroupNorm finish in the convolution's epilogue: whole M tiles per sample, <= 64 slab partials per bin (the apply kernel's own limit),
+  // <= 32 bins per N tile, groups made of whole bins inside one N tile
+  if (!a.conv || (!a.fn_Y && !a.fn_ss) || !a.fn_gamma || !a.fn_beta) return false;
+  if (!a.gn_stats || a.gn_cg <= 0 || 160 % a.gn_cg != 0 || 160 / a.gn_cg > 32 || a.gn_cg * a.gn_groups != a.N) return false;
+  if (a.fn_cg <= 0 || a.fn_cg % a.gn_cg != 0 || 160 % a.fn_cg != 0) return false;
+  if (rpb % bm != 0 || rpb % GN_SLAB_ROWS != 0 || rpb / GN_SLAB_ROWS > 64) return false;
+  return true;
+}
+int gemm_coop_counters(const GemmArgs& a) { return cdiv(a.M, 128) * cdiv(a.N, 160); }     // (an upper bound: one per 128-row tile)
 
 bool conv_k_chunked(int HW, int Cin, int Cout) {
   return HW >= 4096 && (int64_t)HW * Cin * 2 > (int64_t)4 << 20 && !gemm_conv_pingpong(HW, Cout);
@@ -1584,6 +1810,14 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   GILL_REQUIRE(a.wb_rows == 0 || (a.wb_rows % ((d.nwv / 2) * d.mi * 16) == 0 && !a.conv), "per-sample weights: tiles must not straddle samples");
   dim3 grid(tiles_m * d.groups_n, sk, ncls);
   if (d.nwv == 8) GILL_REQUIRE(d.npw == 1, "internal: the ping-pong kernel walks one N tile per workgroup");
+  // COOP: the finish inside this launch (EPI 6: GroupNorm in the conv epilogue; EPI 7: the split-K reduction) — no second launch
+  bool coop = false;
+  if constexpr (BN == 160) {
+    coop = gemm_coop_ok(d.a);
+    if (coop) GILL_REQUIRE(d.nwv == 8 && (d.nwv / 2) * d.mi * 16 == coop_tile_rows(d.a, sk) && (sk == 1 || d.mi == 2) && ncls == 1,
+                           "internal: gemm_coop_ok() and the launcher disagree about the tile");
+  }
+  GILL_REQUIRE(coop || sk > 1 || (a.fn_Y == nullptr && a.fn_ss == nullptr), "fused GroupNorm output without a split-K reducer or an in-kernel finish");
   if (a.conv) {
     if (a.ups == 2) {
       if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 3, 2>(d, grid, s)));
@@ -1591,12 +1825,21 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     } else if (a.ups) {
       if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 2, 2>(d, grid, s)));
       else GILL_TRY((gemm_launch_stages<BN, 2, 0>(d, grid, s)));
+    } else if (coop) {
+      if constexpr (BN == 160) {
+        if (sk > 1) GILL_TRY((gemm_launch_inst<8, 160, 1, 7, 3, BK, 2>(d, grid, s)));
+        else if (d.mi == 2) GILL_TRY((gemm_launch_inst<8, 160, 1, 6, 3, BK, 2>(d, grid, s)));
+        else GILL_TRY((gemm_launch_inst<8, 160, 1, 6, 3, BK, 4>(d, grid, s)));
+      }
     } else {
       if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 1, 2>(d, grid, s)));
       else GILL_TRY((gemm_launch_stages<BN, 1, 0>(d, grid, s)));
     }
   } else {
-    if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 0, 2>(d, grid, s)));
+    if (sk > 1 && coop) {
+      if constexpr (BN == 160) GILL_TRY((gemm_launch_inst<8, 160, 0, 7, 3, BK, 2>(d, grid, s)));
+    }
+    else if (sk > 1) GILL_TRY((gemm_launch_stages<BN, 0, 2>(d, grid, s)));
     else if (a.act == ACT_GEGLU) {
       if constexpr (BN == 128) GILL_TRY((gemm_launch_stages<BN, 0, 1>(d, grid, s)));
       else GILL_REQUIRE(BN == 128, "internal: GEGLU runs on 128-wide tiles");
@@ -1609,7 +1852,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     else if (a.act == ACT_NONE && a.out_mode == OUT_BF16 && !a.resid_f32) GILL_TRY((gemm_launch_stages<BN, 0, 4>(d, grid, s)));
     else GILL_TRY((gemm_launch_stages<BN, 0, 0>(d, grid, s)));
   }
-  if (sk > 1 && !a.partials_only) return gemm_splitk_reduce_launch(red, s);
+  if (sk > 1 && !a.partials_only && !coop) return gemm_splitk_reduce_launch(red, s);
   return 0;
 }
 
@@ -1684,7 +1927,8 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
     GILL_REQUIRE(a.act == ACT_GEGLU || a.out_mode == OUT_QKV || a.out_mode == OUT_SOFTMAX80, "folded LayerNorm is implemented in the GEGLU, QKV and softmax epilogues");
     GILL_REQUIRE(a.alpha == 1.f, "folded LayerNorm: alpha must be 1");
   }
-  GILL_REQUIRE(a.fn_Y == nullptr || (a.splitk > 1 && gemm_fused_norm_ok(a)), "fused GroupNorm output: split-K GEMMs of a supported geometry only");
+  GILL_REQUIRE((a.fn_Y == nullptr && a.fn_ss == nullptr) || gemm_coop_ok(a) || (a.fn_ss == nullptr && a.splitk > 1 && gemm_fused_norm_ok(a)),
+               "fused GroupNorm output: split-K GEMMs of a supported geometry, or an in-kernel finish (gemm_coop_ok), only");
   GILL_REQUIRE(a.C != nullptr || a.fn_Y != nullptr || a.out_mode == OUT_QKV, "no output tensor");
   if (a.splitk > 1) {
     GILL_REQUIRE(a.ws != nullptr, "split-K workspace missing");

@@ -72,7 +72,20 @@ struct GemmArgs {
   // fn_Y [M][N] bf16 = [silu]((C - mean) * rstd * fn_gamma + fn_beta) with mean / rstd over (rows_per_batch rows, fn_cg channels).
   // C may then be null (the raw tensor has no other reader).  gemm_fused_norm_ok() says which geometries the reducer takes.
   bf16_t* fn_Y = nullptr; const float* fn_gamma = nullptr; const float* fn_beta = nullptr; float fn_eps = 1e-5f; int fn_silu = 0; int fn_cg = 0;
+  // COOP (gemm.hip "COOP"): the finish that used to be a second launch, done by the producing kernel's own workgroups, which wait for each other on
+  // an arrival counter — legal because the grid is at most one workgroup per CU (gemm_coop_ok() checks it against the device), i.e. co-resident.
+  //   splitk > 1: every workgroup publishes its fp32 partial tile (write-through), arrives on the counter of its (sample group, N tile), and once all
+  //     slices have arrived finishes one (sample, 40-column) unit exactly as the stand-alone reducer would (slices summed in slice order, bias / row
+  //     vector / residual, GroupNorm partials, and the consuming GroupNorm when fn_Y is set): no reducer launch;
+  //   splitk == 1 (3x3 convolutions on the ping-pong tiles): the epilogue publishes its per-slab GroupNorm partials (gn_stats), waits for the other
+  //     M tiles of its (sample, N tile), totals them in the consumer's order and writes fn_Y = [silu](GroupNorm(C)) straight from the accumulators
+  //     (C itself only when non-null), and / or the per-(sample, channel) scale | shift table fn_ss [B][2][N] (what lnproj.hip applies on load).
+  // coop_ctr: one zeroed 32-bit counter per (sample group, N tile) of THIS launch (gemm_coop_counters() says how many).
+  unsigned* coop_ctr = nullptr; float* fn_ss = nullptr;
 };
+// can this launch finish in-kernel (GemmArgs::coop_ctr)?  Geometry of the ping-pong tiles, whole samples per counter group, grid <= CUs of the device.
+bool gemm_coop_ok(const GemmArgs& a);
+int gemm_coop_counters(const GemmArgs& a);
 bool gemm_fused_norm_ok(const GemmArgs& a);
 int gemm_launch(const GemmArgs& a, hipStream_t s);
 #define GN_SLAB_ROWS 64        // rows per fused GroupNorm-statistics partial of the in-kernel epilogue
@@ -224,7 +237,7 @@ int silu_bf16_launch(const bf16_t* x, bf16_t* y, int64_t n, hipStream_t s);
 int conv_in_launch(const float* x, const bf16_t* w /*[Cout][9][Cin]*/, const float* bias, int B, int Cin, int H, int W,
                    int Cout, bf16_t* y, hipStream_t s);
 // im2col of a tiny-Cin NCHW fp32 tensor for conv_in: out [B*H*W][kpad] bf16, k = tap*Cin + c (zero beyond 9*Cin)
-int im2col_nchw_launch(const float* x, int B, int Cin, int H, int W, int kpad, bf16_t* out, hipStream_t s);
+int im2col_nchw_launch(const float* x, int B, int Cin, int H, int W, int kpad, bf16_t* out, hipStream_t s, unsigned* zero = nullptr, int nzero = 0);
 // conv_out: NHWC bf16 (B,H,W,Cin) -> NCHW fp32 (B,Cout,H,W), 3x3 pad 1, direct (Cout tiny)
 int conv_out_launch(const bf16_t* x, const bf16_t* w /*[Cout][9][Cin]*/, const float* bias, int B, int Cin, int H, int W,
                     int Cout, float* y, hipStream_t s);

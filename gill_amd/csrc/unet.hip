@@ -124,6 +124,9 @@ struct gill_unet {
   float* ln_stats = nullptr;      // per-forward pool of the row-sum planes feeding the folded LayerNorms
   size_t ln_floats = 0, ln_next = 0;
   float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
+  // COOP arrival counters (GemmArgs::coop_ctr): one slot range per GEMM launch of a forward, bump-allocated in launch order (the dry run sizes the
+  // pool), all zeroed by the forward's first kernel (im2col_nchw_launch)
+  unsigned* coop_ctr = nullptr; size_t coop_n = 0, coop_next = 0;
   std::vector<bf16_t*> kcache, vcache;   // per transformer layer: [Bx][H][ctx_pad][dp] / [Bx][H][dpv][ctx_pad]
   int ctx_pad = 0;
   // XALG layers (XfW::xg): per-sample operands of the two cross-attention GEMMs — scores [Bx][80 H][C] + its folded-LayerNorm
@@ -703,21 +706,33 @@ struct UNetRun {
   // The GroupNorm (+ SiLU) that consumes a GEMM's output, offered to the producer: a split-K launch of a supported geometry runs it in
   // its reducer (gemm.hip "REDUCE + GROUPNORM") and sets `done`; otherwise the consumer runs its GroupNorm-apply as before.
   // raw_needed = false: nobody else reads the raw output (conv1 -> norm2 inside a ResnetBlock2D): it is not even written.
-  struct FusedNorm { const NormW* n; float eps; int silu; Tensor y; bool raw_needed; bool done; };
+  // ss: (optional) the consumer wants the per-(sample, channel) scale | shift table [Bx][2][C] instead of a normalised copy (the level-0 transformer
+  // blocks: lnproj.hip applies it to the rows it loads) — only the in-kernel finish (COOP) writes it; y is then unused.
+  struct FusedNorm { const NormW* n; float eps; int silu; Tensor y; bool raw_needed; bool done; float* ss = nullptr; };
   int gemm(GemmArgs& g, RowStats* rs = nullptr, Tensor* ys = nullptr, FusedNorm* fn = nullptr) {
+    // COOP counters of this launch: the same slot range in the dry run and in every real run (whether or not the launch ends up using them)
+    unsigned* ctr = dry ? nullptr : m->coop_ctr + m->coop_next;
+    m->coop_next += (size_t)gemm_coop_counters(g);
     if (dry) return 0;
+    GILL_REQUIRE(m->coop_next <= m->coop_n, "internal: COOP counter pool exhausted");
     pick_sk(g);
     // (split-K partials come from 128-row tiles: not where a sample's rows are fewer — the 8 x 8 maps of the mid block)
     if (g.out_mode == OUT_SOFTMAX80 || (g.wb_rows && g.wb_rows % 128 != 0)) g.splitk = 1;
-    if (fn && g.splitk > 1) {
+    g.coop_ctr = ctr;
+    if (fn) {
       g.rows_per_batch = fn->y.H * fn->y.W;
-      g.fn_Y = fn->y.p; g.fn_gamma = fn->n->g; g.fn_beta = fn->n->b; g.fn_eps = fn->eps; g.fn_silu = fn->silu;
+      g.fn_Y = fn->ss ? nullptr : fn->y.p; g.fn_ss = fn->ss;
+      g.fn_gamma = fn->n->g; g.fn_beta = fn->n->b; g.fn_eps = fn->eps; g.fn_silu = fn->silu;
       g.fn_cg = g.N / m->cfg.norm_num_groups;
-      if (gemm_fused_norm_ok(g)) {
+      // the finish inside the producing launch (gemm.hip "COOP"), else — split-K only — the reducer launch that also normalises
+      if (gemm_coop_ok(g) || (g.splitk > 1 && !fn->ss && gemm_fused_norm_ok(g))) {
         fn->done = true;
-        if (!fn->raw_needed) { g.C = nullptr; g.gn_stats = nullptr; if (ys) ys->stats = nullptr; }
+        if (!fn->raw_needed) {
+          g.C = nullptr;
+          if (g.splitk > 1) { g.gn_stats = nullptr; if (ys) ys->stats = nullptr; }      // (splitk == 1: the partials ARE the hand-off between the workgroups)
+        }
       } else {
-        g.fn_Y = nullptr;
+        g.fn_Y = nullptr; g.fn_ss = nullptr;
       }
     }
     if (rs) { g.row_stats = rs->p; rs->planes = gemm_row_planes(g); }
@@ -870,11 +885,18 @@ struct UNetRun {
     return attention_launch(a, s);
   }
 
+  // does xf() take its GroupNorm as a table (the fused projection kernel applies it on load)?  Mirrors the conditions inside xf().
+  bool xf_wants_table(const XfW& w, int HW, bool shared) const {
+    return w.wqkv1p != nullptr && !shared && lnproj_supported(w.C, Bx * HW, w.heads, w.dp) && HW % 128 == 0;
+  }
+
   // shared: `x` (and Bx on entry) cover only the first half of a CFG pair; the block runs at that half batch up to the end of
   // the self-attention, then the residual stream is duplicated and the rest runs on the full pair (Bx restored on return)
   // pre: x already normalised (this block's GroupNorm, no SiLU) by its producer's reducer; next: see resnet()
+  // pre_ss: this block's GroupNorm as a scale | shift table already written by its producer's in-kernel finish (FusedNorm::ss; only where
+  // xf_wants_table() said so)
   int xf(const Tensor& x, const XfW& w, Tensor* out, bool out_stats, bool shared = false, const Tensor* pre = nullptr,
-         FusedNorm* next = nullptr) {
+         FusedNorm* next = nullptr, const float* pre_ss = nullptr) {
     const int Bpre = Bx, Bfull = shared ? 2 * Bx : Bx;
     Bx = Bfull;                    // every buffer is sized for the full batch
     const int H = x.H, Wd = x.W, C = w.C, HW = H * Wd, M = Bfull * HW, M1 = Bpre * HW;
@@ -894,7 +916,8 @@ struct UNetRun {
     float* gn_ss = nullptr;
     bool gn_folded = false;
     if (lnproj && HW % 128 == 0) gn_ss = (float*)m->arena.alloc(sizeof(float) * (size_t)Bx * 2 * C);
-    if (pre && !shared) n = *pre;
+    if (pre_ss && gn_ss) { gn_ss = const_cast<float*>(pre_ss); gn_folded = true; }
+    else if (pre) n = *pre;
     else GILL_TRY(gnorm(x, nullptr, w.gn, 1e-6f, 0, n, 0.f, gn_ss, &gn_folded));
     Bx = Bfull;
     Tensor t = talloc(H, Wd, C);   // transformer residual stream
@@ -1014,14 +1037,16 @@ struct UNetRun {
     m->arena.off = 0;
     m->gn_next = 0;
     m->ln_next = 0;
-    // (the statistics pools need no zeroing: every partial sum is written exactly once by its producer)
+    m->coop_next = 0;
+    // (the statistics pools need no zeroing: every partial sum is written exactly once by its producer; the COOP arrival counters are zeroed
+    // by the forward's first kernel, below)
     std::vector<Tensor> skips;
     Tensor x = talloc(L, L, ch[0], true);
     {
       // conv_in: im2col (K = 9*Cin padded to 64) + MFMA GEMM
       const size_t mk = m->arena.mark();
       bf16_t* col = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * L * L * 64);
-      if (!dry) GILL_TRY(im2col_nchw_launch(sample, Bx, c.in_channels, L, L, 64, col, s));
+      if (!dry) GILL_TRY(im2col_nchw_launch(sample, Bx, c.in_channels, L, L, 64, col, s, m->coop_ctr, (int)m->coop_n));
       GILL_TRY(linear(col, 64, nullptr, 0, 64, Bx * L * L, m->conv_in_w, m->conv_in_b, ch[0], 64, nullptr, ACT_NONE, x.p, ch[0], &x));
       m->arena.release(mk);
     }
@@ -1029,12 +1054,19 @@ struct UNetRun {
     // Where a block's last GEMM is a split-K launch (levels 2-3 at the 8-sample batch) and the next consumer's first op is a
     // single-source GroupNorm, that norm is offered to the producer's reducer (FusedNorm): `pn` carries the normalised copy forward.
     // The copy is allocated whether or not the offer is taken (same arena layout in the dry run and in every real run).
+    // Round 6: the same offer goes to non-split producers too — the 3x3 convolutions of levels 0-1 finish the norm in their own epilogue
+    // (gemm.hip "COOP": the workgroups of a sample wait for each other's partials) — as a normalised copy, or (table) as the scale | shift table
+    // the level-0 projection kernel applies on load.
     FusedNorm pn{nullptr, 0.f, 0, Tensor(), true, false};
-    auto offer = [&](const NormW& n, float eps, int silu, int H, int W, int C) -> FusedNorm* {
-      pn = FusedNorm{&n, eps, silu, talloc(H, W, C), true, false};
+    auto offer = [&](const NormW& n, float eps, int silu, int H, int W, int C, bool table = false) -> FusedNorm* {
+      Tensor y; y.H = H; y.W = W; y.C = C;
+      if (!table) y = talloc(H, W, C);
+      pn = FusedNorm{&n, eps, silu, y, true, false};
+      if (table) pn.ss = (float*)m->arena.alloc(sizeof(float) * (size_t)Bx * 2 * C);
       return &pn;
     };
-    auto taken = [&]() -> const Tensor* { return pn.done ? &pn.y : nullptr; };
+    auto taken = [&]() -> const Tensor* { return (pn.done && !pn.ss) ? &pn.y : nullptr; };
+    auto taken_ss = [&]() -> const float* { return (pn.done && pn.ss) ? pn.ss : nullptr; };
     for (int i = 0; i < 4; ++i) {
       for (int j = 0; j < 2; ++j) {
         Tensor y;
@@ -1047,26 +1079,25 @@ struct UNetRun {
         pn.done = false;
         // this resnet's consumer: the transformer block's GroupNorm (i < 3), else the next resnet's / the mid block's norm1
         FusedNorm* nx = nullptr;
-        if (!share && i >= 2) {
-          if (i < 3) nx = offer(m->down_xf[i][j].gn, 1e-6f, 0, x.H, x.W, ch[i]);
-          else nx = offer(j == 0 ? m->down_res[3][1].n1 : m->mid_res[0].n1, 1e-5f, 1, x.H, x.W, ch[i]);
-        }
+        if (i < 3) nx = offer(m->down_xf[i][j].gn, 1e-6f, 0, x.H, x.W, ch[i], xf_wants_table(m->down_xf[i][j], x.H * x.W, share));
+        else nx = offer(j == 0 ? m->down_res[3][1].n1 : m->mid_res[0].n1, 1e-5f, 1, x.H, x.W, ch[i]);
         GILL_TRY(resnet(x, nullptr, m->down_res[i][j], &y, true, pre, nx));
         x = y;
         // next consumer: resnet norm1 (j == 0) / the downsample conv or the mid block's norm1 (j == 1)
         if (i < 3) {
           const Tensor* pre2 = taken();
           Tensor pre2_t; if (pre2) { pre2_t = *pre2; pre2 = &pre2_t; }
+          const float* pre2_ss = taken_ss();
           pn.done = false;
           FusedNorm* nx2 = (i >= 2 && j == 0) ? offer(m->down_res[i][1].n1, 1e-5f, 1, x.H, x.W, ch[i]) : nullptr;
-          Tensor z; GILL_TRY(xf(x, m->down_xf[i][j], &z, true, share, pre2, nx2)); x = z;   // next GroupNorm and / or a skip
+          Tensor z; GILL_TRY(xf(x, m->down_xf[i][j], &z, true, share, pre2, nx2, pre2_ss)); x = z;   // next GroupNorm and / or a skip
         }
         skips.push_back(x);
       }
       if (i < 3) {
         Tensor y = talloc(x.H / 2, x.W / 2, ch[i], true);
         pn.done = false;
-        FusedNorm* nx = (i >= 1) ? offer(m->down_res[i + 1][0].n1, 1e-5f, 1, y.H, y.W, ch[i]) : nullptr;
+        FusedNorm* nx = offer(m->down_res[i + 1][0].n1, 1e-5f, 1, y.H, y.W, ch[i]);
         GILL_TRY(conv(x, nullptr, m->down_ds[i], 2, 0, nullptr, 0, nullptr, y, nx));
         x = y;
         skips.push_back(x);
@@ -1094,14 +1125,15 @@ struct UNetRun {
         Tensor y;
         pn.done = false;
         // (norm1 of an up-block resnet is two-source: never offered; its conv2 feeds the transformer block's GroupNorm)
-        FusedNorm* nx = (i == 1) ? offer(m->up_xf[i][j].gn, 1e-6f, 0, x.H, x.W, ch[3 - i]) : nullptr;
+        FusedNorm* nx = (i >= 1) ? offer(m->up_xf[i][j].gn, 1e-6f, 0, x.H, x.W, ch[3 - i], xf_wants_table(m->up_xf[i][j], x.H * x.W, false)) : nullptr;
         GILL_TRY(resnet(x, &skip, m->up_res[i][j], &y, true, nullptr, nx));
         x = y;
         if (i > 0) {
           const Tensor* pre = taken();
           Tensor pre_t; if (pre) { pre_t = *pre; pre = &pre_t; }
+          const float* pre_ss = taken_ss();
           pn.done = false;
-          Tensor z; GILL_TRY(xf(x, m->up_xf[i][j], &z, true, false, pre, nullptr)); x = z;
+          Tensor z; GILL_TRY(xf(x, m->up_xf[i][j], &z, true, false, pre, nullptr, pre_ss)); x = z;
         }
       }
       if (i < 3) {
@@ -1137,11 +1169,12 @@ static int unet_plan_and_alloc(gill_unet* m) {
   UNetRun r{m, nullptr, Bx, nullptr, 0, true};
   GILL_TRY(r.forward(nullptr, nullptr));
   if (Bx % 2 == 0) {               // the CFG shared-prefix path allocates differently: size for the larger of the two
-    const size_t gn1 = m->gn_next; const size_t ln1 = m->ln_next;
+    const size_t gn1 = m->gn_next; const size_t ln1 = m->ln_next; const size_t co1 = m->coop_next;
     r.cfg_pair = true;
     GILL_TRY(r.forward(nullptr, nullptr));   // (arena.high is a running maximum)
     if (gn1 > m->gn_next) m->gn_next = gn1;
     if (ln1 > m->ln_next) m->ln_next = ln1;
+    if (co1 > m->coop_next) m->coop_next = co1;
   }
   // (unet_ctx_cache stages the XALG layers' T = ctx [G | G2]^T here: at most ctx_len x 2 x 8 x 1280 bf16 per sample)
   const size_t t_stage = sizeof(bf16_t) * (size_t)Bx * c.ctx_len * 2 * 8 * c.block_out_channels[3];
@@ -1152,6 +1185,8 @@ static int unet_plan_and_alloc(gill_unet* m) {
   GILL_TRY(m->pool.alloc(&m->gn_stats, m->gn_floats));
   m->ln_floats = m->ln_next + 64;           // counted by the dry run (max batch)
   GILL_TRY(m->pool.alloc(&m->ln_stats, m->ln_floats));
+  m->coop_n = m->coop_next + 64;            // COOP arrival counters: counted by the dry run
+  GILL_TRY(m->pool.alloc(&m->coop_ctr, m->coop_n));
   m->splitk_ws_floats = (size_t)48 << 20;   // 192 MiB of fp32 partials
   GILL_TRY(m->pool.alloc(&m->splitk_ws, m->splitk_ws_floats, false));
   // cross-attention K/V caches

@@ -81,21 +81,24 @@ def conv3x3(x1: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor]
 
 def conv3x3_gn(x: torch.Tensor, w_oihw: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
                groups: int = 32, eps: float = 1e-5, silu: bool = True, resid: Optional[torch.Tensor] = None, splitk: int = 2,
-               want_raw: bool = True):
-  """Split-K 3x3 convolution whose reducer also runs the consuming GroupNorm (+ SiLU).  x (B,H,W,Cin) bf16 NHWC with H * W in
-  {64, 256}; returns (y_raw or None, y_norm), both (B,H,W,Cout) bf16 — NaN-prefilled, so an unwritten element shows."""
+               want_raw: bool = True, coop: bool = True, rowvec: Optional[torch.Tensor] = None, want_table: bool = False, want_norm: bool = True):
+  """3x3 convolution + the consuming GroupNorm (+ SiLU) without a GroupNorm launch of its own (include/gill_amd.h gill_op_conv3x3_gn):
+  splitk >= 2 in the split-K reducer (coop=False) or inside the convolution's launch (coop=True, where the geometry allows); splitk == 1 in the
+  convolution's epilogue (coop=True) or as conv + GroupNorm-apply (coop=False, the reference dataflow).  x (B,H,W,Cin) bf16 NHWC, rowvec (B,Cout).
+  Returns (y_raw or None, y_norm or None[, table (B,2,Cout) fp32 when want_table]) — outputs NaN-prefilled, so an unwritten element shows."""
   x = _bf(x)
   B, H, W, Cin = x.shape
   Cout = w_oihw.shape[0]
   nan = float("nan")
   y_raw = torch.full((B, H, W, Cout), nan, device=x.device, dtype=torch.bfloat16) if want_raw else None
-  y_norm = torch.full((B, H, W, Cout), nan, device=x.device, dtype=torch.bfloat16)
+  y_norm = torch.full((B, H, W, Cout), nan, device=x.device, dtype=torch.bfloat16) if want_norm else None
+  table = torch.full((B, 2, Cout), nan, device=x.device, dtype=torch.float32) if want_table else None
   f = lambda t: None if t is None else t.float().contiguous()   # noqa: E731
-  w, bias, gamma, beta = f(w_oihw), f(bias), f(gamma), f(beta)
+  w, bias, gamma, beta, rowvec = f(w_oihw), f(bias), f(gamma), f(beta), f(rowvec)
   resid = None if resid is None else _bf(resid)
-  N.check(N.lib().gill_op_conv3x3_gn(N.ptr(x), N.ptr(w), N.ptr(bias), N.ptr(resid), N.ptr(gamma), N.ptr(beta), groups, float(eps),
-                                     int(silu), N.ptr(y_raw), N.ptr(y_norm), B, H, W, Cin, Cout, splitk, N.current_stream()))
-  return y_raw, y_norm
+  N.check(N.lib().gill_op_conv3x3_gn(N.ptr(x), N.ptr(w), N.ptr(bias), N.ptr(rowvec), N.ptr(resid), N.ptr(gamma), N.ptr(beta), groups, float(eps),
+                                     int(silu), N.ptr(y_raw), N.ptr(y_norm), N.ptr(table), B, H, W, Cin, Cout, splitk, int(coop), N.current_stream()))
+  return (y_raw, y_norm, table) if want_table else (y_raw, y_norm)
 
 
 def conv3x3_shortcut(x1: torch.Tensor, w_oihw: torch.Tensor, xs1: torch.Tensor, w_sc: torch.Tensor, bias: Optional[torch.Tensor] = None,

@@ -222,14 +222,20 @@ int gill_op_geglu(const void* A, const void* W, const float* bias, void* C, int 
 int gill_op_conv3x3(const void* x1, int C1, const void* x2, int C2, const float* w_oihw, const float* bias,
                     const float* rowvec, const void* resid, void* y, int B, int IH, int IW, int Cout, int stride, int ups,
                     int splitk, void* stream);
-/* 3x3 pad-1 stride-1 convolution run split-K, whose reducer also applies the GroupNorm (+ SiLU) that consumes the output
- * (diffusers ResnetBlock2D: conv1 -> norm2 -> nonlinearity, and a block's last convolution -> the next block's first norm; reference
- * call site gill/custom_sd.py:633-638): y_raw (optional, may be NULL) = conv(x) + bias + resid, y_norm = [silu](GroupNorm(y_raw)).
- * x (B,H,W,Cin) bf16 NHWC, w (Cout,Cin,3,3) fp32, gamma / beta (Cout) fp32; H * W in {64, 256}, Cout % 80 == 0,
- * Cout / groups a multiple of 4 that divides 80, splitk >= 2.  Synchronises. */
-int gill_op_conv3x3_gn(const void* x, const float* w_oihw, const float* bias, const void* resid, const float* gamma,
-                       const float* beta, int groups, float eps, int silu, void* y_raw, void* y_norm, int B, int H, int W,
-                       int Cin, int Cout, int splitk, void* stream);
+/* 3x3 convolution (stride 1, pad 1) + the GroupNorm (+ SiLU) that consumes it, without a GroupNorm launch where the geometry allows (diffusers
+ * ResnetBlock2D: conv1 -> norm2 -> silu, conv2 -> the next block's norm; reference call site gill/custom_sd.py:633-638):
+ * y_raw (optional, may be NULL) = conv(x) + bias + rowvec[b] + resid, y_norm = [silu](GroupNorm(y_raw)).
+ * x (B,H,W,Cin) bf16 NHWC, w (Cout,Cin,3,3) fp32, rowvec (B,Cout) fp32 optional, gamma / beta (Cout) fp32.
+ * splitk >= 2: H * W in {64, 256}, Cout % 80 == 0, Cout / groups a multiple of 4 that divides 80; the normalisation runs in the split-K reducer
+ *   launch (coop = 0) or inside the convolution's own launch by its co-resident workgroups (coop = 1, where the grid fits the device's CUs and
+ *   Cout % 160 == 0; otherwise as coop = 0).
+ * splitk == 1: coop = 1: in the convolution's epilogue (rows per sample a multiple of the 128- / 256-row tile, B * H * W % 256 == 0, Cout % 160 == 0,
+ *   grid <= CUs; an error elsewhere); coop = 0: convolution with fused statistics + a GroupNorm-apply launch (the reference dataflow).
+ * ss_out (optional; splitk == 1 && coop only): the scale | shift table [B][2][Cout] fp32 (y = x * scale + shift); y_norm may then be NULL.
+ * Synchronises. */
+int gill_op_conv3x3_gn(const void* x, const float* w_oihw, const float* bias, const float* rowvec, const void* resid, const float* gamma,
+                       const float* beta, int groups, float eps, int silu, void* y_raw, void* y_norm, float* ss_out, int B, int H, int W,
+                       int Cin, int Cout, int splitk, int coop, void* stream);
 /* conv3x3 (stride 1, pad 1) of x1 ++ x2 plus a fused 1x1 convolution of xs1 ++ xs2 (ResnetBlock2D.conv2 + conv_shortcut as one
  * implicit GEMM): y (B,IH,IW,Cout) bf16 NHWC; w_oihw (Cout, C1+C2, 3, 3) fp32, w_sc (Cout, CS1+CS2) fp32.  Synchronises. */
 int gill_op_conv3x3_shortcut(const void* x1, int C1, const void* x2, int C2, const float* w_oihw, const float* bias,

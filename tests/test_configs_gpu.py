@@ -271,11 +271,11 @@ _SWITCH_DEFAULT_OUT = {}
 _SWITCH_OPT_IN = set()      # switches that default to off (none at present)
 
 
-@pytest.mark.parametrize("switch", ["GILL_UNET_FFN_FUSED", "GILL_UNET_LNPROJ", "GILL_ATT_DMA", "GILL_GEMM_RED_GN", "GILL_UNET_XALG"])
+@pytest.mark.parametrize("switch", ["GILL_UNET_FFN_FUSED", "GILL_UNET_LNPROJ", "GILL_ATT_DMA", "GILL_GEMM_COOP", "GILL_UNET_XALG"])
 def test_fused_block_switches_full_size_forward(cuda, switch):
   """GILL_UNET_FFN_FUSED / GILL_UNET_LNPROJ / GILL_ATT_DMA (the level-0 attention on the LDS-DMA kernel, default, or on the register-staged
-  one) / GILL_GEMM_RED_GN (levels 2-3: GroupNorm-apply inside the split-K reducer of its producer, default, or as its own launch; all read
-  once per process) / GILL_UNET_XALG (levels 1-3: attn2 as two GEMMs on per-sample folded weights, default, or as to_q + attention kernel +
+  one) / GILL_GEMM_COOP (round 6: the finish of a split-K GEMM and the GroupNorm that consumes a 3x3 convolution done inside the producing
+  launch by its co-resident workgroups, default, or as the reducer / GroupNorm-apply launches of round 5; all read once per process) / GILL_UNET_XALG (levels 1-3: attn2 as two GEMMs on per-sample folded weights, default, or as to_q + attention kernel +
   to_out): one full-size SD-1.5 forward with the level-0 feed-forward sub-blocks as the fused
   kernel (default) and as GEGLU + the two-source GEMM — resp. with the projection pairs around norm1 / norm2 as one kernel each (lnproj.hip,
   default) and as separate GEMMs — in two subprocesses on the same seeded weights.  Both forms have their oracle

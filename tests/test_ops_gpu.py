@@ -356,6 +356,10 @@ def test_attention_dma_matches_register_staged(cuda):
   (3, 8, 8, 1280, 1280, 8, True, False, False),      # level 3
   (2, 16, 16, 1280, 1280, 2, False, True, True),     # conv2 + residual -> the transformer block's GroupNorm (no SiLU, eps 1e-6)
   (2, 8, 8, 640, 640, 4, True, True, True),          # groups of 20 channels (Cout 640): 4 groups per 80-column block
+  (8, 8, 8, 1280, 1280, 8, True, False, False),      # level 3 at the CFG batch 8: 4 x 8 tiles x 8 splits = 256 workgroups, two samples per 128-row tile
+  (8, 16, 16, 1280, 1280, 2, False, True, True),     # level 2 at the CFG batch 8: 16 x 8 x 2 = 256 workgroups, two M tiles per sample
+  (4, 8, 8, 640, 640, 4, True, True, True),          # groups of 20 channels on the in-kernel finish (two per 40-column unit)
+  (8, 16, 16, 640, 1280, 3, True, False, True),      # an odd split factor: 6 workgroups per counter group, 4 units
 ])
 def test_conv3x3_split_k_reducer_with_fused_groupnorm(cuda, B, H, W, Cin, Cout, splitk, silu, resid, raw):
   """gemm.hip "REDUCE + GROUPNORM": the split-K reducer of a 3x3 convolution also runs the GroupNorm (+ SiLU) that consumes the
@@ -373,12 +377,73 @@ def test_conv3x3_split_k_reducer_with_fused_groupnorm(cuda, B, H, W, Cin, Cout, 
   ref = F.group_norm(_bf(ref_raw).float(), 32, gamma, beta, eps)
   if silu:
     ref = F.silu(ref)
-  y_raw, y_norm = ops.conv3x3_gn(x.to(cuda), w.to(cuda), b.to(cuda), gamma.to(cuda), beta.to(cuda), 32, eps, silu,
-                                 None if r is None else r.to(cuda), splitk, raw)
+  outs = {}
+  for coop in (False, True):
+    # coop=True: the reduction + normalisation inside the convolution's own launch (gemm.hip "COOP", EPI 7) — ONE body with the reducer kernel
+    # (splitk_finish_unit), so wherever the reducer would have run on 40-column blocks the two must agree to the bit
+    y_raw, y_norm = ops.conv3x3_gn(x.to(cuda), w.to(cuda), b.to(cuda), gamma.to(cuda), beta.to(cuda), 32, eps, silu,
+                                   None if r is None else r.to(cuda), splitk, raw, coop=coop)
+    assert torch.isfinite(y_norm.float()).all()
+    assert _report(f"conv+GN B{B} {H}x{W} {Cin}->{Cout} sk{splitk} coop={coop}", y_norm.permute(0, 3, 1, 2), ref) < 1.5e-2
+    if raw:
+      assert _report("  raw", y_raw.permute(0, 3, 1, 2), ref_raw) < 1.5e-2
+    outs[coop] = (y_raw, y_norm)
+  if Cout % 160 == 0 and (Cout // 80) * B < 256:      # (reducer on 40-column blocks: reduce_gn_width())
+    assert torch.equal(outs[True][1], outs[False][1]), "in-kernel split-K finish differs from the reducer launch"
+    if raw:
+      assert torch.equal(outs[True][0], outs[False][0])
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,silu,resid,raw,rowvec,table", [
+  (8, 64, 64, 320, 320, True, False, False, True, False),     # UNet level 0 at the CFG batch 8: conv1 + time-embedding row -> norm2 (256 workgroups of 256 x 160)
+  (4, 64, 64, 320, 320, False, True, True, False, True),      # the shared CFG prefix (4 samples, 128-row tiles): conv2 + residual -> the transformer's GroupNorm, + table
+  (8, 32, 32, 640, 640, True, False, False, True, False),     # level 1: 128-row tiles, 8 workgroups per (sample, N tile), groups of 20 channels
+  (8, 32, 32, 320, 640, False, True, True, False, False),     # level 1, conv2 form with the raw tensor kept
+  (2, 32, 32, 640, 320, True, False, True, True, True),       # few samples: 16 + 16 workgroups on a 256-CU chip
+  (1, 16, 16, 320, 160, True, False, False, False, False),    # one 256-row tile per sample: a group of one workgroup (no waiting at all)
+])
+def test_conv3x3_groupnorm_finished_in_the_epilogue(cuda, B, H, W, Cin, Cout, silu, resid, raw, rowvec, table):
+  """gemm.hip "COOP" (EPI 6, round 6): the GroupNorm (+ SiLU) that consumes a non-split 3x3 convolution, finished by the convolution's own
+  workgroups — each publishes its per-slab partial sums, waits for the other M tiles of its (sample, N tile) on an arrival counter, totals the
+  partials in the GroupNorm-apply kernel's order and normalises straight from its accumulators.  Against F.conv2d + F.group_norm in fp32, and
+  against the reference dataflow (conv with fused statistics + groupnorm_apply_launch, coop=False): IDENTICAL bits — same statistics, same
+  summation order, same rounding of the values normalised.  table: the scale | shift form lnproj.hip consumes (y = raw * scale + shift)."""
+  from gill_amd import ops
+  x = _bf(_rnd((B, H, W, Cin), 290))
+  w = _rnd((Cout, Cin, 3, 3), 291, (9 * Cin) ** -0.5)
+  b = 0.1 * _rnd((Cout,), 292)
+  r = _bf(_rnd((B, H, W, Cout), 293)) if resid else None
+  rv = 0.3 * _rnd((B, Cout), 296) if rowvec else None
+  gamma, beta = 1.0 + 0.2 * _rnd((Cout,), 294), 0.1 * _rnd((Cout,), 295)
+  eps = 1e-5 if silu else 1e-6
+  ref_raw = F.conv2d(x.float().permute(0, 3, 1, 2), _bf(w).float(), b, padding=1)
+  if rowvec:
+    ref_raw = ref_raw + rv.view(B, Cout, 1, 1)
+  if resid:
+    ref_raw = ref_raw + r.float().permute(0, 3, 1, 2)
+  ref = F.group_norm(_bf(ref_raw).float(), 32, gamma, beta, eps)
+  if silu:
+    ref = F.silu(ref)
+  dev = lambda t: None if t is None else t.to(cuda)   # noqa: E731
+  res = ops.conv3x3_gn(dev(x), dev(w), dev(b), dev(gamma), dev(beta), 32, eps, silu, dev(r), 1, raw, coop=True, rowvec=dev(rv), want_table=table)
+  y_raw, y_norm = res[0], res[1]
   assert torch.isfinite(y_norm.float()).all()
-  assert _report(f"conv+GN B{B} {H}x{W} {Cin}->{Cout} sk{splitk}", y_norm.permute(0, 3, 1, 2), ref) < 1.5e-2
+  assert _report(f"conv+GN in the epilogue B{B} {H}x{W} {Cin}->{Cout}", y_norm.permute(0, 3, 1, 2), ref) < 1.5e-2
   if raw:
     assert _report("  raw", y_raw.permute(0, 3, 1, 2), ref_raw) < 1.5e-2
+  base_raw, base_norm = ops.conv3x3_gn(dev(x), dev(w), dev(b), dev(gamma), dev(beta), 32, eps, silu, dev(r), 1, True, coop=False, rowvec=dev(rv))
+  assert torch.equal(y_norm, base_norm), f"in-epilogue GroupNorm differs from conv + GroupNorm-apply: {(y_norm.float() - base_norm.float()).abs().max().item():.3e}"
+  if raw:
+    assert torch.equal(y_raw, base_raw)
+  again = ops.conv3x3_gn(dev(x), dev(w), dev(b), dev(gamma), dev(beta), 32, eps, silu, dev(r), 1, raw, coop=True, rowvec=dev(rv))[1]
+  assert torch.equal(y_norm, again)
+  if table:
+    t = res[2]
+    assert torch.isfinite(t).all()
+    from_table = base_raw.float() * t[:, 0].view(B, 1, 1, Cout) + t[:, 1].view(B, 1, 1, Cout)
+    if silu:
+      from_table = F.silu(from_table)
+    assert _report("  raw * scale + shift (table)", from_table.permute(0, 3, 1, 2), ref) < 1.5e-2
 
 
 # ---------------------------------------------------------------- norms
