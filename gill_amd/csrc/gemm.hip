@@ -59,6 +59,7 @@ struct GemmDev {
   int kt;            // K elements per ring stage: 64 (2-deep ring) or 32 (4-deep ring, 128-row tiles only)
   int n_major;       // 1: consecutive tile ids walk M first (an XCD's contiguous id range = a range of N tiles over every M tile)
   int tiles_m;
+  int xb_m, xb_n;    // > 0: XCD BLOCK MAP — XCD x owns an xb_m x xb_n block of the (M tile, N group) grid (see xcd_block_pick()); 0: the range map above
 };
 
 __device__ __noinline__ float gelu_erf_call(float v) { return gelu_erf(v); }  // keeps erff out of the unrolled epilogue
@@ -165,14 +166,30 @@ __device__ __forceinline__ void splitk_finish_unit(const GemmArgs& p, const int 
     rr[r] = p.resid ? *reinterpret_cast<const uint2*>((const bf16_t*)p.resid + (size_t)row_of(r) * p.ldr + n) : make_uint2(0u, 0u);
   const float* src = p.ws + (size_t)(mbase + ty) * p.N + n;
   const size_t zstride = (size_t)p.M * p.N, rstride = (size_t)16 * p.N;
+  // slices are ADDED in slice order whatever the order their loads go out in.  Few rows per thread (RPT = 4: the 64-row samples of UNet level 3,
+  // split up to eight ways): the first eight slices' loads all at once — 32 independent 16-B loads per thread, ONE memory round trip — where a loop
+  // over the slices is one round trip per slice (round 6: inside gemm_kernel's COOP finish one workgroup per CU has no neighbour to hide them: the
+  // level-3 finish took 21 us that way; clamped slice index + predicated add, so absent slices cost a redundant load and nothing else).
+  constexpr int CH = (RPT <= 4) ? 8 : 2;
+  {
+    float4 t[CH][RPT];
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) v[r] = *reinterpret_cast<const float4*>(src + (size_t)r * rstride);
-  float4 t1[RPT];
+    for (int u = 0; u < CH; ++u) {
+      const int zz = (u < p.splitk) ? u : p.splitk - 1;
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) t1[r] = *reinterpret_cast<const float4*>(src + zstride + (size_t)r * rstride);      // (splitk >= 2)
+      for (int r = 0; r < RPT; ++r) t[u][r] = *reinterpret_cast<const float4*>(src + (size_t)zz * zstride + (size_t)r * rstride);
+    }
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) { v[r].x += t1[r].x; v[r].y += t1[r].y; v[r].z += t1[r].z; v[r].w += t1[r].w; }
-  for (int z = 2; z < p.splitk; ++z) {
+    for (int r = 0; r < RPT; ++r) v[r] = t[0][r];
+#pragma unroll
+    for (int u = 1; u < CH; ++u) {
+      if (u < p.splitk) {      // (uniform; splitk >= 2)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) { v[r].x += t[u][r].x; v[r].y += t[u][r].y; v[r].z += t[u][r].z; v[r].w += t[u][r].w; }
+      }
+    }
+  }
+  for (int z = CH; z < p.splitk; ++z) {
     float4 t[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) t[r] = *reinterpret_cast<const float4*>(src + (size_t)z * zstride + (size_t)r * rstride);
@@ -363,8 +380,19 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
   }
   // weight-heavy problems (N*K > the activation matrix: UNet levels 2-3, the LM) give each XCD a range of N tiles, so every
   // weight is fetched into one L2 only; activation-heavy ones a range of M tiles (N tiles and 3x3 halo rows share the L2)
-  const int gn = d.n_major ? tile / d.tiles_m : tile % d.groups_n;
-  const int tm = d.n_major ? tile % d.tiles_m : tile / d.groups_n;
+  int gn = d.n_major ? tile / d.tiles_m : tile % d.groups_n;
+  int tm = d.n_major ? tile % d.tiles_m : tile / d.groups_n;
+  if (d.xb_m > 0) {
+    // XCD block map (round 6): the 8 XCDs tile the (M tile, N group) grid with xb_m x xb_n blocks, so that an XCD's L2 holds xb_m tiles' worth of
+    // activations (read once, re-used by the 3x3 taps and by the block's N groups) and 1 / (groups_n / xb_n) of the weights — the two range maps
+    // above are its extreme cases (all of M x 1/8 of N: every L2 pulls the whole activation tensor per tap; 1/8 of M x all of N: every L2 pulls
+    // every weight).  gridDim.x == tiles_m * groups_n == 8 * xb_m * xb_n (xcd_block_pick()).
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int blocks_m = d.tiles_m / d.xb_m;
+    const int bmi = xcd % blocks_m, bni = xcd / blocks_m;
+    tm = bmi * d.xb_m + idx % d.xb_m;
+    gn = bni * d.xb_n + idx / d.xb_m;
+  }
   const int m0 = tm * BM;
   const int tn_first = gn * d.npw;
   // (convolutions and split-K partials: one N tile per workgroup — gemm_launch_bn() — known at compile time, so that the K walk's
@@ -1738,6 +1766,45 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
   }
 }
 
+// XCD BLOCK MAP.  Model of the fabric traffic of one launch under a map that gives every XCD an xm x xn block of the (M tile, N group) grid (all
+// K splits of a tile sit on its XCD: blockIdx.y does not move the XCD when gridDim.x % 8 == 0):
+//   activations: the block's rows x the channels a K walk reads, once if they fit next to the streaming weights in the 4 MiB L2 (budget 2 MiB),
+//                else once per re-read (a tap-major 3x3 convolution re-reads its input rows 9 times, a plain GEMM once per N tile a workgroup walks);
+//   weights:     the block's N columns x K, once (the block's M tiles walk K in step and share the stream).
+// Picks the block with the least modelled traffic; the two range maps (n_major / m-major) are candidates like any other, and the block map is only
+// used where it beats the range map in force by 15 % (profiles/r06_xcd_block_map.md: level-2 convolutions 417 -> ... MB per dispatch).
+static void xcd_block_pick(const GemmArgs& a, GemmDev& d, int bm_rows, int bn_cols, int ncls) {
+  d.xb_m = d.xb_n = 0;
+  static const bool on = [] { const char* e = getenv("GILL_XMAP"); return !(e && e[0] == '0'); }();     // round-6 A/B switch (removed once measured)
+  const int nwg = d.tiles_m * d.groups_n;
+  // (the ping-pong tiles only — the 3x3 convolutions and the long-K plain GEMMs of levels 1-3, one workgroup per CU: the launches whose fetch
+  // profiles/r05_fetch_by_kernel.md flagged; the model is not trusted on the multi-N-tile walks of the GEGLU / QKV kernels)
+  if (!on || ncls != 1 || nwg % 8 != 0 || nwg < 16 || a.wb_rows || d.nwv != 8 || bn_cols != 160) return;
+  const double l2_budget = 2.0 * 1024 * 1024;
+  const int taps = a.conv ? 9 : 1;
+  const double row_bytes = 2.0 * (a.conv ? (double)(a.Cin + a.KX) * (a.stride == 2 ? 4 : 1) : (double)a.K);     // input bytes behind one output row
+  const double col_bytes = 2.0 * (double)a.K * bn_cols * d.npw;                                                   // weight bytes of one N group
+  auto cost = [&](double xm, double xn) {
+    const double A = xm * bm_rows * row_bytes, W = xn * col_bytes;
+    // (a plain GEMM's N groups of one M tile run side by side on the XCD and share the activation stream; only a workgroup's own walk over npw N
+    // tiles comes back to the same rows later)
+    const double rereads = (A <= l2_budget) ? 1.0 : (a.conv ? (a.k_chunked ? 1.0 : (double)taps) : (double)d.npw);
+    return A * rereads + W;
+  };
+  double best = 1e30; int bxm = 0, bxn = 0;
+  for (int blocks_m = 1; blocks_m <= 8; blocks_m *= 2) {
+    const int blocks_n = 8 / blocks_m;
+    if (d.tiles_m % blocks_m != 0 || d.groups_n % blocks_n != 0) continue;
+    const int xm = d.tiles_m / blocks_m, xn = d.groups_n / blocks_n;
+    const double c = cost(xm, xn);
+    if (c < best) { best = c; bxm = xm; bxn = xn; }
+  }
+  if (bxm == 0) return;
+  // the range map in force: n_major = (all of M, 1/8 of N) per XCD, else (1/8 of M, all of N) — priced with the same model
+  const double cur = d.n_major ? cost(d.tiles_m, d.groups_n / 8.0) : cost(d.tiles_m / 8.0, d.groups_n);
+  if (best <= 0.85 * cur) { d.xb_m = bxm; d.xb_n = bxn; }
+}
+
 template <int BN>
 static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   GemmDev d;
@@ -1807,6 +1874,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     const int64_t ael = (int64_t)a.M * (a.conv ? a.Cin + a.KX : a.K);
     d.n_major = (wel > ael && d.groups_n >= 8) ? 1 : 0;
   }
+  xcd_block_pick(a, d, (d.nwv / 2) * d.mi * 16, BN, ncls);
   GILL_REQUIRE(a.wb_rows == 0 || (a.wb_rows % ((d.nwv / 2) * d.mi * 16) == 0 && !a.conv), "per-sample weights: tiles must not straddle samples");
   dim3 grid(tiles_m * d.groups_n, sk, ncls);
   if (d.nwv == 8) GILL_REQUIRE(d.npw == 1, "internal: the ping-pong kernel walks one N tile per workgroup");
@@ -1863,7 +1931,7 @@ static int gemm_launch_stream64(const GemmArgs& a, hipStream_t s) {
   GILL_REQUIRE(d.zero != nullptr, "zero page unavailable");
   const int sk = a.splitk > 1 ? a.splitk : 1;
   d.a.splitk = sk;
-  d.tiles_n = a.N / 64; d.tiles_m = cdiv(a.M, 128); d.npw = 1; d.groups_n = d.tiles_n; d.n_major = 1;
+  d.tiles_n = a.N / 64; d.tiles_m = cdiv(a.M, 128); d.npw = 1; d.groups_n = d.tiles_n; d.n_major = 1; d.xb_m = d.xb_n = 0;
   d.kt = 64;
   d.ksteps = a.K / 64;
   d.ksteps_per_split = cdiv(d.ksteps, sk);

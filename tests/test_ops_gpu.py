@@ -400,7 +400,7 @@ def test_conv3x3_split_k_reducer_with_fused_groupnorm(cuda, B, H, W, Cin, Cout, 
   (8, 32, 32, 640, 640, True, False, False, True, False),     # level 1: 128-row tiles, 8 workgroups per (sample, N tile), groups of 20 channels
   (8, 32, 32, 320, 640, False, True, True, False, False),     # level 1, conv2 form with the raw tensor kept
   (2, 32, 32, 640, 320, True, False, True, True, True),       # few samples: 16 + 16 workgroups on a 256-CU chip
-  (1, 16, 16, 320, 160, True, False, False, False, False),    # one 256-row tile per sample: a group of one workgroup (no waiting at all)
+  (1, 16, 16, 320, 320, True, False, False, False, False),    # one sample of 256 rows: two 128-row tiles per (sample, N tile), four workgroups in all
 ])
 def test_conv3x3_groupnorm_finished_in_the_epilogue(cuda, B, H, W, Cin, Cout, silu, resid, raw, rowvec, table):
   """gemm.hip "COOP" (EPI 6, round 6): the GroupNorm (+ SiLU) that consumes a non-split 3x3 convolution, finished by the convolution's own
