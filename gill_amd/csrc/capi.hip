@@ -173,7 +173,7 @@ extern "C" int gill_op_conv3x3_gn(const void* x, const float* w_oihw, const floa
     GILL_TRY(st.alloc(sizeof(float) * (size_t)B * (H * W / GN_SLAB_ROWS_MIN) * (Cout / sbin) * 2));
     g.gn_stats = (float*)st.p; g.gn_groups = Cout / sbin; g.gn_cg = sbin;
   }
-  if (coop) g.coop_ctr = (unsigned*)ctr.p;
+  if (coop) { g.coop_ctr = (unsigned*)ctr.p; g.coop_splitk = 1; }
   if (splitk == 1 && !coop) {
     // reference dataflow: the convolution files its statistics, a GroupNorm-apply launch normalises the rounded tensor
     g.fn_Y = nullptr; g.fn_ss = nullptr;

@@ -340,8 +340,19 @@ __device__ __forceinline__ void ln_row_factors(const GemmArgs& p, int m, float& 
 // small plain GEMMs: the same 48 KiB of LDS as the 2-wave 64 x 128 tile (three workgroups per CU), twice the waves per CU.
 // (The timing-only ablation guards of round 4 — PP_ABL: no fragment reads / no LDS-DMA / no MFMAs / no bookkeeping / no epilogue / no barriers —
 // are gone from this file; their table is profiles/r04_pingpong_ablations.md, the bare loops live on in tools/ubench/gemm_loop.hip and gemm_ws.hip.)
-template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT, int MI>
-__global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 2 : 1) : (MI == 2 ? 3 : 2)) void gemm_kernel(const GemmDev d) {
+// The kernel body is a device function of the workgroup's coordinates (gemm_kernel below passes blockIdx / gridDim), so that a PERSISTENT launch can
+// run several GEMMs back to back in one workgroup (tools/ubench/persist_resnet.hip, round 6: the go / no-go prototype of one launch per ResnetBlock2D).
+// SEAM (prototype only; 0 in every product instantiation — all of it compiles away): the tile is one PHASE of such a launch.  On entry it waits on
+// the arrival counter of the M-tile group whose rows it reads (seam_in) — after issuing the WEIGHT pieces of its first ring stages when
+// `prefetch` is set (weights do not depend on the previous phase: MI355X_MICROARCH "prefetch-credit") — and on exit (EPI 7) it publishes its
+// finished units and arrives on seam_out.
+struct GemmTileCtx {
+  int bx, by, bz, gdx, gdy;
+  unsigned* seam_in = nullptr; unsigned seam_in_target = 0; int seam_in_mtg = 1; int prefetch = 0;
+  unsigned* seam_out = nullptr;
+};
+template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT, int MI, int SEAM = 0>
+__device__ __forceinline__ void gemm_tile(const GemmDev& d, const GemmTileCtx cx) {
   constexpr int BM = (NWV / 2) * MI * 16;
   static_assert(MI == 4 || (MI == 2 && NWV == 4 && CONV == 0 && (STAGES == 2 || STAGES == 3) && KT == 64) ||
                     (MI == 2 && NWV == 8 && BN == 160 && STAGES == 3 && KT == 64) || (MI == 2 && NWV == 8 && BN == 64 && STAGES == 6 && CONV == 0 && KT == 64) ||
@@ -373,7 +384,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
   // XCD-aware (bijective) remap of the workgroup id
   int tile;
   {
-    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int nwg = cx.gdx, bid = cx.bx;
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -387,7 +398,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
     // activations (read once, re-used by the 3x3 taps and by the block's N groups) and 1 / (groups_n / xb_n) of the weights — the two range maps
     // above are its extreme cases (all of M x 1/8 of N: every L2 pulls the whole activation tensor per tap; 1/8 of M x all of N: every L2 pulls
     // every weight).  gridDim.x == tiles_m * groups_n == 8 * xb_m * xb_n (xcd_block_pick()).
-    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int bid = cx.bx, xcd = bid & 7, idx = bid >> 3;
     const int blocks_m = d.tiles_m / d.xb_m;
     const int bmi = xcd % blocks_m, bni = xcd / blocks_m;
     tm = bmi * d.xb_m + idx % d.xb_m;
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
   // state is dead by the epilogue instead of being carried around it for a next tile that never comes)
   const int ntl = (CONV != 0 || EPI == 2 || EPI == 7) ? 1 : ((d.tiles_n - tn_first < d.npw) ? d.tiles_n - tn_first : d.npw);   // N tiles of this workgroup
   int n0 = tn_first * BN;
-  const int z = blockIdx.y;
+  const int z = cx.by;
   const int kt_beg = z * d.ksteps_per_split;
   int kt_end = kt_beg + d.ksteps_per_split;
   if (kt_end > d.ksteps) kt_end = d.ksteps;
@@ -410,7 +421,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
   // layer is four stride-1 2x2-tap convolutions of the SOURCE grid — K = 4 Cin instead of 9 Cin, the same linear map with 2.25x
   // fewer multiply-adds.  blockIdx.z = parity class; p.M = source pixels (rows of one class); output row of source row m:
   // (b * OH + 2y + py) * OW + 2x + px.
-  const int cls = (CONV == 3) ? blockIdx.z : 0;
+  const int cls = (CONV == 3) ? cx.bz : 0;
   const int ups_py = cls >> 1, ups_px = cls & 1;
 
   // ---- per-lane staging geometry: instruction i of wave w fills tile rows (i*NWV+w)*RPI .. +RPI
@@ -599,6 +610,23 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
                                        (__attribute__((address_space(3))) void*)l, 16, 0, WBLK ? 2 : 0);     // (aux 2 = nt)
     }
   };
+  // (SEAM prologue only: the two halves of issue_dma on their own — the W pieces `koff` elements ahead of the walk's current position)
+  auto issue_dma_a = [&](int buf) {
+    bf16_t* As = smem + buf * BUF_ELEMS;
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[i],
+                                       (__attribute__((address_space(3))) void*)(As + (i * NWV + w) * RPI * KT), 16, 0, 0);
+  };
+  auto issue_dma_w = [&](int buf, int koff) {
+    bf16_t* Bs = smem + buf * BUF_ELEMS + A_ELEMS;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      if (i == WI - 1 && !w_last_ok) break;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[i] + koff),
+                                       (__attribute__((address_space(3))) void*)(Bs + (i * NWV + w) * RPI * KT), 16, 0, 0);
+    }
+  };
   auto issue_post = [&]() {
     ++steps_in_tile;
     --seg_left;
@@ -622,9 +650,34 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
 
   static_assert(STAGES >= 2 && STAGES <= 6, "ring depth");
   const int total_steps = ntl * nsteps;
+  if constexpr (SEAM != 0) {
+    static_assert(SEAM == 0 || (PP && !WBLK), "SEAM: the ping-pong tiles");
+    if (cx.seam_in) {
+      if (cx.prefetch) {
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+          if (s < total_steps) issue_dma_w(s, s * KT);
+      }
+      if (tid == 0) {
+        unsigned* c = cx.seam_in + tm / cx.seam_in_mtg;
+        for (unsigned spins = 0; __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cx.seam_in_target && spins < COOP_SPIN_LIMIT; ++spins)
+          __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __builtin_amdgcn_s_barrier();      // (raw: a __syncthreads() here would drain the weight pieces in flight)
+#pragma unroll
+      for (int s = 0; s < STAGES - 1; ++s)
+        if (s < total_steps) { issue_prepare(); issue_dma_a(s); if (!cx.prefetch) issue_dma_w(s, 0); issue_post(); }
+    } else {
+#pragma unroll
+      for (int s = 0; s < STAGES - 1; ++s)
+        if (s < total_steps) issue(s);
+    }
+  } else {
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < total_steps) issue(s);
+  }
   // folded LayerNorm (GEGLU / QKV epilogues): the row factors are loaded here, under the first tile's DMA latency
   float ln_rr[4] = {1.f, 1.f, 1.f, 1.f}, ln_rm[4] = {0.f, 0.f, 0.f, 0.f};   // (first MI entries used)
   if constexpr (EPI == 1 || EPI == 3 || EPI == 5) {
@@ -664,6 +717,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
     // two-way test — wait_vm()'s general switch is a chain of ~13 compare-and-branch pairs, twice per K step, at the END of group A's MMA phase
     auto landed = [&](int k) {
       if (k >= nsteps) return;
+      if constexpr (SEAM != 0) {
+        // prefetched prologue: the pieces went out as [W0 W1 | A0 A1] — stage 0 is complete once only A1's pieces are in flight
+        if (cx.seam_in && cx.prefetch && k == 0 && issued == STAGES - 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI) : "memory"); return; }
+      }
       if (issued - 1 - k <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (w_last_ok) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + WI) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + WI - 1) : "memory");
@@ -857,7 +914,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
       __syncthreads();                                       // ... before the one arrival of the workgroup
       const int rpb = p.rows_per_batch;
       const int mtg = rpb > BM ? rpb / BM : 1, spg = rpb < BM ? BM / rpb : 1;
-      const int G = mtg * (int)gridDim.y;
+      const int G = mtg * cx.gdy;
       const int tg = tm / mtg;
       unsigned char* cs = smem_raw + 16384;                  // (the ring is dead; [0, 5 KiB) is the row-major epilogue's `red`, unused here)
       float2 (*part)[10] = reinterpret_cast<float2 (*)[10]>(cs);
@@ -878,6 +935,17 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
         if (rpb == 256) splitk_finish_unit<16, 40>(p, b, col0, tid, part, quad, mr, poison);
         else splitk_finish_unit<4, 40>(p, b, col0, tid, part, quad, mr, poison);
         __syncthreads();                                     // (the scratch is reused by the next unit)
+      }
+      if constexpr (SEAM != 0) {
+        if (cx.seam_out) {      // this phase's units are finished: publish them (plain stores -> one agent-scope release) and arrive
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(cx.seam_out + tg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
       }
     }
   } else if constexpr (EPI == 1) {
@@ -1358,6 +1426,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
   }   // N tiles of this workgroup
 #undef SWZ
 }
+template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT, int MI>
+__global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 2 : 1) : (MI == 2 ? 3 : 2)) void gemm_kernel(const GemmDev d) {
+  GemmTileCtx cx;
+  cx.bx = blockIdx.x; cx.by = blockIdx.y; cx.bz = blockIdx.z; cx.gdx = gridDim.x; cx.gdy = gridDim.y;
+  gemm_tile<NWV, BN, CONV, EPI, STAGES, KT, MI, 0>(d, cx);
+}
 
 // split-K reduction + epilogue
 // Block = 64 rows x W columns (W = 80 when the fused GroupNorm bins need it, else 64), 16 row lanes x W/4 column quads:
@@ -1583,14 +1657,16 @@ static int coop_tile_rows(const GemmArgs& a, int sk) {
   if (!gemm_plain_pingpong_args(a)) return 0;
   return ((int64_t)cdiv(a.M, 256) * tiles_n * sk <= 128 || a.M % 256 != 0) ? 128 : 256;
 }
-// GILL_GEMM_COOP = 0: every finish as its own launch (split-K reducers, GroupNorm-apply), the round-5 dataflow (A/B and the on / off parity test)
-static bool coop_on() {
-  static const bool on = [] { const char* e = getenv("GILL_GEMM_COOP"); return !(e && e[0] == '0'); }();
-  return on;
+// GILL_GEMM_COOP = 0: every finish as its own launch (split-K reducers, GroupNorm-apply), the round-5 dataflow (A/B and the on / off parity test);
+// 1 (default): the GroupNorm finish in the 3x3 convolutions' epilogue (EPI 6: a measured go); 2: also the split-K finish (EPI 7: a measured no-go)
+int gemm_coop_mode() {
+  static const int mode = [] { const char* e = getenv("GILL_GEMM_COOP"); return e ? atoi(e) : 1; }();
+  return mode;
 }
 bool gemm_coop_ok(const GemmArgs& a) {
-  if (!a.coop_ctr || !coop_on()) return false;
+  if (!a.coop_ctr || gemm_coop_mode() == 0) return false;
   const int sk = a.splitk > 1 ? a.splitk : 1;
+  if (sk > 1 && !a.coop_splitk) return false;
   const int bm = coop_tile_rows(a, sk);
   const int rpb = a.rows_per_batch;
   if (bm == 0 || rpb <= 0 || a.M % bm != 0 || a.M % rpb != 0) return false;
@@ -1775,11 +1851,10 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
 // used where it beats the range map in force by 15 % (profiles/r06_xcd_block_map.md: level-2 convolutions 417 -> ... MB per dispatch).
 static void xcd_block_pick(const GemmArgs& a, GemmDev& d, int bm_rows, int bn_cols, int ncls) {
   d.xb_m = d.xb_n = 0;
-  static const bool on = [] { const char* e = getenv("GILL_XMAP"); return !(e && e[0] == '0'); }();     // round-6 A/B switch (removed once measured)
   const int nwg = d.tiles_m * d.groups_n;
   // (the ping-pong tiles only — the 3x3 convolutions and the long-K plain GEMMs of levels 1-3, one workgroup per CU: the launches whose fetch
   // profiles/r05_fetch_by_kernel.md flagged; the model is not trusted on the multi-N-tile walks of the GEGLU / QKV kernels)
-  if (!on || ncls != 1 || nwg % 8 != 0 || nwg < 16 || a.wb_rows || d.nwv != 8 || bn_cols != 160) return;
+  if (ncls != 1 || nwg % 8 != 0 || nwg < 16 || a.wb_rows || d.nwv != 8 || bn_cols != 160) return;
   const double l2_budget = 2.0 * 1024 * 1024;
   const int taps = a.conv ? 9 : 1;
   const double row_bytes = 2.0 * (a.conv ? (double)(a.Cin + a.KX) * (a.stride == 2 ? 4 : 1) : (double)a.K);     // input bytes behind one output row

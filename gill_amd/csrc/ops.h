@@ -82,10 +82,15 @@ struct GemmArgs {
   //     (C itself only when non-null), and / or the per-(sample, channel) scale | shift table fn_ss [B][2][N] (what lnproj.hip applies on load).
   // coop_ctr: one zeroed 32-bit counter per (sample group, N tile) of THIS launch (gemm_coop_counters() says how many).
   unsigned* coop_ctr = nullptr; float* fn_ss = nullptr;
+  // coop_splitk: also allow the split-K finish (EPI 7).  MEASURED NO-GO (profiles/r06_coop_finish.md: +1 ... +6 us per launch against conv + reducer,
+  // the loop +1.7 %): the engine sets it only under GILL_GEMM_COOP=2, the operator entry sets it on request (the parity tests, tools/coop_bench.py,
+  // tools/ubench/persist_resnet.hip build on it).
+  int coop_splitk = 0;
 };
 // can this launch finish in-kernel (GemmArgs::coop_ctr)?  Geometry of the ping-pong tiles, whole samples per counter group, grid <= CUs of the device.
 bool gemm_coop_ok(const GemmArgs& a);
 int gemm_coop_counters(const GemmArgs& a);
+int gemm_coop_mode();      // GILL_GEMM_COOP: 0 = every finish a launch of its own, 1 (default) = GroupNorm finish in the conv epilogue, 2 = + the split-K finish
 bool gemm_fused_norm_ok(const GemmArgs& a);
 int gemm_launch(const GemmArgs& a, hipStream_t s);
 #define GN_SLAB_ROWS 64        // rows per fused GroupNorm-statistics partial of the in-kernel epilogue

@@ -719,6 +719,7 @@ struct UNetRun {
     // (split-K partials come from 128-row tiles: not where a sample's rows are fewer — the 8 x 8 maps of the mid block)
     if (g.out_mode == OUT_SOFTMAX80 || (g.wb_rows && g.wb_rows % 128 != 0)) g.splitk = 1;
     g.coop_ctr = ctr;
+    g.coop_splitk = gemm_coop_mode() >= 2;      // (the split-K finish in-kernel: a measured no-go, opt-in — GemmArgs::coop_splitk)
     if (fn) {
       g.rows_per_batch = fn->y.H * fn->y.W;
       g.fn_Y = fn->ss ? nullptr : fn->y.p; g.fn_ss = fn->ss;
