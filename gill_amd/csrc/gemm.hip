@@ -281,6 +281,14 @@ __device__ __forceinline__ float ld_wt_f32(const float* p) {
   return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 #define COOP_SPIN_LIMIT (1u << 18)
+__device__ __forceinline__ void coop_arrive(unsigned* ctr) { __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool coop_wait(unsigned* ctr, unsigned target) {
+  for (unsigned spins = 0;; ++spins) {
+    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    if (spins > COOP_SPIN_LIMIT) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
 __device__ __forceinline__ bool coop_arrive_wait(unsigned* ctr, unsigned target) {
   __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (unsigned spins = 0;; ++spins) {
@@ -1265,7 +1273,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, const GemmTileCtx cx
           if (st && hi) *reinterpret_cast<float4*>((float*)p.C + crow[i] + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
           uint4 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
-          const bool stc = st && (EPI != 6 || p.C != nullptr);     // (COOP: the raw tensor only where somebody else reads it)
+          const bool stc = st && EPI != 6;     // (COOP: the raw tensor — where somebody else reads it — is stored AFTER the arrival, see below)
           if (stc && hi) *reinterpret_cast<uint4*>((bf16_t*)p.C + crow[i] + n) = o;
           else if (stc) *reinterpret_cast<uint2*>((bf16_t*)p.C + crow[i] + n) = make_uint2(o.x, o.y);
           if constexpr (EPI == 6) {      // the finished values stay in the accumulators until the group's statistics are complete
@@ -1345,13 +1353,36 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, const GemmTileCtx cx
       // folds gamma / beta into per-column scale | shift and normalises the ROUNDED values it still holds in its accumulators — what the
       // stand-alone pass would have read back from HBM.
       static_assert(EPI != 6 || (PP && CONV == 1), "COOP GroupNorm finish: the ping-pong convolution tiles");
+      // Order (round 6, second pass): nothing but the few partial stores is in flight at the drain — the raw tensor's 40-80 KiB of stores per
+      // workgroup go out AFTER the arrival and land while the group fills up, and gamma / beta are in registers before the wait.
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       float* cs = reinterpret_cast<float*>(smem_raw + 16384);    // scratch behind `red`: seg [32 bins][2][4] | tot [32][2] | scale [BN] | shift [BN] | flag
       float* c_seg = cs; float* c_tot = cs + 256; float* c_sc = cs + 320; float* c_sh = cs + 320 + BN; unsigned* okf = reinterpret_cast<unsigned*>(cs + 320 + 2 * BN);
       const int bsmp = m0 / p.rows_per_batch;
+      unsigned* gctr = p.coop_ctr + (size_t)bsmp * d.tiles_n + n0 / BN;
+      if (tid == 0) coop_arrive(gctr);
+      const bool colt = tid < BN && n0 + tid < p.N;
+      const float gam_c = colt ? p.fn_gamma[n0 + tid] : 0.f, bet_c = colt ? p.fn_beta[n0 + tid] : 0.f;
+      if (p.C) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const bool pair = (2 * g + 1 < NT);
+          const int j1 = pair ? 2 * g + 1 : 2 * g;
+          const int n = nbase + (pair ? g * 32 + fkc * 8 : (2 * g) * 16 + fkc * 4);
+          const bool nok = n < p.N;
+          const bool hi = pair && (n + 4 < p.N);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const f32x4 a0 = acc[i][2 * g], a1 = acc[i][j1];
+            uint4 o; o.x = pack_bf2(a0[0], a0[1]); o.y = pack_bf2(a0[2], a0[3]); o.z = pack_bf2(a1[0], a1[1]); o.w = pack_bf2(a1[2], a1[3]);
+            if (mok[i] && nok && hi) *reinterpret_cast<uint4*>((bf16_t*)p.C + crow[i] + n) = o;
+            else if (mok[i] && nok) *reinterpret_cast<uint2*>((bf16_t*)p.C + crow[i] + n) = make_uint2(o.x, o.y);
+          }
+        }
+      }
       if (tid == 0) {
-        const bool ok = coop_arrive_wait(p.coop_ctr + (size_t)bsmp * d.tiles_n + n0 / BN, (unsigned)(p.rows_per_batch / BM));
+        const bool ok = coop_wait(gctr, (unsigned)(p.rows_per_batch / BM));
         *okf = ok ? 1u : 0u;
       }
       __syncthreads();
@@ -1380,9 +1411,9 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, const GemmTileCtx cx
         const float sq = q * inv_n;         // E[x^2]
         const float var = fmaxf(sq - sm * sm, 0.f);
         const float rstd = rsqrtf(var + p.fn_eps);
-        float sc = rstd * p.fn_gamma[n0 + tid];
+        float sc = rstd * gam_c;
         if (!ok) sc = __builtin_nanf("");
-        const float sh = p.fn_beta[n0 + tid] - sm * sc;
+        const float sh = bet_c - sm * sc;
         c_sc[tid] = sc; c_sh[tid] = sh;
         if (p.fn_ss && m0 == bsmp * p.rows_per_batch) {        // the scale | shift table, once per (sample, N tile): [B][2][N]
           p.fn_ss[((size_t)bsmp * 2 + 0) * p.N + n0 + tid] = sc;

@@ -81,7 +81,7 @@ int main(int argc, char** argv) {
   auto conv_args = [&](int which, int v, int wset, unsigned* c) {
     GemmArgs g;
     g.conv = 1; g.IH = HW; g.IW = HW; g.OH = HW; g.OW = HW; g.Cin = C; g.stride = 1;
-    g.M = M; g.N = C; g.K = K; g.K1 = C; g.rows_per_batch = rpb; g.splitk = S;
+    g.M = M; g.N = C; g.K = K; g.K1 = C; g.rows_per_batch = rpb; g.splitk = S; g.ldc = C;
     g.fn_cg = C / 32; g.fn_eps = which == 0 ? 1e-5f : 1e-6f; g.fn_silu = which == 0 ? 1 : 0;
     if (which == 0) {      // conv1: norm1(x) -> + bias + time-embedding row -> norm2 + SiLU (the raw tensor has no other reader)
       g.A = n1; g.W = W1[wset]; g.bias = b1; g.rowvec = temb; g.rowvec_bstride = C; g.ws = ws1;
