@@ -351,6 +351,11 @@ def main():
                   "N > 1 line then carries efficiency_vs_scale_origin = value / (N x this)")
   a = ap.parse_args()
 
+  if a.share_gpu:
+    # test rig: several ranks on ONE GPU.  The UNet's in-kernel GroupNorm finishes wait inside a launch and need the device's CUs to themselves
+    # (include/gill_amd.h "Exclusive-device contract"): two ranks' waiting launches side by side starve each other until the bounded waits give up.
+    # The library reads the switch at its first launch.
+    os.environ["GILL_GEMM_COOP"] = "0"
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -463,6 +468,12 @@ def main():
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
   clocks = sampler.stop() if sampler else None
+  from gill_amd import _native as _N
+  n_giveups = _N.lib().gill_coop_timeouts()
+  if n_giveups != 0:
+    print(f"[bench rank {rank}] {n_giveups} in-kernel GroupNorm finish(es) timed out (GPU shared with another waiting launch?): outputs are NaN-poisoned; "
+          "rerun with GILL_GEMM_COOP=0", file=sys.stderr)
+    sys.exit(5)
   per_rank = None
   if world > 1:
     # every rank's own wall time and model-build time (a straggler or a slow loader shows up in the line), then the MAX as the job's time

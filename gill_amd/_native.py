@@ -81,6 +81,7 @@ SYMBOLS: Dict[str, Tuple[object, List[object]]] = {
   "gill_vae_decode": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
   "gill_op_conv3x3_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
   "gill_pndm_schedule": (_i, [_i, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+  "gill_coop_timeouts": (_i, []),
   "gill_op_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _i, _vp]),
   "gill_op_geglu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
   "gill_op_conv3x3": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -281,11 +281,15 @@ __device__ __forceinline__ float ld_wt_f32(const float* p) {
   return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 #define COOP_SPIN_LIMIT (1u << 18)
+// give-ups since the last gemm_coop_check(): a waiter that ran out of patience (the GPU is being shared with another process or stream that ALSO
+// runs waiting workgroups — the co-residency contract of GemmArgs::coop_ctr is broken) counts itself here before it poisons its outputs
+__device__ unsigned g_coop_giveups;
+__device__ __forceinline__ void coop_note_giveup() { __hip_atomic_fetch_add(&g_coop_giveups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void coop_arrive(unsigned* ctr) { __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ bool coop_wait(unsigned* ctr, unsigned target) {
   for (unsigned spins = 0;; ++spins) {
     if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-    if (spins > COOP_SPIN_LIMIT) return false;
+    if (spins > COOP_SPIN_LIMIT) { coop_note_giveup(); return false; }
     __builtin_amdgcn_s_sleep(2);
   }
 }
@@ -293,7 +297,7 @@ __device__ __forceinline__ bool coop_arrive_wait(unsigned* ctr, unsigned target)
   __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (unsigned spins = 0;; ++spins) {
     if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-    if (spins > COOP_SPIN_LIMIT) return false;
+    if (spins > COOP_SPIN_LIMIT) { coop_note_giveup(); return false; }
     __builtin_amdgcn_s_sleep(2);
   }
 }
@@ -1723,6 +1727,22 @@ bool gemm_coop_ok(const GemmArgs& a) {
   return true;
 }
 int gemm_coop_counters(const GemmArgs& a) { return cdiv(a.M, 128) * cdiv(a.N, 160); }     // (an upper bound: one per 128-row tile)
+// Reads and clears the give-up count of the in-kernel finishes (a small synchronous copy: call it where the host waits anyway).  Non-zero means
+// outputs of an earlier launch were NaN-poisoned because waiting workgroups were not co-resident: this process shared the GPU with another stream
+// or process that ALSO ran waiting workgroups (two of them can starve each other for CUs).  The contract is exclusive use of the device by ONE
+// handle's stream while it runs, or GILL_GEMM_COOP=0.
+int gemm_coop_giveups(unsigned* count) {
+  unsigned n = 0;
+  *count = 0;
+  if (gemm_coop_mode() == 0) return 0;
+  GILL_CHECK_HIP(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_coop_giveups), sizeof(n)));
+  if (n) {
+    const unsigned zero = 0;
+    GILL_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_giveups), &zero, sizeof(zero)));
+  }
+  *count = n;
+  return 0;
+}
 
 bool conv_k_chunked(int HW, int Cin, int Cout) {
   return HW >= 4096 && (int64_t)HW * Cin * 2 > (int64_t)4 << 20 && !gemm_conv_pingpong(HW, Cout);

@@ -90,6 +90,7 @@ struct GemmArgs {
 // can this launch finish in-kernel (GemmArgs::coop_ctr)?  Geometry of the ping-pong tiles, whole samples per counter group, grid <= CUs of the device.
 bool gemm_coop_ok(const GemmArgs& a);
 int gemm_coop_counters(const GemmArgs& a);
+int gemm_coop_giveups(unsigned* count);      // read + clear the device-side give-up counter of the bounded waits (synchronous)
 int gemm_coop_mode();      // GILL_GEMM_COOP: 0 = every finish a launch of its own, 1 (default) = GroupNorm finish in the conv epilogue, 2 = + the split-K finish
 bool gemm_fused_norm_ok(const GemmArgs& a);
 int gemm_launch(const GemmArgs& a, hipStream_t s);

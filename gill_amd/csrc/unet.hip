@@ -1285,9 +1285,29 @@ static int unet_ctx_cache(gill_unet* m, const bf16_t* ctx, int Bx, hipStream_t s
   return 0;
 }
 
+// The in-kernel GroupNorm finishes (gemm.hip "COOP") wait for each other inside a launch: legal only while this handle's stream has the device's CUs
+// to itself.  A bounded wait that ran out NaN-poisons its outputs and counts itself on the device; every entry point looks at that count first
+// (its own time-table upload synchronises with the stream anyway) and refuses to go on silently.
+static int unet_coop_check() {
+  unsigned n = 0;
+  GILL_TRY(gemm_coop_giveups(&n));
+  if (n) {
+    gill_set_error("an earlier call's in-kernel GroupNorm finish timed out " + std::to_string(n) + " time(s) and NaN-poisoned its outputs: the GPU is shared with "
+                   "another stream or process that also runs waiting workgroups.  Give the handle the device to itself, or set GILL_GEMM_COOP=0");
+    return -5;
+  }
+  return 0;
+}
+extern "C" int gill_coop_timeouts(void) {
+  unsigned n = 0;
+  if (gemm_coop_giveups(&n) != 0) return -1;
+  return (int)n;
+}
+
 extern "C" int gill_unet_forward(gill_unet* m, const float* sample, const float* timesteps_host, const void* ctx_bf16,
                                  int Bx, float* eps_out, void* stream) {
   GILL_REQUIRE(m && sample && timesteps_host && ctx_bf16 && eps_out, "null argument");
+  GILL_TRY(unet_coop_check());
   GILL_REQUIRE(Bx >= 1 && Bx <= m->cfg.max_batch, "batch exceeds the UNet handle's max_batch");
   hipStream_t s = (hipStream_t)stream;
   GILL_TRY(unet_time_table(m, timesteps_host, Bx, s));
@@ -1344,6 +1364,7 @@ extern "C" int gill_sd_denoise(gill_unet* m, const void* cond_bf16, const void* 
   GILL_REQUIRE(m && cond_bf16 && latents0 && latents_out, "null argument");
   GILL_REQUIRE(guidance <= 1.0f || uncond_bf16 == nullptr || n_uncond == 1 || n_uncond == B,
                "negative embeddings: batch must be 1 or B");
+  GILL_TRY(unet_coop_check());
   hipStream_t caller = (hipStream_t)stream;
   GILL_TRY(m->fence.enter(caller));
   const int rc = sd_denoise_on(m, cond_bf16, uncond_bf16, n_uncond, latents0, B, num_steps, guidance, latents_out, m->fence.stream);

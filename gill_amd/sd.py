@@ -250,6 +250,10 @@ class GillSDPipeline:
     if output_type in ("pil", "np"):      # custom_sd.py:654-661: decode_latents -> run_safety_checker -> numpy_to_pil
       from PIL import Image
       u8 = self.decode_latents(out, as_uint8=True).cpu().numpy()
+      n = N.lib().gill_coop_timeouts()      # (the copy above synchronised: the loop's give-up count is final — include/gill_amd.h "Exclusive-device contract")
+      if n != 0:
+        raise N.GillNativeError(f"{n} in-kernel GroupNorm finish(es) of the denoise loop timed out and NaN-poisoned the latents: the GPU is shared with "
+                                "another stream or process that also runs waiting workgroups; give this pipeline the device, or set GILL_GEMM_COOP=0")
       if self.safety_checker is not None:
         img01, has_nsfw = self.safety_checker(u8.astype("float32") / 255.0, [Image.fromarray(im) for im in u8])
         u8 = (img01 * 255).round().astype("uint8")

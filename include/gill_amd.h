@@ -203,6 +203,14 @@ int gill_vae_decode(gill_vae* h, const float* latents, int B, float* image_f32, 
 /* PNDM schedule known-answers for tests (host arrays): timesteps_out must hold num_steps+1 ints;
  * returns the number written.  alphas_cumprod_out (optional) must hold 1000 doubles. */
 int gill_pndm_schedule(int num_steps, int32_t* timesteps_out, double* alphas_cumprod_out);
+/* Exclusive-device contract of the UNet engine (round 6).  Some of its 3x3 convolutions finish the GroupNorm that consumes them inside their own
+ * launch: their workgroups wait for each other on arrival counters, which is deadlock-free only while the handle's stream has the device's CUs to
+ * itself (one process per GPU, as DESIGN.md section 5 deploys it; kernels of other streams that do not themselves wait only delay it).  Two such
+ * launches running side by side (two processes sharing one GPU, two handles on two streams) can starve each other: the waits are bounded, a
+ * workgroup that gives up NaN-poisons its outputs and counts itself.  gill_unet_forward / gill_sd_denoise fail with -5 when the count is non-zero
+ * on entry (and clear it); this function reads and clears it on demand (synchronous small copy; < 0 on a HIP error).  GILL_GEMM_COOP=0 in the
+ * environment turns the in-kernel finishes off (every GroupNorm a launch of its own, the round-5 dataflow: -0.6 % on the loop). */
+int gill_coop_timeouts(void);
 
 /* ------------------------------------------------------------------------------------------
  * Operator-level entry points (the kernels the three stages are built from), exported so the

@@ -437,6 +437,8 @@ def test_conv3x3_groupnorm_finished_in_the_epilogue(cuda, B, H, W, Cin, Cout, si
     assert torch.equal(y_raw, base_raw)
   again = ops.conv3x3_gn(dev(x), dev(w), dev(b), dev(gamma), dev(beta), 32, eps, silu, dev(r), 1, raw, coop=True, rowvec=dev(rv))[1]
   assert torch.equal(y_norm, again)
+  from gill_amd import _native as N
+  assert N.lib().gill_coop_timeouts() == 0      # no bounded wait gave up (include/gill_amd.h "Exclusive-device contract")
   if table:
     t = res[2]
     assert torch.isfinite(t).all()
