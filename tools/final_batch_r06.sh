@@ -1,9 +1,9 @@
 set +x
-# round 5 evidence batch on the current build: GPU suite with stats, driver bench command, rocprofv3 kernel stats + forward timeline, MFMA-busy and fetch PMC passes, C4 / C5 / 16-prompt benches
-O=gpurun_out/r05_final; mkdir -p $O
+# round 6 evidence batch on the current build: GPU suite with stats, driver bench command, rocprofv3 kernel stats + forward timeline, MFMA-busy and fetch PMC passes, C4 / C5 / 16-prompt benches
+O=gpurun_out/r06_final; mkdir -p $O
 python -m pytest tests -m gpu -q -s > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.log 2>&1; tail -1 $O/bench_driver_cmd.log | cut -c1-400
-bash tools/prof.sh r05_final/prof > $O/prof_head.txt 2>&1
+bash tools/prof.sh r06_final/prof > $O/prof_head.txt 2>&1
 db=$(find $O/prof -name "*.db" | head -1); python tools/forward_timeline.py $db > $O/forward_timeline.txt 2>&1; head -3 $O/forward_timeline.txt
 cp $O/prof/kernel_stats.md $O/kernel_stats.md
 (cd /tmp && export TMPDIR=/tmp && GILL_NO_GRAPH=1 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OLDPWD/$O/pmc -o m --output-format csv -- python $OLDPWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pmc --no-scale-origin > $OLDPWD/$O/pmc_run.log 2>&1)
