@@ -173,15 +173,7 @@ extern "C" int gill_op_conv3x3_gn(const void* x, const float* w_oihw, const floa
     GILL_TRY(st.alloc(sizeof(float) * (size_t)B * (H * W / GN_SLAB_ROWS_MIN) * (Cout / sbin) * 2));
     g.gn_stats = (float*)st.p; g.gn_groups = Cout / sbin; g.gn_cg = sbin;
   }
-  DevBuf gran, epoch;
-  if (coop) {
-    g.coop_ctr = (unsigned*)ctr.p; g.coop_splitk = 1;
-    if (g.gn_stats) {      // (splitk == 1: the granule hand-off — tags count this entry's launches, so a repeat never takes its predecessor's granules for its own)
-      GILL_TRY(gran.alloc_zero(st.bytes * 2, s));
-      GILL_TRY(epoch.alloc_zero(sizeof(unsigned), s));
-      g.coop_gran = (unsigned long long*)gran.p; g.coop_epoch = (const unsigned*)epoch.p;
-    }
-  }
+  if (coop) { g.coop_ctr = (unsigned*)ctr.p; g.coop_splitk = 1; }
   if (splitk == 1 && !coop) {
     // reference dataflow: the convolution files its statistics, a GroupNorm-apply launch normalises the rounded tensor
     g.fn_Y = nullptr; g.fn_ss = nullptr;
@@ -198,7 +190,6 @@ extern "C" int gill_op_conv3x3_gn(const void* x, const float* w_oihw, const floa
   else GILL_REQUIRE(gemm_coop_ok(g) || gemm_fused_norm_ok(g), "conv3x3_gn: unsupported geometry (H * W in {64, 256}, Cout % 80 == 0, group width | 80)");
   for (int r = 0; r < op_repeat(); ++r) {
     GILL_CHECK_HIP(hipMemsetAsync(ctr.p, 0, sizeof(unsigned) * (size_t)ncnt, s));
-    if (epoch.p) GILL_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)epoch.p, r + 1, 1, s));
     GILL_TRY(gemm_launch(g, s));
   }
   GILL_CHECK_HIP(hipStreamSynchronize(s));

@@ -199,9 +199,8 @@ int conv_in_launch(const float* x, const bf16_t* w, const float* bias, int B, in
 // zero / nzero: a range of 32-bit words this kernel also clears — the UNet forward's COOP arrival counters (GemmArgs::coop_ctr), reset by the
 // forward's first kernel instead of a launch (or a memset node) of their own
 __global__ __launch_bounds__(256) void im2col_nchw_kernel(const float* __restrict__ x, int B, int Cin, int H, int W, int kpad,
-                                                          bf16_t* __restrict__ out, unsigned* __restrict__ zero, int nzero, unsigned* __restrict__ epoch) {
+                                                          bf16_t* __restrict__ out, unsigned* __restrict__ zero, int nzero) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += gridDim.x * blockDim.x) zero[i] = 0u;
-  if (epoch && blockIdx.x == 0 && threadIdx.x == 0) *epoch = *epoch + 1u;      // this forward's COOP granule tag (GemmArgs::coop_epoch): never 0 after the first forward
   const int64_t total = (int64_t)B * H * W * (kpad / 8);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int oct = (int)(i % (kpad / 8));
@@ -223,10 +222,10 @@ __global__ __launch_bounds__(256) void im2col_nchw_kernel(const float* __restric
     *reinterpret_cast<uint4*>(out + pix * kpad + oct * 8) = u;
   }
 }
-int im2col_nchw_launch(const float* x, int B, int Cin, int H, int W, int kpad, bf16_t* out, hipStream_t s, unsigned* zero, int nzero, unsigned* epoch) {
+int im2col_nchw_launch(const float* x, int B, int Cin, int H, int W, int kpad, bf16_t* out, hipStream_t s, unsigned* zero, int nzero) {
   GILL_REQUIRE(kpad % 64 == 0 && 9 * Cin <= kpad, "im2col: kpad must be a multiple of 64 covering 9*Cin");
   const int64_t total = (int64_t)B * H * W * (kpad / 8);
-  hipLaunchKernelGGL(im2col_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, B, Cin, H, W, kpad, out, zero, zero ? nzero : 0, epoch);
+  hipLaunchKernelGGL(im2col_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, B, Cin, H, W, kpad, out, zero, zero ? nzero : 0);
   GILL_CHECK_HIP(hipGetLastError());
   return 0;
 }

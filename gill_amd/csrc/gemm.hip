@@ -1322,11 +1322,6 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, const GemmTileCtx cx
         if (fkc == 0 && mok[i]) *reinterpret_cast<float2*>(plane + (size_t)(mrow + i * 16) * 2) = make_float2(rws[i], rwq[i]);
       }
     }
-    unsigned coop_tag = 0;
-    if constexpr (EPI == 6) {
-      coop_tag = *p.coop_epoch;
-      if (tid == 0) *reinterpret_cast<unsigned*>(smem_raw + 16384 + 4 * (320 + 2 * BN)) = 1u;      // okf (see the COOP block below): set before the barrier
-    }
     if (p.gn_stats) {
       __syncthreads();
       constexpr int HALVES = BM / 64;
@@ -1349,15 +1344,9 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, const GemmTileCtx cx
           const int b = mfirst / p.rows_per_batch;
           const int slab = (mfirst - b * p.rows_per_batch) / GN_SLAB_ROWS + (CONV == 3 ? cls * (p.rows_per_batch / GN_SLAB_ROWS) : 0);
           const int nslab = (CONV == 3 ? 4 : 1) * (p.rows_per_batch / GN_SLAB_ROWS);
-          const size_t cell = (((size_t)b * nslab + slab) * p.gn_groups + bin) * 2 + which;
-          p.gn_stats[cell] = a;
-          if constexpr (EPI == 6) {
-            // COOP: the other workgroups of the group read it inside this launch — as ONE naturally aligned 8-byte {tag, value} GRANULE, written by
-            // one sc1 store (Guideline 16, R2: "the data IS the flag").  tag = this forward's epoch (a device word the forward's first kernel bumps):
-            // what an earlier forward left in the cell carries an older tag, so nothing is zeroed and no counter is needed.
-            __hip_atomic_store(p.coop_gran + cell, ((unsigned long long)coop_tag << 32) | (unsigned long long)__float_as_uint(a), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-          }
+          float* dst = p.gn_stats + (((size_t)b * nslab + slab) * p.gn_groups + bin) * 2 + which;
+          if constexpr (EPI == 6) st_wt_f32(dst, a);       // COOP: the other workgroups of the group read it inside this launch
+          else *dst = a;
         }
       }
     }
@@ -1370,9 +1359,13 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, const GemmTileCtx cx
       static_assert(EPI != 6 || (PP && CONV == 1), "COOP GroupNorm finish: the ping-pong convolution tiles");
       // Order (round 6, second pass): nothing but the few partial stores is in flight at the drain — the raw tensor's 40-80 KiB of stores per
       // workgroup go out AFTER the arrival and land while the group fills up, and gamma / beta are in registers before the wait.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
       float* cs = reinterpret_cast<float*>(smem_raw + 16384);    // scratch behind `red`: seg [32 bins][2][4] | tot [32][2] | scale [BN] | shift [BN] | flag
       float* c_seg = cs; float* c_tot = cs + 256; float* c_sc = cs + 320; float* c_sh = cs + 320 + BN; unsigned* okf = reinterpret_cast<unsigned*>(cs + 320 + 2 * BN);
       const int bsmp = m0 / p.rows_per_batch;
+      unsigned* gctr = p.coop_ctr + (size_t)bsmp * d.tiles_n + n0 / BN;
+      if (tid == 0) coop_arrive(gctr);
       const bool colt = tid < BN && n0 + tid < p.N;
       const float gam_c = colt ? p.fn_gamma[n0 + tid] : 0.f, bet_c = colt ? p.fn_beta[n0 + tid] : 0.f;
       if (p.C) {
@@ -1392,39 +1385,25 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, const GemmTileCtx cx
           }
         }
       }
+      if (tid == 0) {
+        const bool ok = coop_wait(gctr, (unsigned)(p.rows_per_batch / BM));
+        *okf = ok ? 1u : 0u;
+      }
+      __syncthreads();
+      const bool ok = *okf != 0u;
       const int bins_tile = BN / p.gn_cg;                       // <= 32 (gemm_coop_ok)
       const int ns = p.rows_per_batch / GN_SLAB_ROWS;           // <= 64 partials per (sample, bin)
       if (tid < bins_tile * 8) {
-        // SWEEP: the thread re-reads its 16 granules (sc1 loads: L2-served, never this CU's L1) until every tag is this forward's — the wait and the
-        // read are one and the same round trip; no arrival counter, no poll, no acquire.  Bounded: a sweeper that gives up poisons the workgroup's
-        // outputs and counts itself (the exclusive-device contract, include/gill_amd.h).
         const int seg = tid & 3, which = (tid >> 2) & 1, lb = tid >> 3;
-        const unsigned long long* src = p.coop_gran + (((size_t)bsmp * ns + seg * 16) * p.gn_groups + n0 / p.gn_cg + lb) * 2 + which;
+        const float* src = p.gn_stats + (((size_t)bsmp * ns + seg * 16) * p.gn_groups + n0 / p.gn_cg + lb) * 2 + which;
         const size_t step = (size_t)p.gn_groups * 2;
         float pv[16];
-        bool all = false;
-        for (unsigned spins = 0; !all; ++spins) {
-          all = true;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            if (seg * 16 + i < ns) {
-              const unsigned long long x = __hip_atomic_load(src + (size_t)i * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              pv[i] = __uint_as_float((unsigned)x);
-              all = all && ((unsigned)(x >> 32) == coop_tag);
-            } else {
-              pv[i] = 0.f;
-            }
-          }
-          if (!all) {
-            if (spins > (COOP_SPIN_LIMIT >> 1)) { coop_note_giveup(); *okf = 0u; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
+        for (int i = 0; i < 16; ++i) pv[i] = (seg * 16 + i < ns) ? ld_wt_f32(src + (size_t)i * step) : 0.f;      // sc1 loads: the producers stored sc1
         c_seg[(lb * 2 + which) * 4 + seg] = (((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]))) +
                                             (((pv[8] + pv[9]) + (pv[10] + pv[11])) + ((pv[12] + pv[13]) + (pv[14] + pv[15])));
       }
       __syncthreads();
-      const bool ok = *okf != 0u;
       if (tid < bins_tile * 2) { const float* g4 = c_seg + tid * 4; c_tot[tid] = (g4[0] + g4[1]) + (g4[2] + g4[3]); }
       __syncthreads();
       if (tid < BN && n0 + tid < p.N) {
@@ -1720,9 +1699,9 @@ int gemm_coop_mode() {
   return mode;
 }
 bool gemm_coop_ok(const GemmArgs& a) {
-  if (gemm_coop_mode() == 0) return false;
+  if (!a.coop_ctr || gemm_coop_mode() == 0) return false;
   const int sk = a.splitk > 1 ? a.splitk : 1;
-  if (sk > 1 ? (!a.coop_ctr || !a.coop_splitk) : (!a.coop_gran || !a.coop_epoch)) return false;
+  if (sk > 1 && !a.coop_splitk) return false;
   const int bm = coop_tile_rows(a, sk);
   const int rpb = a.rows_per_batch;
   if (bm == 0 || rpb <= 0 || a.M % bm != 0 || a.M % rpb != 0) return false;

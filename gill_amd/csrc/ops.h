@@ -82,9 +82,6 @@ struct GemmArgs {
   //     (C itself only when non-null), and / or the per-(sample, channel) scale | shift table fn_ss [B][2][N] (what lnproj.hip applies on load).
   // coop_ctr: one zeroed 32-bit counter per (sample group, N tile) of THIS launch (gemm_coop_counters() says how many).
   unsigned* coop_ctr = nullptr; float* fn_ss = nullptr;
-  // splitk == 1 hands its partial sums over as 8-byte {tag, value} granules instead (no counter): coop_gran = the granule twin of the gn_stats slot
-  // (same cell index), coop_epoch = a device word holding this forward's tag (bumped once per forward; granules of earlier forwards carry older tags)
-  unsigned long long* coop_gran = nullptr; const unsigned* coop_epoch = nullptr;
   // coop_splitk: also allow the split-K finish (EPI 7).  MEASURED NO-GO (profiles/r06_coop_finish.md: +1 ... +6 us per launch against conv + reducer,
   // the loop +1.7 %): the engine sets it only under GILL_GEMM_COOP=2, the operator entry sets it on request (the parity tests, tools/coop_bench.py,
   // tools/ubench/persist_resnet.hip build on it).
@@ -246,8 +243,7 @@ int silu_bf16_launch(const bf16_t* x, bf16_t* y, int64_t n, hipStream_t s);
 int conv_in_launch(const float* x, const bf16_t* w /*[Cout][9][Cin]*/, const float* bias, int B, int Cin, int H, int W,
                    int Cout, bf16_t* y, hipStream_t s);
 // im2col of a tiny-Cin NCHW fp32 tensor for conv_in: out [B*H*W][kpad] bf16, k = tap*Cin + c (zero beyond 9*Cin)
-int im2col_nchw_launch(const float* x, int B, int Cin, int H, int W, int kpad, bf16_t* out, hipStream_t s, unsigned* zero = nullptr, int nzero = 0,
-                       unsigned* epoch = nullptr);
+int im2col_nchw_launch(const float* x, int B, int Cin, int H, int W, int kpad, bf16_t* out, hipStream_t s, unsigned* zero = nullptr, int nzero = 0);
 // conv_out: NHWC bf16 (B,H,W,Cin) -> NCHW fp32 (B,Cout,H,W), 3x3 pad 1, direct (Cout tiny)
 int conv_out_launch(const bf16_t* x, const bf16_t* w /*[Cout][9][Cin]*/, const float* bias, int B, int Cin, int H, int W,
                     int Cout, float* y, hipStream_t s);

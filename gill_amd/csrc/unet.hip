@@ -127,8 +127,6 @@ struct gill_unet {
   // COOP arrival counters (GemmArgs::coop_ctr): one slot range per GEMM launch of a forward, bump-allocated in launch order (the dry run sizes the
   // pool), all zeroed by the forward's first kernel (im2col_nchw_launch)
   unsigned* coop_ctr = nullptr; size_t coop_n = 0, coop_next = 0;
-  unsigned long long* gn_gran = nullptr;   // granule twin of gn_stats (GemmArgs::coop_gran): same cell indices, {forward tag, partial sum} per cell
-  unsigned* coop_epoch = nullptr;          // [1]: the running forward's granule tag, bumped by the forward's first kernel
   std::vector<bf16_t*> kcache, vcache;   // per transformer layer: [Bx][H][ctx_pad][dp] / [Bx][H][dpv][ctx_pad]
   int ctx_pad = 0;
   // XALG layers (XfW::xg): per-sample operands of the two cross-attention GEMMs — scores [Bx][80 H][C] + its folded-LayerNorm
@@ -721,7 +719,6 @@ struct UNetRun {
     // (split-K partials come from 128-row tiles: not where a sample's rows are fewer — the 8 x 8 maps of the mid block)
     if (g.out_mode == OUT_SOFTMAX80 || (g.wb_rows && g.wb_rows % 128 != 0)) g.splitk = 1;
     g.coop_ctr = ctr;
-    if (g.gn_stats) { g.coop_gran = m->gn_gran + (g.gn_stats - m->gn_stats); g.coop_epoch = m->coop_epoch; }
     g.coop_splitk = gemm_coop_mode() >= 2;      // (the split-K finish in-kernel: a measured no-go, opt-in — GemmArgs::coop_splitk)
     if (fn) {
       g.rows_per_batch = fn->y.H * fn->y.W;
@@ -1050,7 +1047,7 @@ struct UNetRun {
       // conv_in: im2col (K = 9*Cin padded to 64) + MFMA GEMM
       const size_t mk = m->arena.mark();
       bf16_t* col = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)Bx * L * L * 64);
-      if (!dry) GILL_TRY(im2col_nchw_launch(sample, Bx, c.in_channels, L, L, 64, col, s, m->coop_ctr, (int)m->coop_n, m->coop_epoch));
+      if (!dry) GILL_TRY(im2col_nchw_launch(sample, Bx, c.in_channels, L, L, 64, col, s, m->coop_ctr, (int)m->coop_n));
       GILL_TRY(linear(col, 64, nullptr, 0, 64, Bx * L * L, m->conv_in_w, m->conv_in_b, ch[0], 64, nullptr, ACT_NONE, x.p, ch[0], &x));
       m->arena.release(mk);
     }
@@ -1187,8 +1184,6 @@ static int unet_plan_and_alloc(gill_unet* m) {
   m->arena.base = m->arena_mem; m->arena.cap = need; m->arena.dry = false; m->arena.off = 0;
   m->gn_floats = m->gn_next + 64;           // counted by the dry run
   GILL_TRY(m->pool.alloc(&m->gn_stats, m->gn_floats));
-  GILL_TRY(m->pool.alloc(&m->gn_gran, m->gn_floats));
-  GILL_TRY(m->pool.alloc(&m->coop_epoch, (size_t)1));
   m->ln_floats = m->ln_next + 64;           // counted by the dry run (max batch)
   GILL_TRY(m->pool.alloc(&m->ln_stats, m->ln_floats));
   m->coop_n = m->coop_next + 64;            // COOP arrival counters: counted by the dry run
