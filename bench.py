@@ -340,6 +340,7 @@ def main():
   ap.add_argument("--small", action="store_true", help="opt-125m shapes (debug only; not the benchmark config)")
   ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"], help="c5: BASELINE configs[4], c2 with the UNet's resnet convolutions in fp8 e4m3 (not a parity mode); c2 (default): BASELINE configs[1]/[2], SD-1.5 UNet 512x512; "
                   "c4: configs[3], SD-2.1-768 UNet (1024-d context, head dim 64, v-prediction, 96x96 latents) + gen_emb_dim=1024 mapper")
+  ap.add_argument("--fp8-convs-only", action="store_true", help="--config c5 without the fp8 GEGLU projections (the round-5 form of the mode, for A/B)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
   ap.add_argument("--pmc-timeout", type=int, default=300)
@@ -379,7 +380,7 @@ def main():
   opt_cfg = synth.OptConfig.opt_125m() if a.small else synth.OptConfig.opt_6_7b()
   unet_cfg = synth.UNetConfig.sd21_768() if a.config == "c4" else synth.UNetConfig.sd15()
   if a.config == "c5":
-    unet_cfg.fp8_convs = True
+    unet_cfg.fp8_convs = 2 if a.fp8_convs_only else True       # (gill_unet_config.fp8_convs: 1 = convolutions + GEGLU projections, 2 = convolutions only)
   vae_cfg = synth.VAEConfig(latent_size=unet_cfg.sample_size)
   tflop_fwd = UNET_TFLOP_SD21_768 if a.config == "c4" else UNET_TFLOP_PER_SAMPLE_FORWARD
   side = 8 * unet_cfg.sample_size
@@ -571,9 +572,10 @@ def main():
       metric = "768x768 images/sec/node, OPT-6.7B+SD2.1-768 50-step (BASELINE configs[3]; not the headline metric)"
     dtype = "bf16"
     if a.config == "c5":
-      cfg_name, unet_name = "configs[4]", "SD-1.5 UNet with fp8 (e4m3) resnet convolutions, everything else bf16"
-      metric = "512x512 images/sec/node, OPT-6.7B+SD1.5 50-step, fp8 resnet convolutions (BASELINE configs[4]; not the headline metric)"
-      dtype = "fp8 e4m3 (44 resnet convolutions) + bf16"
+      lin = "" if a.fp8_convs_only else " and the 11 GEGLU projections of levels 1-3"
+      cfg_name, unet_name = "configs[4]", f"SD-1.5 UNet with fp8 (e4m3) resnet convolutions{lin}, everything else bf16"
+      metric = "512x512 images/sec/node, OPT-6.7B+SD1.5 50-step, fp8 resnet convolutions + GEGLU projections (BASELINE configs[4]; not the headline metric)"
+      dtype = "fp8 e4m3 (44 resnet convolutions" + ("" if a.fp8_convs_only else " + 11 GEGLU projections") + ") + bf16"
     rec = {
       "metric": metric, "value": value, "unit": "images/s",
       "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,

@@ -91,6 +91,7 @@ SYMBOLS: Dict[str, Tuple[object, List[object]]] = {
   "gill_op_conv3x3_gn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
   "gill_op_conv3x3_shortcut": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
   "gill_op_ffn_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+  "gill_op_geglu_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
   "gill_op_lnproj": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
   "gill_op_cross_attention_folded": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
 }

@@ -128,6 +128,22 @@ struct ConvF8Args {
   int splitk = 1; float* ws = nullptr;     // fp32 partials [splitk][M][N]; finish with gemm_splitk_reduce_launch
 };
 int conv3x3_fp8_launch(const ConvF8Args& a, hipStream_t s);
+
+// GEGLU projection with fp8 (e4m3) activations and weights (linear_fp8.hip): C[M][N / 2] bf16 = (A8 . Wv8^T * sv + bv) * gelu(A8 . Wg8^T * sg + bg),
+// W8 [N][K] in the engine's value / gate-interleaved row order (16 value rows | 16 gate rows per 16 outputs), K % 128 == 0
+#define F8_LIN_ACT_SCALE 16.0f     // LayerNorm-ed activations are stored as fp8(16 * x): |x| up to 28 sigma in range, the bulk in e4m3's normal range
+struct LinF8Args {
+  int M = 0, N = 0, K = 0;
+  const unsigned char* A8 = nullptr;       // [M][K] fp8: ln_quant_fp8_launch
+  const unsigned char* W8 = nullptr;       // [N][K] fp8: linear_weight_quant_fp8_launch
+  const float* colscale = nullptr;         // [N]: weight scale / activation scale
+  const float* bias = nullptr;             // [N]
+  bf16_t* C = nullptr;                     // [M][N / 2] bf16
+};
+int geglu_fp8_launch(const LinF8Args& a, hipStream_t s);
+int linear_weight_quant_fp8_launch(const bf16_t* w, int N, int K, float act_scale, unsigned char* w8, float* colscale, hipStream_t s);
+int ln_quant_fp8_launch(const bf16_t* t, int M, int C, const float* ln_stats, int planes, int ln_rows, float eps, float act_scale, unsigned char* y,
+                        hipStream_t s);
 int conv_fp8_kpad(int Cin);
 int quant_bf16_fp8_launch(const bf16_t* x, float scale, int64_t n, unsigned char* y, hipStream_t s);
 int conv_weight_quant_fp8_launch(const void* w_oihw, int dtype, int Cout, int Cin, float act_scale, unsigned char* w8, float* colscale,

@@ -56,6 +56,7 @@ struct XfW {  // Transformer2DModel with one BasicTransformerBlock
   bf16_t* wkv2 = nullptr;     // [2*H*dp][ctx_dim]
   LinW out2;
   bf16_t* wff1 = nullptr; float* bff1 = nullptr;   // GEGLU-permuted [8C][C]
+  unsigned char* wff1_8 = nullptr; float* cs_ff1 = nullptr;   // gill_unet_config.fp8_convs: the same (LayerNorm-folded) rows in e4m3 + per-row de-quantisation scale (linear_fp8.hip)
   bf16_t* w1c = nullptr; float* b1c = nullptr; bf16_t* w2p = nullptr;   // the same weights as the fused feed-forward kernel reads them (ffn.hip; C = 320 only)
   bf16_t* wpp = nullptr;        // proj_out's weight in the permuted k order: set when the fused feed-forward kernel also runs attn2.to_out (ffn.hip PRE)
   bool w1c_kperm = false;       // the layout w1c was written in: the PRE kernel's permuted k order (ffn_relayout_launch with Wpp) — the kernel form run in xf() must match it
@@ -422,7 +423,7 @@ struct Loader {
     return 0;
   }
   // hw: tokens per sample at this layer (the softmax GEMM of the two-GEMM cross-attention runs on 64-row tiles of ONE sample)
-  int xf(const std::string& p, int C, int H, int ctx_dim, int layer_id, int hw, XfW* x) {
+  int xf(const std::string& p, int C, int H, int ctx_dim, int layer_id, int hw, XfW* x, bool f8 = false) {
     x->C = C; x->heads = H; x->d = C / H; x->dp = attn_padded_dim(x->d); x->dpv = round_up(x->dp, 32); x->layer_id = layer_id;
     GILL_REQUIRE(x->dp > 0, "unsupported attention head dim");
     const int hdp = H * x->dp;
@@ -488,6 +489,13 @@ struct Loader {
     GILL_TRY(ln_fold_rows_launch(x->wqkv1, 3 * hdp, C, x->ln1.g, x->ln1.b, x->s_qkv1, x->c_qkv1, s));
     GILL_TRY(ln_fold_rows_launch(x->wq2, hdp, C, x->ln2.g, x->ln2.b, x->s_q2, x->c_q2, s));
     GILL_TRY(ln_fold_rows_launch(x->wff1, 8 * C, C, x->ln3.g, x->ln3.b, x->s_ff1, x->bff1, s));
+    // fp8 mode (BASELINE configs[4]): the GEGLU projection of the blocks that run it as a GEMM (levels 1-3; level 0 has the fused feed-forward
+    // kernel) on the fp8 matrix instruction — the folded rows quantised per output row
+    if (f8 && C % 128 == 0 && !(ffn_fused_on() && ffn_fused_supported(C, 128))) {
+      GILL_TRY(pool.alloc(&x->wff1_8, (size_t)8 * C * C, false));
+      GILL_TRY(pool.alloc(&x->cs_ff1, (size_t)8 * C, false));
+      GILL_TRY(linear_weight_quant_fp8_launch(x->wff1, 8 * C, C, F8_LIN_ACT_SCALE, x->wff1_8, x->cs_ff1, s));
+    }
     // cross-attention as two GEMMs: where the 80 key slots per head are no wider than the head itself (d >= 80: SD-1.5 levels 1-3)
     // ... and a sample is whole 64-row tiles (per-sample weights: a tile must not straddle samples — sample_size 32 / 96 have 16- / 144-token
     // mid blocks); otherwise the layer keeps its K / V caches and the attention-kernel form
@@ -588,6 +596,7 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
 
   int layer_id = 0;
   const bool f8 = cfg->fp8_convs != 0;   // ResnetBlock2D convolutions on the fp8 matrix instruction (conv_fp8.hip)
+  const bool f8lin = cfg->fp8_convs == 1; // ... and the GEGLU projections of levels 1-3 (linear_fp8.hip); fp8_convs = 2: the convolutions only (round-5 mode, for A/B)
   auto hw_of = [&](int level) { const int side = cfg->sample_size >> level; return side * side; };   // pixels per sample
   // down blocks: CrossAttnDownBlock2D x3, DownBlock2D
   for (int i = 0; i < 4; ++i) {
@@ -600,14 +609,14 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
     if (i < 3) {
       m->down_xf[i].resize(2);
       for (int j = 0; j < 2; ++j)
-        if ((rc = L.xf(p + ".attentions." + std::to_string(j), ch[i], Hl[i], ctxd, layer_id++, hw_of(i), &m->down_xf[i][j]))) return fail(rc);
+        if ((rc = L.xf(p + ".attentions." + std::to_string(j), ch[i], Hl[i], ctxd, layer_id++, hw_of(i), &m->down_xf[i][j], f8lin))) return fail(rc);
       if ((rc = L.conv3(p + ".downsamplers.0.conv", ch[i], ch[i], hw_of(i), &m->down_ds[i]))) return fail(rc);
     }
   }
   // mid
   if ((rc = L.resnet("mid_block.resnets.0", ch[3], ch[3], hw_of(3), temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[0], f8)))
     return fail(rc);
-  if ((rc = L.xf("mid_block.attentions.0", ch[3], Hl[3], ctxd, layer_id++, hw_of(3), &m->mid_xf))) return fail(rc);
+  if ((rc = L.xf("mid_block.attentions.0", ch[3], Hl[3], ctxd, layer_id++, hw_of(3), &m->mid_xf, f8lin))) return fail(rc);
   if ((rc = L.resnet("mid_block.resnets.1", ch[3], ch[3], hw_of(3), temb_dim, &temb_off, m->temb_proj_w, m->temb_proj_b, &m->mid_res[1], f8)))
     return fail(rc);
   // up blocks: UpBlock2D, CrossAttnUpBlock2D x3
@@ -627,7 +636,7 @@ extern "C" int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, co
     if (i > 0) {
       m->up_xf[i].resize(3);
       for (int j = 0; j < 3; ++j)
-        if ((rc = L.xf(p + ".attentions." + std::to_string(j), outc, Hl[3 - i], ctxd, layer_id++, hw_of(3 - i), &m->up_xf[i][j]))) return fail(rc);
+        if ((rc = L.xf(p + ".attentions." + std::to_string(j), outc, Hl[3 - i], ctxd, layer_id++, hw_of(3 - i), &m->up_xf[i][j], f8lin))) return fail(rc);
     }
     if (i < 3)
       if ((rc = L.conv3(p + ".upsamplers.0.conv", outc, outc, hw_of(3 - i), &m->up_us[i], false, true))) return fail(rc);
@@ -1016,7 +1025,17 @@ struct UNetRun {
     }
     // --- GEGLU feed-forward
     bf16_t* ffh = (bf16_t*)m->arena.alloc(sizeof(bf16_t) * (size_t)M * 4 * C);
-    {
+    unsigned char* t8 = w.wff1_8 ? (unsigned char*)m->arena.alloc((size_t)M * C) : nullptr;
+    if (w.wff1_8) {
+      // fp8 mode: norm3 applied explicitly into an e4m3 copy of t (one pass: 3 bytes per element), then the GEGLU GEMM on the fp8 matrix instruction
+      if (!dry) {
+        GILL_TRY(ln_quant_fp8_launch(tres, M, C, st3.p, st3.planes, 0, 1e-5f, F8_LIN_ACT_SCALE, t8, s));
+        LinF8Args a;
+        a.M = M; a.N = 8 * C; a.K = C; a.A8 = t8; a.W8 = w.wff1_8; a.colscale = w.cs_ff1; a.bias = w.bff1; a.C = ffh;
+        GILL_TRY(geglu_fp8_launch(a, s));
+        GILL_TRY(dbg_sync("geglu fp8", M, 8 * C, C));
+      }
+    } else {
       GemmArgs g;
       g.M = M; g.N = 8 * C; g.K = C; g.K1 = C; g.A = tres; g.lda = C; g.W = w.wff1; g.bias = w.bff1;
       g.ln_stats = st3.p; g.ln_planes = st3.planes; g.ln_colsum = w.s_ff1;
@@ -1553,6 +1572,41 @@ extern "C" int gill_op_ffn_fused(const void* t, const float* ln_g, const float* 
   if (o2) { fa.X = (const bf16_t*)o2p.p; fa.Wo = (const bf16_t*)wop.p; fa.bo2 = bo2; fa.Wpp = (const bf16_t*)wpp.p; }
   const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
   for (int r = 0; r < rep; ++r) GILL_TRY(ffn_fused_launch(fa, s));
+  GILL_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Operator-level entry for the fp8 GEGLU projection (linear_fp8.hip) on NATURAL operands (diffusers parameter layouts): permutes the rows into the
+// engine's value / gate interleave, folds norm3 into them, quantises rows and LayerNorm-ed activations to e4m3 exactly as the engine's fp8 mode does,
+// launches the kernel.  out [M][inner] = h * gelu(g), [h | g] = LN(t) W^T + b (W [2 inner][C], diffusers order [value rows | gate rows]).  C % 128 == 0.
+// For tests/test_fp8_gpu.py and tools; synchronises.
+extern "C" int gill_op_geglu_fp8(const void* t, const float* ln_g, const float* ln_b, const void* W, const float* b, void* out, int M, int inner, int C,
+                                 void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GILL_REQUIRE(t && ln_g && ln_b && W && b && out && M > 0 && inner % 16 == 0 && C % 128 == 0, "geglu_fp8: null argument / inner % 16 / C % 128");
+  DevBuf idx, wperm, bperm, cs, w8, sc, st, t8;
+  std::vector<int32_t> map = geglu_row_permutation(inner);
+  GILL_TRY(idx.alloc(sizeof(int32_t) * map.size()));
+  GILL_CHECK_HIP(hipMemcpyAsync(idx.p, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice, s));
+  GILL_TRY(wperm.alloc(sizeof(bf16_t) * (size_t)2 * inner * C)); GILL_TRY(bperm.alloc(sizeof(float) * 2 * inner)); GILL_TRY(cs.alloc(sizeof(float) * 2 * inner));
+  GILL_TRY(scatter_rows_bf16_launch((const bf16_t*)W, 2 * inner, C, (const int32_t*)idx.p, (bf16_t*)wperm.p, C, s));
+  GILL_TRY(permute_f32_launch(b, (const int32_t*)idx.p, 2 * inner, (float*)bperm.p, s));
+  GILL_TRY(ln_fold_rows_launch((bf16_t*)wperm.p, 2 * inner, C, ln_g, ln_b, (float*)cs.p, (float*)bperm.p, s));
+  GILL_TRY(w8.alloc((size_t)2 * inner * C)); GILL_TRY(sc.alloc(sizeof(float) * 2 * inner));
+  GILL_TRY(linear_weight_quant_fp8_launch((const bf16_t*)wperm.p, 2 * inner, C, F8_LIN_ACT_SCALE, (unsigned char*)w8.p, (float*)sc.p, s));
+  GILL_TRY(st.alloc(sizeof(float) * (size_t)M * 2));
+  hipLaunchKernelGGL(ffn_op_rowsums_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, (const bf16_t*)t, M, C, (float*)st.p);
+  GILL_CHECK_HIP(hipGetLastError());
+  GILL_TRY(t8.alloc((size_t)M * C));
+  LinF8Args a;
+  a.M = M; a.N = 2 * inner; a.K = C; a.A8 = (const unsigned char*)t8.p; a.W8 = (const unsigned char*)w8.p; a.colscale = (const float*)sc.p;
+  a.bias = (const float*)bperm.p; a.C = (bf16_t*)out;
+  const int rep = [] { const char* e = getenv("GILL_OP_REPEAT"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
+  for (int r = 0; r < rep; ++r) {
+    GILL_TRY(ln_quant_fp8_launch((const bf16_t*)t, M, C, (const float*)st.p, 1, 0, 1e-5f, F8_LIN_ACT_SCALE, (unsigned char*)t8.p, s));
+    GILL_TRY(geglu_fp8_launch(a, s));
+  }
   GILL_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
 }

@@ -38,6 +38,19 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
   return out
 
 
+def geglu_fp8(t: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+  """BASELINE configs[4]: diffusers GEGLU of LayerNorm(t) on the fp8 matrix instruction (csrc/linear_fp8.hip): t (M,C) bf16, w (2 inner, C) bf16 in
+  diffusers order, bias (2 inner); activations and weights quantised to e4m3 as the engine's fp8 mode does.  Returns (M, inner) bf16."""
+  t, w = _bf(t), _bf(w)
+  M, Cc = t.shape
+  inner = w.shape[0] // 2
+  out = torch.empty((M, inner), device=t.device, dtype=torch.bfloat16)
+  f = lambda x: x.float().contiguous()   # noqa: E731
+  ln_g, ln_b, bias = f(ln_g), f(ln_b), f(bias)
+  N.check(N.lib().gill_op_geglu_fp8(N.ptr(t), N.ptr(ln_g), N.ptr(ln_b), N.ptr(w), N.ptr(bias), N.ptr(out), M, inner, Cc, N.current_stream()))
+  return out
+
+
 def geglu(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
   """diffusers GEGLU: h, g = (a @ w.T + bias).chunk(2, -1); h * gelu(g)."""
   a, w = _bf(a), _bf(w)

@@ -30,15 +30,17 @@ def shard_range(n: int, distributed: bool = True) -> Tuple[int, int]:
   return shard_bounds(n, r, w)
 
 
-def gather_rows(local: torch.Tensor, n_total: int, distributed: bool = True) -> torch.Tensor:
+def gather_rows(local: torch.Tensor, n_total: int, distributed: bool = True, force_collective: bool = False) -> torch.Tensor:
   """All-gather row-sharded results (rows = prompts) back into (n_total, ...) on every rank.
   Uneven shards are padded to the largest shard for the collective and trimmed afterwards.  EVERY rank must call this,
   also one whose shard is empty (n_total < world): it passes a (0, ...) tensor of the right trailing shape / dtype /
-  device — entering the collective with nothing to contribute is what keeps the other ranks from hanging."""
+  device — entering the collective with nothing to contribute is what keeps the other ranks from hanging.
+  force_collective: run the collective even in a one-rank group (a single-GPU box can then exercise the RCCL communicator and
+  its all-gather kernel: tests/test_coverage_gpu.py::test_gather_rows_rccl_one_rank)."""
   r, w = world(distributed)
   if local is None:
     raise ValueError("gather_rows: pass a (0, ...) tensor for an empty shard, not None (every rank enters the collective)")
-  if w == 1:
+  if w == 1 and not (force_collective and dist.is_available() and dist.is_initialized()):
     return local
   max_rows = (n_total + w - 1) // w
   lo, hi = shard_bounds(n_total, r, w)

@@ -154,8 +154,10 @@ typedef struct {
   int32_t max_batch;            /* largest UNet batch (2 x prompts with CFG) */
   int32_t heads_per_level[4];   /* all 0: num_heads at every level (SD-1.x); SD-2.x: 5,10,20,20 (head dim 64 everywhere) */
   int32_t v_prediction;         /* 0: the UNet predicts epsilon (SD-1.x, SD-2.1-base); 1: v (SD-2.1-768) */
-  int32_t fp8_convs;            /* 1: ResnetBlock2D 3x3 convolutions with fp8 (e4m3) activations and weights on the fp8 matrix
-                                 * instruction (BASELINE.json configs[4]); 0 (the parity configuration): everything bf16 */
+  int32_t fp8_convs;            /* BASELINE configs[4] (no reference counterpart: the reference runs SD in fp16).  1: the ResnetBlock2D 3x3 convolutions
+                                 * AND the GEGLU projections of the level 1-3 transformer blocks with fp8 (e4m3) activations and weights on the fp8
+                                 * matrix instruction (csrc/conv_fp8.hip, csrc/linear_fp8.hip); 2: the convolutions only (the round-5 mode); 0: off
+                                 * (bf16, the parity configuration) */
 } gill_unet_config;
 
 int gill_unet_create(gill_unet** out, const gill_unet_config* cfg, const gill_tensor* weights, int n_weights);
@@ -268,6 +270,12 @@ int gill_op_ffn_fused(const void* t_bf16, const float* ln_g, const float* ln_b, 
                       void* out_bf16, float* gn_stats, int M, int rows_per_batch, const void* o2_bf16, const void* Wo_bf16,
                       const float* bo2, void* stream);
 
+/* BASELINE configs[4] (not a reference function): the GEGLU projection of a BasicTransformerBlock (diffusers ff.net.0; reference call site
+ * gill/custom_sd.py:633-638) on CDNA4's fp8 matrix instruction — out (M, inner) bf16 = h * gelu(g), [h | g] = LayerNorm(t; ln_g, ln_b) W^T + b with
+ * t (M, C) bf16, W (2 inner, C) bf16 in diffusers order [value rows | gate rows], b (2 inner) fp32; activations and weights quantised to e4m3 exactly as
+ * the engine's fp8 mode does (per-row weight scales, fp8(16 * LNhat(t))).  inner % 16 == 0, C % 128 == 0.  Synchronises. */
+int gill_op_geglu_fp8(const void* t, const float* ln_g, const float* ln_b, const void* W, const float* b, void* out, int M, int inner, int C,
+                      void* stream);
 /* The two projections around norm1 / norm2 of a level-0 (C = 320, 8 heads of 40) transformer block as one kernel (csrc/lnproj.hip), on
  * natural (diffusers-layout) operands.  mode 0: t = proj_in(x); [q | k | v] = [to_q; to_k; to_v](LN(t)) (W2 = the three weights stacked,
  * (960, 320)).  mode 1: t += to_out(x) + b1 (in place, x = the attention output); q = to_q(LN(t)) (W2 (320, 320)).  Outputs in the

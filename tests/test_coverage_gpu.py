@@ -458,6 +458,40 @@ def test_gather_rows_rccl(n_total):
     assert rows == [float(i) for i in range(n_total)]
 
 
+def _nccl_one_rank_worker(port, q):
+  import torch.distributed as dist
+  from gill_amd import parallel
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  torch.cuda.set_device(0)
+  dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+  local = torch.arange(8, dtype=torch.float32, device="cuda:0").reshape(-1, 1, 1, 1).expand(-1, 4, 64, 64).contiguous()   # 8 prompts' latents: 512 KiB
+  out = parallel.gather_rows(local, 8, force_collective=True)
+  torch.cuda.synchronize()
+  q.put((out[:, 0, 0, 0].cpu().tolist(), tuple(out.shape), ".".join(str(v) for v in torch.cuda.nccl.version())))
+  dist.destroy_process_group()
+
+
+def test_gather_rows_rccl_one_rank(cuda):
+  """The collective of the N > 1 path on the hardware that IS available: a one-rank `nccl` (= RCCL on ROCm) process group on this box's
+  single MI355X, gather_rows forced through dist.all_gather_into_tensor — communicator creation, the RCCL all-gather kernel on gfx950 and
+  the padding / trimming around it run for real (the xGMI links do not: that takes the 2-GPU test above, skipped on one-GPU boxes)."""
+  import socket
+  import torch.multiprocessing as mp
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  p = ctx.Process(target=_nccl_one_rank_worker, args=(port, q))
+  p.start()
+  rows, shape, ver = q.get(timeout=180)
+  p.join(60)
+  print(f"[RCCL {ver}, one rank] all_gather_into_tensor of {shape}: ok")
+  assert rows == [float(i) for i in range(8)] and shape == (8, 4, 64, 64)
+
+
 def test_bench_two_ranks_share_one_gpu_gloo(cuda):
   """bench.py's multi-rank path end to end with real kernels: `python bench.py --gpus 2` self-spawns two ranks under
   torch.distributed.run (127.0.0.1); they shard 2 x 2 prompts, run the whole hot path, all-gather the latents and print ONE json

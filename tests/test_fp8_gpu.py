@@ -55,6 +55,46 @@ def test_conv3x3_fp8_vs_quantised_fp32(cuda, B, H, W, Cin, Cout, sk):
   assert rel < 6e-2
 
 
+@pytest.mark.parametrize("M,C", [(256, 640), (2048, 1280), (200, 128), (8192, 640)])
+def test_geglu_fp8_vs_quantised_fp32(cuda, M, C):
+  """linear_fp8.hip: the GEGLU projection (diffusers ff.net.0 on norm3's output) with e4m3 activations and weights on
+  v_mfma_scale_f32_16x16x128_f8f6f4, against fp32 arithmetic on the SAME quantised operands — fp8(16 * LNhat(t)) with the statistics of the bf16
+  rows, rows of bf16(gamma * W) quantised per output row, bias + beta . W^T in fp32 (torch.float8_e4m3fn emulates the quantiser) — and, reported,
+  against the un-quantised GEGLU (what the e4m3 operands cost).  Shapes: UNet level 1 (C = 640, 5 K steps of 128), level 2 (1280), a ragged M, and the
+  level-1 row count of the 8-sample batch."""
+  from gill_amd import ops
+  inner = 4 * C
+  t = (synth.normal("g8_t", (M, C), 11) * 1.7 + 0.3).bfloat16()
+  g = 1.0 + 0.2 * synth.normal("g8_g", (C,), 12)
+  be = 0.1 * synth.normal("g8_be", (C,), 13)
+  w = synth.normal("g8_w", (2 * inner, C), 14, std=C ** -0.5).bfloat16()
+  b = 0.1 * synth.normal("g8_b", (2 * inner,), 15)
+  got = ops.geglu_fp8(t.to(cuda), g.to(cuda), be.to(cuda), w.to(cuda), b.to(cuda)).float().cpu()
+  assert torch.isfinite(got).all()
+  tf = t.float()
+  mean = tf.mean(-1, keepdim=True)
+  var = (tf * tf).mean(-1, keepdim=True) - mean * mean          # (the kernel's E[x^2] - E[x]^2 form)
+  tn = (tf - mean) * torch.rsqrt(var.clamp_min(0) + 1e-5)
+  xq = _q(tn, 16.0)
+  wf = (w.float() * g).bfloat16().float()                        # ln_fold_rows: gamma folded into the rows, rounded to bf16
+  sc = wf.abs().amax(dim=1, keepdim=True) / 448.0
+  wq = _q(wf / sc, 1.0) * sc
+  bias = b + w.float() @ be                                      # beta . W^T on the un-folded rows
+  proj = xq @ wq.T + bias
+  h, gate = proj.chunk(2, dim=-1)
+  ref = h * F.gelu(gate)
+  err = (got - ref).abs().max().item()
+  scale = ref.abs().max().item()
+  print(f"[geglu fp8 {M}x{C}] max_abs={err:.3e} of {scale:.2f}")
+  assert err < 1.5e-2 * scale      # bf16 output rounding + fp32 accumulation order + the A-S erf (1.5e-7); the quantisation itself is in `ref`
+  proj_full = F.layer_norm(tf, (C,), g, be, 1e-5) @ w.float().T + b
+  hf, gf = proj_full.chunk(2, dim=-1)
+  full = hf * F.gelu(gf)
+  rel = ((got - full).norm() / full.norm()).item()
+  print(f"  vs un-quantised GEGLU: rel-L2 {rel:.3e}")
+  assert rel < 6e-2
+
+
 def _bfw(sd):
   return {k: v.bfloat16().float() for k, v in sd.items()}
 
