@@ -103,7 +103,7 @@ def _bfw(sd):
 def test_fp8_unet_mode_vs_bf16_mode(cuda, which):
   """gill_unet_config.fp8_convs = 1 against this build's parity (bf16) configuration on the same weights and inputs through
   gill_sd_denoise (10 PLMS steps, CFG 7.5): the latents must stay within a stated distance — what the e4m3 operands of the 44
-  resnet convolutions cost after 11 recurrent UNet calls — and the fp8 mode must itself be bit-reproducible (its statistics
+  resnet convolutions and (round 6) the 11 GEGLU projections of levels 1-3 cost after 11 recurrent UNet calls — and the fp8 mode must itself be bit-reproducible (its statistics
   and split-K reductions are the same fixed-order ones)."""
   import dataclasses
   from gill_amd.sd import GillSDPipeline
@@ -121,7 +121,10 @@ def test_fp8_unet_mode_vs_bf16_mode(cuda, which):
   rel = ((got - ref).norm() / ref.norm()).item()
   cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
   print(f"[fp8 UNet mode vs bf16 mode, {which}, 10-step CFG] rel-L2 {rel:.3e} cos {cos:.5f}")
-  assert rel < 8e-2 and cos > 0.995      # the same bar the bf16 mode is held to against the fp32 oracle
+  # sd15: the bar the bf16 mode is held to against the fp32 oracle.  tiny: 1e-1 since round 6 — with the GEGLU projections in e4m3 as well (an e4m3
+  # x e4m3 dot product of zero-mean operands carries ~5 % relative error whatever its length: test_geglu_fp8_vs_quantised_fp32 reports 5.3e-2) the
+  # random tiny UNet lands at 8.3e-2 after its 11 recurrent calls; the full-size UNet at 6.0e-2 (profiles/r06_fp8_tests.log)
+  assert rel < (1e-1 if which == "tiny" else 8e-2) and cos > 0.995
   again = pipe8(**kw).images.float().cpu()
   assert torch.equal(again, got)
 
@@ -130,8 +133,8 @@ def test_fp8_unet_mode_vs_bf16_mode(cuda, which):
 def test_fp8_unet_forward_vs_fp32_oracle(cuda, which):
   """the fp8 mode was only ever compared with this build's own bf16 mode.  Here ONE UNet forward (CFG pair, t = 961) with
   the 44 resnet convolutions in e4m3 goes against the fp32 CPU oracle (oracle/unet_ref.py, the same one the bf16 mode is held to), next to
-  the bf16 mode's own distance on the same inputs.  Measured: bf16 1.17e-2 (both sizes); fp8 5.4e-2 at full size, 5.8e-2 on the tiny UNet, cosine
-  0.9983-0.9986 — what e4m3 operands in the 44 resnet convolutions cost one forward.  Bars: bf16 5e-2 / 0.998 (its bar everywhere), fp8 8e-2 /
+  the bf16 mode's own distance on the same inputs.  Measured: bf16 1.16e-2 / 1.21e-2; fp8 5.84e-2 at full size, 6.13e-2 on the tiny UNet, cosine
+  0.9981-0.9983 (round 5, convolutions only: 5.4e-2 / 5.8e-2) — what e4m3 operands in the 44 resnet convolutions and the 11 GEGLU projections cost one forward.  Bars: bf16 5e-2 / 0.998 (its bar everywhere), fp8 8e-2 /
   0.997 (the bar bench.py's forward_check applies to the C5 line)."""
   import dataclasses
   from gill_amd.sd import GillSDPipeline
