@@ -86,7 +86,9 @@ def test_geglu_fp8_vs_quantised_fp32(cuda, M, C):
   err = (got - ref).abs().max().item()
   scale = ref.abs().max().item()
   print(f"[geglu fp8 {M}x{C}] max_abs={err:.3e} of {scale:.2f}")
-  assert err < 1.5e-2 * scale      # bf16 output rounding + fp32 accumulation order + the A-S erf (1.5e-7); the quantisation itself is in `ref`
+  # bf16 output rounding + fp32 accumulation order + e4m3 roundings flipped by the last bit of rstd (one flip = 6 % of that element): measured
+  # 0.9-1.4e-2 of the output range (profiles/r06_fp8_tests.log); the quantisation itself is in `ref`
+  assert err < 2e-2 * scale
   proj_full = F.layer_norm(tf, (C,), g, be, 1e-5) @ w.float().T + b
   hf, gf = proj_full.chunk(2, dim=-1)
   full = hf * F.gelu(gf)
