@@ -60,6 +60,7 @@ struct AttCfg {
 // |score| >= 2^15, ADVICE r03.  The d = 40 shapes that matter run on the LDS-DMA kernel below; this kernel keeps the exact fp32 offset.)
 template <int DP, int ATT_THREADS>
 __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_kernel(const AttnArgs p) {
+  kernarg_warm<sizeof(AttnArgs)>();
   using Cfg = AttCfg<DP, ATT_THREADS>;
   constexpr int ATT_QB = ATT_THREADS / 2;
   constexpr int KS = Cfg::KS, NDT = Cfg::NDT, KSTR = Cfg::KSTR, VSTR = Cfg::VSTR;
@@ -340,6 +341,7 @@ __global__ __launch_bounds__(ATT_THREADS, (DP <= 64 ? 4 : 2)) void attention_ker
 // loop +0.8 %; with a sched_group_barrier order "1 MFMA, 1 LDS read, 7 VALU" over the whole tile (148 VGPRs) loop +-0.3 %.  Removed.
 template <int DP, int ATT_THREADS>
 __global__ __launch_bounds__(ATT_THREADS, 4) void attention_dma_kernel(const AttnArgs p) {
+  kernarg_warm<sizeof(AttnArgs)>();
   static_assert(DP == 48, "QF3 needs three padding dims behind d = 40");
   constexpr int NW = ATT_THREADS / 64;            // waves per workgroup
   constexpr int ATT_QB = ATT_THREADS / 2;         // queries per workgroup

@@ -15,6 +15,38 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define GILL_WAVE 64
 
 
+// KERNARG WARM-UP.  A kernel's arguments are s_load'ed from the kernarg segment, which was written for this launch: the first touch of each of its
+// 64-byte lines is a scalar-cache miss served from memory (~0.5-1 us under load), and hipcc issues those loads where the values are first needed —
+// behind branches and integer divisions — so an argument struct of several hundred bytes costs several SERIALISED misses before the first memory
+// instruction of the kernel is out (the "set-up" part of every launch's fixed cost, profiles/r05_opt_stream64.md).  First statement of a kernel:
+// one dword of every line, all in flight at once, one wait — the compiler's own loads then hit the scalar cache.  BYTES = explicit argument bytes
+// (only offsets inside them are touched; the hidden block behind them shares their last line or follows it); at most 10 lines.
+template <int OFF>
+__device__ __forceinline__ unsigned kernarg_touch(uint64_t ka) {
+  unsigned t;
+  asm volatile("s_load_dword %0, %1, %2" : "=s"(t) : "s"(ka), "i"(OFF));
+  return t;
+}
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+  const uint64_t ka = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+  constexpr int L = (BYTES + 63) / 64;
+  static_assert(L >= 1 && L <= 10, "kernarg_warm: 1 .. 640 argument bytes");
+  unsigned t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, t8 = 0, t9 = 0;
+  t0 = kernarg_touch<0>(ka);
+  if constexpr (L > 1) t1 = kernarg_touch<64>(ka);
+  if constexpr (L > 2) t2 = kernarg_touch<128>(ka);
+  if constexpr (L > 3) t3 = kernarg_touch<192>(ka);
+  if constexpr (L > 4) t4 = kernarg_touch<256>(ka);
+  if constexpr (L > 5) t5 = kernarg_touch<320>(ka);
+  if constexpr (L > 6) t6 = kernarg_touch<384>(ka);
+  if constexpr (L > 7) t7 = kernarg_touch<448>(ka);
+  if constexpr (L > 8) t8 = kernarg_touch<512>(ka);
+  if constexpr (L > 9) t9 = kernarg_touch<576>(ka);
+  // (the destination registers stay allocated up to the wait: inputs of this statement)
+  asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(t0), "s"(t1), "s"(t2), "s"(t3), "s"(t4), "s"(t5), "s"(t6), "s"(t7), "s"(t8), "s"(t9) : "memory");
+}
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // fp32 -> bf16 through the native type: hipcc lowers these to gfx950's v_cvt_pk_bf16_f32 (round-to-nearest-even,

@@ -429,6 +429,7 @@ int copy_bytes_launch(void* dst, const void* src, size_t bytes, hipStream_t s) {
 }
 
 __global__ __launch_bounds__(256) void sd_stage_kernel(const SdLoopArgs a) {
+  kernarg_warm<sizeof(SdLoopArgs)>();
   const int step = a.ctr[0];          // nobody writes ctr[0] while this kernel runs
   const int64_t total = (int64_t)a.B * a.n;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -449,6 +450,7 @@ int sd_stage_launch(const SdLoopArgs& a, hipStream_t s) {
 }
 
 __global__ __launch_bounds__(256) void plms_step_kernel(const SdLoopArgs a) {
+  kernarg_warm<sizeof(SdLoopArgs)>();
   const int step = a.ctr[1];          // written by this step's stage kernel; nobody writes it while this kernel runs
   const PlmsRow r = a.rows[step];
   const int64_t total = (int64_t)a.B * a.n;

@@ -58,6 +58,7 @@ struct Slab { const bf16_t* src; int ld; };   // rows x 64 k starting at src, ro
 // prologue); the ring slots of every later stage shift by FNPRE mod 7.
 template <bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_fused_kernel(const FfnArgs p) {
+  kernarg_warm<sizeof(FfnArgs)>();
   constexpr int SB = PRE ? FNPRE % 7 : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;

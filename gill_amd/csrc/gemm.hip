@@ -1463,6 +1463,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, const GemmTileCtx cx
 }
 template <int NWV, int BN, int CONV, int EPI, int STAGES, int KT, int MI>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 2 : 1) : (MI == 2 ? 3 : 2)) void gemm_kernel(const GemmDev d) {
+  kernarg_warm<sizeof(GemmDev)>();
   GemmTileCtx cx;
   cx.bx = blockIdx.x; cx.by = blockIdx.y; cx.bz = blockIdx.z; cx.gdx = gridDim.x; cx.gdy = gridDim.y;
   gemm_tile<NWV, BN, CONV, EPI, STAGES, KT, MI, 0>(d, cx);
@@ -1476,6 +1477,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? ((BN == 128 && STAGES == 2) ? 
 // GroupNorm partial).
 template <int W, int R>
 __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArgs p) {
+  kernarg_warm<sizeof(GemmArgs)>();
   constexpr int QW = W / 4;                     // column quads per row
   constexpr int ROWS = 16 * R;                  // rows per block: 64 for large outputs, 16 when blocks would be too few
   __shared__ float2 rowp[ROWS][QW];               // per (row, quad) {sum, sum of squares} of the bf16-rounded outputs
@@ -1585,6 +1587,7 @@ __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_kernel(const GemmArg
 
 template <int RPT, int W>
 __global__ __launch_bounds__(4 * W) void gemm_splitk_reduce_gn_kernel(const GemmArgs p) {
+  kernarg_warm<sizeof(GemmArgs)>();
   __shared__ float2 part[16][W / 4];     // per (row lane, column quad) {sum, sum of squares} over the thread's rows
   __shared__ float2 quad[W / 4];         // per column quad, over the 16 row lanes
   __shared__ float2 mr[W / 4];           // per group of the block: {mean, rstd}   (fn_cg >= 4)

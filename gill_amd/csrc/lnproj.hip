@@ -87,6 +87,7 @@ struct Slab { const bf16_t* src; int ld; };
 
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lnproj_kernel(const LnProjArgs p) {
+  kernarg_warm<sizeof(LnProjArgs)>();
   constexpr int K1 = lp_k1(MODE), NSEG = lp_nseg(MODE), G1 = lp_g1(MODE), NST = lp_nst(MODE), KS1 = K1 / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;

@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
                                                               const float* __restrict__ stats1, int nb1, int r1, int ns1, int bs1,
                                                               const float* __restrict__ stats2, int nb2, int r2, int o2, int ns2, int bs2,
                                                               bf16_t* __restrict__ y, int rows, int cc, float out8_scale, float* __restrict__ ss_out) {
+  kernarg_warm<152>();     // 5 + 3 pointers and 17 scalars: three lines
   // block = (slab of `rows` pixels, sample b, chunk of cc <= 256 channels).  Phase 1: fold statistics and affine into
   // per-channel (scale, shift) in LDS — one channel per thread, so the dependent loads of the prologue are paid once,
   // not C/256 times; phase 2: y = [silu](x * scale + shift), 16-B loads and stores.
