@@ -38,7 +38,7 @@ static float* op_splitk_ws(size_t floats) {
 }
 
 // splitk: 0 = the launcher's heuristic, n > 1 = forced.  splitk < 0: FORCE THE GENERAL ROW-MAJOR TILES — never the 64 x 64-blocked
-// STREAM64 copy that weight-streaming shapes (M <= 256, N * K >= 4 Mi) otherwise take — with the heuristic split (-1) or -splitk ways (< -1), so that
+// blocked copy that weight-streaming shapes (N * K >= 4 Mi; the STREAM64 tile up to 256 rows, the general tiles on the blocked layout above) otherwise take — with the heuristic split (-1) or -splitk ways (< -1), so that
 // the operator tests can pin both paths on the same shape (the UNet and CLIP engines run such shapes on the general tiles).
 extern "C" int gill_op_gemm(const void* A, const void* W, const float* bias, const void* resid_bf16, void* C, int M, int N,
                             int K, float alpha, int act, int out_f32, int splitk, void* stream) {
@@ -54,9 +54,9 @@ extern "C" int gill_op_gemm(const void* A, const void* W, const float* bias, con
   g.C = C; g.ldc = N;
   const bool row_major = splitk < 0;
   if (row_major) splitk = (splitk == -1) ? 0 : -splitk;
-  // weight-streaming shapes at a few hundred rows run the way the OPT engine runs them: on a 64 x 64-blocked copy of W (STREAM64)
+  // weight-streaming shapes run the way the OPT engine runs them: on a 64 x 64-blocked copy of W (gemm_launch picks the tile by M)
   DevBuf wblk;
-  if (!row_major && M <= 256 && act != ACT_GEGLU && gemm_stream64_weights(N, K)) {
+  if (!row_major && act != ACT_GEGLU && gemm_stream64_weights(N, K)) {
     GILL_TRY(wblk.alloc(sizeof(bf16_t) * (size_t)N * K));
     GILL_TRY(convert_to_bf16_blk64_launch(W, 0, N, K, (bf16_t*)wblk.p, s));
     g.W = (const bf16_t*)wblk.p; g.w_blk64 = 1;

@@ -515,6 +515,10 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, const GemmTileCtx cx
     }
     return half * (BN / 2) + c;
   };
+  // 64 x 64-blocked weights on the GENERAL tiles too (plain GEMMs, GemmArgs::w_blk64 with more rows than the STREAM64 tile is for — ADVICE r05): the
+  // tile's weight rows come out of N / 64 blocks, a K step ahead is the next 8 KiB block of each
+  const bool wblk = WBLK || (CONV == 0 && p.w_blk64 != 0);
+  const int w_step = wblk ? 4096 : KT;
   const bf16_t* Wb = p.W + (p.wb_rows ? (size_t)(m0 / p.wb_rows) * (size_t)p.wb_stride : (size_t)0);     // per-sample weights (GemmArgs::wb_rows)
   auto w_setup = [&]() {
 #pragma unroll
@@ -522,7 +526,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, const GemmTileCtx cx
       int row = tile_col((i * NWV + w) * RPI + srow);
       int n = n_issue + row;
       if (n > p.N - 1) n = p.N - 1;
-      if constexpr (WBLK) w_ptr[i] = Wb + ((size_t)(n_issue / 64) * d.ksteps + kt_beg) * 4096 + row * 64 + schunk * 8;
+      if (wblk) w_ptr[i] = Wb + ((size_t)(n >> 6) * d.ksteps + kt_beg) * 4096 + (n & 63) * 64 + schunk * 8;     // (N % 64 == 0: n is never clamped across a block)
       else w_ptr[i] = Wb + ((size_t)cls * p.N + n) * p.K + schunk * 8 + kt_beg * KT;
     }
   };
@@ -645,7 +649,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& d, const GemmTileCtx cx
 #pragma unroll
     for (int i = 0; i < AI; ++i) a_ptr[i] += KT;
 #pragma unroll
-    for (int i = 0; i < WI; ++i) w_ptr[i] += WBLK ? 4096 : KT;
+    for (int i = 0; i < WI; ++i) w_ptr[i] += WBLK ? 4096 : (CONV == 0 ? w_step : KT);
     k_issue += KT;
   };
   auto issue = [&](int buf) {
@@ -1765,6 +1769,7 @@ bool gemm_stream64_weights(int N, int K) {
   return N % 64 == 0 && K % 64 == 0 && K >= 1024 && (int64_t)N * K >= ((int64_t)4 << 20);
 }
 int gemm_pick_splitk_blk64(int M, int N, int K) {
+  if (M > GEMM_STREAM64_MAX_ROWS) return gemm_pick_splitk(M, N, K, ACT_NONE);     // (runs on the general tiles: gemm_launch())
   const int tiles = cdiv(M, 128) * (N / 64), ksteps = K / BK;
   if (tiles >= 160) return 1;
   int s = (256 + tiles / 2) / tiles;
@@ -2143,7 +2148,8 @@ int gemm_launch(const GemmArgs& a, hipStream_t s) {
     GILL_REQUIRE(!a.conv && a.N % 64 == 0 && a.K1 == a.K && !a.gn_stats && !a.row_stats && !a.ln_stats && !a.wb_rows && !a.fn_Y &&
                      a.act != ACT_GEGLU && a.out_mode != OUT_SOFTMAX80,
                  "64 x 64-blocked weights (STREAM64): plain GEMMs with the row-major, QKV or split-K epilogue only");
-    return gemm_launch_stream64(a, s);
+    if (a.M <= GEMM_STREAM64_MAX_ROWS) return gemm_launch_stream64(a, s);
+    // more rows than that: the general tiles read the blocked layout (the 128 x 64 tile is CU-bound per M tile: profiles/r05_opt_stream64.md)
   }
   const int bn = tile_width(a);
   if (bn == 160) return gemm_launch_bn<160>(a, s);

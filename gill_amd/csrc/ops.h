@@ -43,7 +43,7 @@ struct GemmArgs {
   int kv_tok_offset = 0;  // K / Vt rows land at token t + kv_tok_offset (appending to a KV cache); Q rows stay at t
   // split-K (0/1 = off).  ws must hold splitk*M*N floats.
   int splitk = 1; float* ws = nullptr;
-  int w_blk64 = 0;         // W is stored as [N / 64][K / 64][64][64] (convert_to_bf16_blk64_launch): the STREAM64 kernel, any M
+  int w_blk64 = 0;         // W is stored as [N / 64][K / 64][64][64] (convert_to_bf16_blk64_launch): the STREAM64 kernel up to GEMM_STREAM64_MAX_ROWS rows, the general tiles above
   int partials_only = 0;   // split-K: write the fp32 partials and stop — the caller runs its own reducer (opt.hip: reduce + residual + LayerNorm)
   // Both kinds of fused statistics are FIXED-ORDER: a producer writes each partial sum exactly once (no atomics, nothing to
   // zero), the consumer adds the partials in index order, so two runs of the same launch sequence are bit-identical.
@@ -105,7 +105,11 @@ bool gemm_fused_gn_ok(int N, int cg);
 // heuristic split-K factor for under-filled grids.  plain: not a conv (64-row tiles available); generic: 128-row 4-wave tiles only (the fp8 conv
 // kernel): neither the 64-row nor the ping-pong rules
 int gemm_pick_splitk(int M, int N, int K, int act, bool plain = false, bool generic = false);
-// STREAM64 (gemm.hip): which weight matrices are stored 64 x 64-blocked, and the split-K factor of a GEMM on one
+// STREAM64 (gemm.hip): which weight matrices are stored 64 x 64-blocked, and the split-K factor of a GEMM on one.  Up to GEMM_STREAM64_MAX_ROWS rows
+// such a GEMM runs on the 128 x 64 streaming tile, above on the general tiles, which read the blocked layout as well
+#ifndef GEMM_STREAM64_MAX_ROWS
+#define GEMM_STREAM64_MAX_ROWS 256
+#endif
 bool gemm_stream64_weights(int N, int K);
 int gemm_pick_splitk_blk64(int M, int N, int K);
 

@@ -22,7 +22,8 @@ def _bf(t: torch.Tensor) -> torch.Tensor:
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
          alpha: float = 1.0, act: str = "none", out_f32: bool = False, splitk: int = 0, row_major: bool = False) -> torch.Tensor:
   """act(alpha * a @ w.T + bias + resid); a (M,K) bf16, w (N,K) bf16, bias (N) fp32, resid (M,N) bf16.
-  row_major: keep weight-streaming shapes (M <= 256, N * K >= 4 Mi) on the general tiles instead of the 64 x 64-blocked STREAM64 copy."""
+  row_major: keep weight-streaming shapes (N * K >= 4 Mi) on row-major weights instead of the 64 x 64-blocked copy (STREAM64 tile up to 256 rows, general
+  tiles on the blocked layout above)."""
   if row_major:
     splitk = -1 if splitk <= 1 else -splitk
   a, w = _bf(a), _bf(w)

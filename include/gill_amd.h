@@ -220,7 +220,8 @@ int gill_coop_timeouts(void);
  * ------------------------------------------------------------------------------------------ */
 /* C[M,N] = act(alpha * A[M,K] . W[N,K]^T + bias[N] + resid[M,N]); act: 0 none 1 relu 2 gelu(erf) 3 silu.
  * out_f32: C is fp32 instead of bf16.  splitk: 0 = auto, n > 1 = forced n-way split; < 0 = the general row-major tiles even for the
- * weight-streaming shapes (M <= 256, N * K >= 4 Mi) that otherwise run on a 64 x 64-blocked copy of W (-1: auto split, -n: n ways).
+ * weight-streaming shapes (N * K >= 4 Mi) that otherwise run on a 64 x 64-blocked copy of W — the STREAM64 tile up to 256 rows, the general tiles reading
+ * the blocked layout above — (-1: auto split, -n: n ways).
  * Split-K launches share one grow-only workspace owned by the library: one caller at a time (as everywhere on this path). */
 int gill_op_gemm(const void* A, const void* W, const float* bias, const void* resid_bf16, void* C, int M, int N, int K,
                  float alpha, int act, int out_f32, int splitk, void* stream);

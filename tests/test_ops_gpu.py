@@ -100,6 +100,24 @@ def test_gemm_stream64_blocked_weights(cuda, M, N, K, sk):
   assert _report(f"gemm row-major tiles bf16 {M}x{N}x{K} sk{sk}", out_rm, pre) < 1e-2
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(512, 4096, 1024, 0), (512, 1024, 4096, 0), (384, 2048, 2048, 2), (1000, 4096, 1024, 0), (260, 1600 + 64 * 7, 4096, 0)])
+def test_gemm_blocked_weights_on_the_general_tiles(cuda, M, N, K, sk):
+  """above 256 rows a GEMM on 64 x 64-blocked weights leaves the STREAM64 tile (CU-bound per M tile) for the general tiles, which read the
+  blocked layout themselves (gemm.hip `wblk`: only the weight pointers differ).  Same tiles, same K order as on row-major weights, so the two
+  results must be bit-identical; vs torch as usual.  (OPT prefills of 16 prompts and long get_log_likelihood_scores sequences take this path.)"""
+  from gill_amd import ops
+  a, w = _bf(_rnd((M, K), 31)), _bf(_rnd((N, K), 32, 0.05))
+  bias = _rnd((N,), 33)
+  pre = a.float() @ w.float().T + bias
+  out = ops.gemm(a.to(cuda), w.to(cuda), bias.to(cuda), act="relu", out_f32=True, splitk=sk)
+  assert _report(f"gemm blocked / general tiles relu f32 {M}x{N}x{K} sk{sk}", out, F.relu(pre)) < 1e-4
+  out_rm = ops.gemm(a.to(cuda), w.to(cuda), bias.to(cuda), act="relu", out_f32=True, splitk=sk, row_major=True)
+  assert torch.equal(out, out_rm)
+  out16 = ops.gemm(a.to(cuda), w.to(cuda), bias.to(cuda), splitk=sk)
+  assert _report(f"gemm blocked / general tiles bf16 {M}x{N}x{K} sk{sk}", out16, pre) < 1e-2
+  assert torch.equal(out16, ops.gemm(a.to(cuda), w.to(cuda), bias.to(cuda), splitk=sk, row_major=True))
+
+
 def test_geglu(cuda):
   from gill_amd import ops
   M, K, inner = 192, 320, 1280
