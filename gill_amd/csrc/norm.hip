@@ -407,21 +407,38 @@ int groupnorm_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, int B, 
 // (A producer's partials are never modified: a UNet skip tensor is normalised twice — by the next block and by the up block's
 // concatenated norm1 — and the second consumer must see the same partials as the first.)
 #define GN_MAX_PARTIALS 64
-__global__ __launch_bounds__(256) void groupnorm_total_kernel(const float* __restrict__ stats, int ns, int nb, float* __restrict__ tot) {
+// Block = 16 (bin, moment) columns x 64 slab slices (1024 threads); grid = (columns / 16, samples).  Slice q adds the slabs q, q + 64, q + 128, ...
+// on eight accumulators, the 64 slices are then added on a fixed tree: a fixed order for a given slab count (bit-reproducible), and 64 x the loads in
+// flight of round 5's one-thread-per-column form, which took 90-220 us for the VAE's 4096 slabs per sample (19 launches, 1.8 ms per decode).
+#define GN_TOT_COLS 16
+#define GN_TOT_SLICES 64
+__global__ __launch_bounds__(GN_TOT_COLS * GN_TOT_SLICES) void groupnorm_total_kernel(const float* __restrict__ stats, int ns, int nb, float* __restrict__ tot) {
+  __shared__ float part[GN_TOT_SLICES][GN_TOT_COLS + 1];
   const int b = blockIdx.y;
-  const int idx = blockIdx.x * 256 + threadIdx.x;      // (bin, moment)
-  if (idx >= nb * 2) return;
-  const float* base = stats + (size_t)b * ns * nb * 2 + idx;
+  const int col = threadIdx.x & (GN_TOT_COLS - 1), q = threadIdx.x / GN_TOT_COLS;
+  const int idx = blockIdx.x * GN_TOT_COLS + col;      // (bin, moment)
+  const bool live = idx < nb * 2;
+  const float* base = stats + (size_t)b * ns * nb * 2 + (live ? idx : 0);
   const size_t step = (size_t)nb * 2;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
-  int sl = 0;
-  for (; sl + 8 <= ns; sl += 8) {
-    a0 += base[(size_t)sl * step]; a1 += base[(size_t)(sl + 1) * step]; a2 += base[(size_t)(sl + 2) * step];
-    a3 += base[(size_t)(sl + 3) * step]; a4 += base[(size_t)(sl + 4) * step]; a5 += base[(size_t)(sl + 5) * step];
-    a6 += base[(size_t)(sl + 6) * step]; a7 += base[(size_t)(sl + 7) * step];
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int sl = q; sl < ns; sl += 8 * GN_TOT_SLICES) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s2 = sl + u * GN_TOT_SLICES;
+      v[u] = (s2 < ns) ? base[(size_t)s2 * step] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += v[u];
   }
-  for (; sl < ns; ++sl) a0 += base[(size_t)sl * step];
-  tot[(size_t)b * nb * 2 + idx] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  part[q][col] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  // slices folded pairwise, halving: 64 -> 32 -> ... -> 1 (every thread of the upper half idles; six barriers on a 1 KiB table)
+  for (int h = GN_TOT_SLICES / 2; h >= 1; h >>= 1) {
+    if (q < h) part[q][col] += part[q + h][col];
+    __syncthreads();
+  }
+  if (q == 0 && live) tot[(size_t)b * nb * 2 + idx] = part[0][col];
 }
 
 static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
@@ -445,12 +462,12 @@ int groupnorm_apply_launch(const bf16_t* x1, int C1, const bf16_t* x2, int C2, i
   if (nslab1 > GN_MAX_PARTIALS || (stats2 && nslab2 > GN_MAX_PARTIALS))
     GILL_REQUIRE(tot_scratch != nullptr, "groupnorm: more than 64 partials per bin need a totals scratch (groupnorm_totals_floats)");
   if (nslab1 > GN_MAX_PARTIALS) {
-    hipLaunchKernelGGL(groupnorm_total_kernel, dim3(cdiv(2 * nb1, 256), B), dim3(256), 0, s, stats1, nslab1, nb1, tot_scratch);
+    hipLaunchKernelGGL(groupnorm_total_kernel, dim3(cdiv(2 * nb1, GN_TOT_COLS), B), dim3(GN_TOT_COLS * GN_TOT_SLICES), 0, s, stats1, nslab1, nb1, tot_scratch);
     stats1 = tot_scratch; ns1 = 1; bs1 = 1;
   }
   if (stats2 && nslab2 > GN_MAX_PARTIALS) {
     float* t2 = tot_scratch + (size_t)B * nb1 * 2;
-    hipLaunchKernelGGL(groupnorm_total_kernel, dim3(cdiv(2 * nb2, 256), B), dim3(256), 0, s, stats2, nslab2, nb2, t2);
+    hipLaunchKernelGGL(groupnorm_total_kernel, dim3(cdiv(2 * nb2, GN_TOT_COLS), B), dim3(GN_TOT_COLS * GN_TOT_SLICES), 0, s, stats2, nslab2, nb2, t2);
     stats2 = t2; ns2 = 1; bs2 = 1;
   }
   GILL_CHECK_HIP(hipGetLastError());
