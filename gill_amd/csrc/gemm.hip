@@ -1627,8 +1627,17 @@ static inline int reduce_rows(const GemmArgs& a) {
 // Long-K plain GEMMs whose width tiles by 160 (the feed-forward output GEMMs of UNet levels 1-3: K = 5 C) run on the convolutions'
 // ping-pong kernel too: their 64 x 160 / 128 x 160 four-wave tiles fetch 22 / 14 KiB per MFLOP through a 64 B/clk L2 port, the 8-wave
 // tiles 14 / 10 (round 4 A/B: 57 -> 43 us at level 1, loop -0.5 %)
+// (round 6: ... and, from K = 640 up, the plain GEMMs whose ping-pong tiling is ONE full round of workgroups — proj_in / attn1.to_out of level 1 at the CFG batch 8,
+// 8192 x 640 x 640: 256 ping-pong workgroups, one per CU, instead of 320 four-wave 128 x 128 tiles of which 64 CUs get two; 17.4 -> 14.3 us stand-alone,
+// tools/pp_shortk_probe.py.  Fewer tiles than CUs (2048 x 1280 x 1280: 16.4 -> 18.3 us) and K = 320 (level 0: +-0) stay on the general tiles.)
 static bool gemm_plain_pingpong(int M, int N, int K) {
-  return N % 160 == 0 && M % 128 == 0 && K >= 2560 && K % 64 == 0;
+  if (N % 160 != 0 || M % 128 != 0 || K % 64 != 0) return false;
+  if (K >= 2560) return true;
+  // workgroups the launcher will make of it (gemm_launch_bn: 128-row tiles when 256-row ones give at most 128): ONE balanced round only — with
+  // ten K steps a second, partial round costs more than the tile gains
+  const int64_t wg256 = (int64_t)cdiv(M, 256) * (N / 160);
+  const int64_t wg = (wg256 <= 128 || M % 256 != 0) ? (int64_t)(M / 128) * (N / 160) : wg256;
+  return K >= 640 && wg >= 200 && wg <= 256;
 }
 
 // ... and the launch's other conditions (tile_width() and gemm_launch_bn() used to test different things): the 8-wave plain kernel has

@@ -18,7 +18,8 @@ def per_call(fn, r1=4, r2=24):
     ms[r] = e0.elapsed_time(e1)
   os.environ["GILL_OP_REPEAT"] = "1"
   return (ms[r2] - ms[r1]) * 1e3 / (r2 - r1)
-for (M, N, K) in [(8192, 5120, 640), (2048, 10240, 1280), (8192, 1920, 640), (2048, 3840, 1280), (8192, 640, 2560)]:
+for (M, N, K) in [(8192, 5120, 640), (2048, 10240, 1280), (8192, 1920, 640), (2048, 3840, 1280), (8192, 640, 2560), (8192, 640, 640), (2048, 1280, 1280), (32768, 320, 320), (32768, 320, 1280), (512, 1280, 1280)]:
   a = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) * 0.03).bfloat16(); b = torch.randn(N, device=dev)
-  t = per_call(lambda: ops.gemm(a, w, b))
+  r = torch.randn(M, N, device=dev).bfloat16()
+  t = per_call(lambda: ops.gemm(a, w, b, r))
   print(f"GEMM {M} x {N} x {K}: {t:7.1f} us  {2.0 * M * N * K / t / 1e6:6.0f} TFLOP/s")
