@@ -1642,8 +1642,9 @@ static bool gemm_plain_pingpong(int M, int N, int K) {
 
 // ... and the launch's other conditions (tile_width() and gemm_launch_bn() used to test different things): the 8-wave plain kernel has
 // the lean bf16 row-major epilogue only
+// (per-sample weights — GemmArgs::wb_rows, the cross-attention values GEMM — where samples are whole 256-row tiles: round 6, loop 441.8 -> 440.0 ms)
 static bool gemm_plain_pingpong_args(const GemmArgs& a) {
-  return !a.conv && gemm_plain_pingpong(a.M, a.N, a.K) && a.act == ACT_NONE && a.out_mode == OUT_BF16 && !a.resid_f32 && !a.wb_rows && !a.ln_stats;
+  return !a.conv && gemm_plain_pingpong(a.M, a.N, a.K) && a.act == ACT_NONE && a.out_mode == OUT_BF16 && !a.resid_f32 && a.wb_rows % 256 == 0 && !a.ln_stats;
 }
 
 // Tile width.  Tried and removed (numbers in profiles/r02_big_tile.md, profiles/r01_sweep_gemm_tiles.md): a 256 x 256 8-wave tile for
