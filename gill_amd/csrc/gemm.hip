@@ -1630,6 +1630,11 @@ static inline int reduce_rows(const GemmArgs& a) {
 // (round 6: ... and, from K = 640 up, the plain GEMMs whose ping-pong tiling is ONE full round of workgroups — proj_in / attn1.to_out of level 1 at the CFG batch 8,
 // 8192 x 640 x 640: 256 ping-pong workgroups, one per CU, instead of 320 four-wave 128 x 128 tiles of which 64 CUs get two; 17.4 -> 14.3 us stand-alone,
 // tools/pp_shortk_probe.py.  Fewer tiles than CUs (2048 x 1280 x 1280: 16.4 -> 18.3 us) and K = 320 (level 0: +-0) stay on the general tiles.)
+// GILL_GEMM_PP = 0 (A/B switch, read once): no ping-pong tiles for the convolutions, the short-K plain GEMMs and the QKV GEMMs (the long-K plain GEMMs keep them)
+static bool gemm_pp_switch() {
+  static const int pp_env = [] { const char* v = getenv("GILL_GEMM_PP"); return v ? atoi(v) : 1; }();
+  return pp_env != 0;
+}
 static bool gemm_plain_pingpong(int M, int N, int K) {
   if (N % 160 != 0 || M % 128 != 0 || K % 64 != 0) return false;
   if (K >= 2560) return true;
@@ -1637,7 +1642,7 @@ static bool gemm_plain_pingpong(int M, int N, int K) {
   // ten K steps a second, partial round costs more than the tile gains
   const int64_t wg256 = (int64_t)cdiv(M, 256) * (N / 160);
   const int64_t wg = (wg256 <= 128 || M % 256 != 0) ? (int64_t)(M / 128) * (N / 160) : wg256;
-  return K >= 640 && wg >= 200 && wg <= 256;
+  return gemm_pp_switch() && K >= 640 && wg >= 200 && wg <= 256;
 }
 
 // ... and the launch's other conditions (tile_width() and gemm_launch_bn() used to test different things): the 8-wave plain kernel has
@@ -1645,6 +1650,19 @@ static bool gemm_plain_pingpong(int M, int N, int K) {
 // (per-sample weights — GemmArgs::wb_rows, the cross-attention values GEMM — where samples are whole 256-row tiles: round 6, loop 441.8 -> 440.0 ms)
 static bool gemm_plain_pingpong_args(const GemmArgs& a) {
   return !a.conv && gemm_plain_pingpong(a.M, a.N, a.K) && a.act == ACT_NONE && a.out_mode == OUT_BF16 && !a.resid_f32 && a.wb_rows % 256 == 0 && !a.ln_stats;
+}
+
+// QKV GEMMs (head-major scatter epilogue, folded LayerNorm) on the 256 x 160 ping-pong tiles where those give a balanced round of one workgroup per CU
+// (round 6): the workgroups fill >= 75 % of their last round of 256, and 128-row tiles would not fill theirs better.  Level 2 at the CFG batch 8
+// (2048 x 3840 x 1280: 192 workgroups) 52.5 -> 38.5 us per launch, loop -0.9 %.  Returns the wave M sub-tile count (4) or 0.
+// (Measured with it and not kept: the 128-row tiles where THEY are the balanced choice — level 1, 8192 x 1920 x 640, 768 workgroups = three rounds:
+// 46.9 -> 42.7 us per launch, and the loop gains nothing because the card then clocks 15 MHz lower, three boxes, profiles/r06_skeleton_ab.log.
+// Round 4 had these GEMMs on 128-wide ping-pong tiles at every level and lost 0.6-1 %: K = 320 at level 0 and the 1.5-round grids were in it.)
+static int gemm_qkv_pingpong_mi(const GemmArgs& a) {
+  if (!gemm_pp_switch() || a.conv || a.out_mode != OUT_QKV || a.N % 160 != 0 || a.M % 256 != 0 || a.K % 64 != 0 || a.K < 640 || a.splitk > 1 || a.wb_rows || a.w_blk64) return 0;
+  auto fill = [](int64_t wg) { return (double)wg / (double)(((wg + 255) / 256) * 256); };
+  const double f128 = fill((int64_t)(a.M / 128) * (a.N / 160)), f256 = fill((int64_t)(a.M / 256) * (a.N / 160));
+  return (f256 >= 0.75 && f256 >= f128) ? 4 : 0;
 }
 
 // Tile width.  Tried and removed (numbers in profiles/r02_big_tile.md, profiles/r01_sweep_gemm_tiles.md): a 256 x 256 8-wave tile for
@@ -1657,7 +1675,7 @@ static inline int tile_width(const GemmArgs& a) {
   int bn = (a.N % 160 == 0) ? 160 : 128;
   // ... and except for the head-major scatter epilogue (QKV / to_q), whose columns fall into 48..160-wide heads: 128-wide tiles
   // measured 579.3 -> 576.3 ms on the loop
-  if (!a.conv && a.out_mode == OUT_QKV && a.N % 128 == 0) bn = 128;
+  if (!a.conv && a.out_mode == OUT_QKV && a.N % 128 == 0 && !gemm_qkv_pingpong_mi(a)) bn = 128;
   // ... except on the 64-row tile (plain GEMMs with few tiles, see gemm_launch_bn): 64 x 128 needs 48 KiB of LDS, i.e. three
   // workgroups (six waves) per CU instead of two (four) — loop 587.3 -> 584.7 ms
   if (!a.conv && a.splitk <= 1 && a.N % 128 == 0 && !a.gn_stats && (int64_t)cdiv(a.M, 128) * cdiv(a.N, 160) < 300 && a.M > 64 && a.out_mode != OUT_SOFTMAX80 &&
@@ -1685,8 +1703,7 @@ bool gemm_fused_gn_ok(int N, int cg) {
 // (round 4: 256 x 128 ping-pong tiles for the widths 160 does not divide — the VAE decoder's 128 / 256 / 512-channel convolutions: 484.8 /
 // 403.2 / 303.9 us against 464.8 / 406.1 / 301.0 us on the four-wave 128 x 128 tiles, VAE decode 12.74 vs 12.69 ms.  Not kept.)
 bool gemm_conv_pingpong(int rows_multiple_of, int Cout) {
-  static const int pp_env = [] { const char* v = getenv("GILL_GEMM_PP"); return v ? atoi(v) : 1; }();
-  return pp_env != 0 && rows_multiple_of % 256 == 0 && Cout % 160 == 0;
+  return gemm_pp_switch() && rows_multiple_of % 256 == 0 && Cout % 160 == 0;
 }
 
 // ---- COOP (GemmArgs::coop_ctr): which launches may finish in-kernel.
@@ -1896,7 +1913,7 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
       return gemm_launch_inst<4, BN, CONV, EPI, 3, BK, 2>(d, grid, s);
     }
   }
-  if constexpr (BN == 160 && (CONV != 0 || EPI == 2 || EPI == 4)) {
+  if constexpr (BN == 160 && (CONV != 0 || EPI == 2 || EPI == 4 || (CONV == 0 && EPI == 3))) {
     if (d.nwv == 8 && d.mi == 2) return gemm_launch_inst<8, BN, CONV, EPI, 3, BK, 2>(d, grid, s);   // ping-pong 128 x 160 tile
     if (d.nwv == 8) return gemm_launch_inst<8, BN, CONV, EPI, 3>(d, grid, s);     // ping-pong 256 x 160 tile
   }
@@ -1995,6 +2012,7 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
     d.nwv = 8; d.mi = 4;
     if (((int64_t)cdiv(Mk, 256) * d.tiles_n * sk <= 128) || Mk % 256 != 0) d.mi = 2;
   }
+  if (BN == 160 && gemm_qkv_pingpong_mi(a)) { d.nwv = 8; d.mi = gemm_qkv_pingpong_mi(a); }
   // (round 4: the short-K GEGLU / QKV GEMMs on 256 x 128 / 128 x 128 ping-pong tiles, one N tile per workgroup: loop 464.0 -> 478.0 / 480.4 ms
   // (GEGLU), 467.0 / 468.8 ms (QKV) — ten K steps do not amortise a prologue and an epilogue that no second workgroup covers.  Not kept.)
   d.kt = 64;
