@@ -1895,6 +1895,7 @@ static int gemm_launch_stages(const GemmDev& d, dim3 grid, hipStream_t s) {
     }
   }
   if constexpr (CONV == 0 && EPI == 5) {
+    if (d.nwv == 8) return gemm_launch_inst<8, BN, CONV, EPI, 3, BK, 2>(d, grid, s);     // ping-pong 128 x 160 tile
     // 64 x 160 tile on four waves of 32 x 80.  Measured on the three UNet shapes of the 8-sample batch back to back (tools/xalg_bench.py, 20
     // launches each, operands warm): two waves of 64 x 80 1177 us, this with a 2-deep ring 1003-1013 us, 3-deep 1212 us, 3-deep only on
     // the <= 256-workgroup grids 1051 us.  In the UNet forward the per-sample weights are cold (13 MB per layer, read once per call) and
@@ -1996,6 +1997,10 @@ static int gemm_launch_bn(const GemmArgs& a, hipStream_t s) {
   // need the 160-wide tile): loop 492.4 -> 489.4 ms against the two-wave tile.
   if (d.nwv == 2 && BN == 160 && a.act == ACT_NONE && a.out_mode == OUT_BF16) { d.nwv = 4; d.mi = 2; }
   if (a.out_mode == OUT_SOFTMAX80) { d.nwv = 4; d.mi = 2; }      // (see gemm_launch_stages)
+  // ... or, where 128-row ping-pong tiles are exactly one balanced round (level 1 at the CFG batch 8: 8192 x 640 x 640 = 256 workgroups instead of 512
+  // four-wave ones), those (round 6, like the plain GEMMs of that shape)
+  if (BN == 160 && a.out_mode == OUT_SOFTMAX80 && gemm_pp_switch() && sk == 1 && a.M % 128 == 0 && a.wb_rows % 128 == 0 && a.K >= 640 &&
+      (int64_t)(a.M / 128) * d.tiles_n >= 200 && (int64_t)(a.M / 128) * d.tiles_n <= 256) { d.nwv = 8; d.mi = 2; }
   // (round 4: the 64-row four-wave tile with its 3-deep ring — 96 instead of 64 KB in flight per CU — on ALL GEGLU / QKV / 128-wide plain
   // GEMMs, not only the few-tile ones: loop 460.4 -> 469.4 / 464.8 / 460.7 ms.  Not kept.)
   // 3x3 convolutions: 256 x 160 tile with the ping-pong main loop, one workgroup per CU (GILL_GEMM_PP = 0 keeps the two

@@ -590,7 +590,8 @@ def test_lnproj_proj_in_qkv_vs_torch(cuda, B, HW):
 
 
 # ---------------------------------------------------------------- cross-attention as two GEMMs on per-sample weights (csrc/unet.hip "XALG")
-@pytest.mark.parametrize("B,HW,C,nh,ctx_len", [(2, 64, 1280, 8, 77), (3, 256, 1280, 8, 77), (2, 1024, 640, 8, 77), (2, 128, 640, 4, 80), (1, 64, 640, 8, 5)])
+@pytest.mark.parametrize("B,HW,C,nh,ctx_len", [(2, 64, 1280, 8, 77), (3, 256, 1280, 8, 77), (2, 1024, 640, 8, 77), (2, 128, 640, 4, 80), (1, 64, 640, 8, 5),
+                                                 (8, 1024, 640, 8, 77)])     # (last: level 1 at the CFG batch 8 — both GEMMs on 256 ping-pong workgroups, per-sample weights)
 def test_cross_attention_folded_vs_torch(cuda, B, HW, C, nh, ctx_len):
   """norm2 -> attn2 (to_q, to_k / to_v of the prompt context, softmax, to_out) -> residual of a BasicTransformerBlock, computed by the two
   GEMMs the engine runs at UNet levels 1-3 — P = softmax80(LN(t) Mq_b^T) and out = t + P Wo_b^T + bo on weights folded per sample from
