@@ -1662,6 +1662,9 @@ static int gemm_qkv_pingpong_mi(const GemmArgs& a) {
   if (!gemm_pp_switch() || a.conv || a.out_mode != OUT_QKV || a.N % 160 != 0 || a.M % 256 != 0 || a.K % 64 != 0 || a.K < 640 || a.splitk > 1 || a.wb_rows || a.w_blk64) return 0;
   auto fill = [](int64_t wg) { return (double)wg / (double)(((wg + 255) / 256) * 256); };
   const double f128 = fill((int64_t)(a.M / 128) * (a.N / 160)), f256 = fill((int64_t)(a.M / 256) * (a.N / 160));
+  // ONE round only: several rounds of these tiles (level 1 at UNet batch 16: 768 workgroups) make the kernel faster and the card clock lower, like the
+  // 128-row form at batch 8 — loop 764.6 ms without, 767.3 ms with, 15-35 MHz apart (profiles/r06_skeleton_ab.log, session r06_s33)
+  if ((int64_t)(a.M / 256) * (a.N / 160) > 256) return 0;
   return (f256 >= 0.75 && f256 >= f128) ? 4 : 0;
 }
 
